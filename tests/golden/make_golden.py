@@ -1,0 +1,337 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in this directory by running the REAL reference.
+
+Runs only in the build container, where the reference is mounted read-only at /root/reference.
+It imports `vidgen` through `oracle/shim` (a stand-in for the un-installed fvcore / termcolor),
+loads seeded weights (tests/golden/seeded.py) into the reference's own modules, runs them on
+seeded inputs on CPU and stores inputs + outputs as small .npz files.  No reference source,
+bytecode or pickled reference object is written anywhere: fixtures are plain arrays.
+
+    python tests/golden/make_golden.py            # regenerate everything
+"""
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("LVT_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(ROOT, "oracle", "shim"))
+sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import seeded  # noqa: E402
+
+torch.manual_seed(0)
+META = {"torch": torch.__version__, "threads": torch.get_num_threads(),
+        "mkldnn": bool(torch.backends.mkldnn.is_available())}
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    out["_meta"] = np.frombuffer(json.dumps(META).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %-28s %8.1f KiB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def ref_cfg(path, **over):
+    from vidgen.config import get_cfg
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(REF, path))
+    cfg.MODEL.DEVICE = "cpu"
+    for k, v in over.items():
+        node = cfg
+        ks = k.split(".")
+        for s in ks[:-1]:
+            node = node[s]
+        node[ks[-1]] = v
+    return cfg
+
+
+def load_into(module, params):
+    missing, unexpected = module.load_state_dict(params, strict=False)
+    assert not unexpected, unexpected
+    # everything missing must be a non-parameter buffer
+    pnames = {n for n, _ in module.named_parameters()}
+    assert not (set(missing) & pnames), set(missing) & pnames
+
+
+def dealias_codebook(cb, state):
+    """Give the reference codebook GPU semantics on CPU: running_sum gets its own storage."""
+    for i, ve in enumerate(cb.ve):
+        ve.embedding.weight.data = state["ve.%d.embedding.weight" % i].clone()
+        ve.running_size = state["ve.%d.running_size" % i].clone()
+        ve.running_sum = state["ve.%d.running_sum" % i].clone()
+
+
+def cb_state_of(cb):
+    return {k: v.detach().clone() for k, v in cb.state_dict().items()}
+
+
+# ------------------------------------------------------------------------------------------------
+def golden_vqvae():
+    from vidgen.modeling.meta_arch.build import build_model
+    import vidgen.modeling.meta_arch  # noqa: F401  (registers the meta-archs)
+    from vidgen.utils.events import EventStorage
+
+    SEED = 1234
+    cfg = ref_cfg("configs/vqvae/PR-DVQVAE2.yaml")
+    model = build_model(cfg)
+    enc = seeded.seeded_params(seeded.VQVAE_ENCODER_SHAPES, SEED, "enc.")
+    dec = seeded.seeded_params(seeded.VQVAE_DECODER_SHAPES, SEED, "dec.")
+    load_into(model.encoder, enc)
+    load_into(model.generator, dec)
+
+    # G1 encoder ---------------------------------------------------------------------------------
+    x = seeded.seeded_input("g1.x", (2, 3, 64, 64), SEED, -1.0, 1.0)
+    with torch.no_grad():
+        z_e = model.encoder(x.clone())
+    save("g1_encoder", seed=SEED, x=x, z_e=z_e)
+    zstd = float(z_e.std())
+
+    # G2 vq nearest (standalone function, two codebook regimes) -----------------------------------
+    from vidgen.modeling.vq.vq_utils import vq
+    rows = z_e.permute(0, 2, 3, 1).contiguous()[..., :64].contiguous()      # (2,16,16,64)
+    cb_n = torch.from_numpy(seeded.seeded_array("g2.embedding", (512, 64), SEED)) * zstd
+    idx_n = vq(rows, cb_n)
+    cb_u = torch.from_numpy(seeded.seeded_input("g2.u", (512, 64), SEED, -1 / 512, 1 / 512).numpy())
+    idx_u = vq(rows, cb_u)   # reference's *initial* codebook regime: near-ties everywhere
+    save("g2_vq", seed=SEED, rows=rows, cb_normal=cb_n, idx_normal=idx_n, cb_uniform=cb_u, idx_uniform=idx_u)
+
+    # G3 DVQ 'st' one EMA step, de-aliased (GPU semantics) and aliased (reference-on-CPU quirk) ----
+    state0 = seeded.seeded_codebook_state(SEED, scale=zstd)
+    dealias_codebook(model.codebook, state0)
+    with torch.no_grad():
+        z_q_st, z_q_bar = model.codebook(z_e, "st")
+    st1 = cb_state_of(model.codebook)
+    # aliased: fresh module state where running_sum IS the weight storage (as constructed on CPU)
+    for i, ve in enumerate(model.codebook.ve):
+        ve.embedding.weight.data = state0["ve.%d.embedding.weight" % i].clone()
+        ve.running_size = state0["ve.%d.running_size" % i].clone()
+        ve.running_sum = ve.embedding.weight.detach()
+    with torch.no_grad():
+        a_st, a_bar = model.codebook(z_e, "st")
+    st1a = cb_state_of(model.codebook)
+    with torch.no_grad():
+        dealias_codebook(model.codebook, state0)
+        idx = model.codebook(z_e)          # mode "" -> (N,4,16,16)
+    save("g3_dvq_st", seed=SEED, scale=zstd, z_e=z_e, z_q_st=z_q_st, z_q_bar=z_q_bar, idx=idx,
+         aliased_z_q_bar=a_bar,
+         **{"new." + k: v for k, v in st1.items()}, **{"aliased." + k: v for k, v in st1a.items()})
+
+    # G4 decoder ---------------------------------------------------------------------------------
+    z = seeded.seeded_input("g4.z", (2, 256, 16, 16), SEED, -1.0, 1.0) * zstd
+    with torch.no_grad():
+        xt = model.generator(z.clone())
+    save("g4_decoder", seed=SEED, scale=zstd, z=z, x_tilde=xt)
+
+    # G5 full supervised loss + grads, B=2 frames and B=1 clip of 16 frames ------------------------
+    for tag, data in (("frames", [{"image": seeded.seeded_input("g5.f%d" % i, (3, 64, 64), SEED).numpy()}
+                                  for i in range(2)]),
+                      ("clip", [{"image_sequence": seeded.seeded_input("g5.c", (16, 3, 64, 64), SEED).numpy()}])):
+        dealias_codebook(model.codebook, state0)
+        model.zero_grad()
+        model.train()
+        with EventStorage(0):
+            losses = model(data, mode="supervised")
+        sum(losses.values()).backward()
+        g = {n: p.grad.clone() for n, p in list(model.encoder.named_parameters()) +
+             [("G." + n, p) for n, p in model.generator.named_parameters()]}
+        st = cb_state_of(model.codebook)
+        save("g5_vqvae_loss_" + tag, seed=SEED, scale=zstd,
+             loss_reconstruction=losses["loss_reconstruction"], loss_commitment=losses["loss_commitment"],
+             grad_enc_first=g["layers.0.weight"], grad_enc_first_bias=g["layers.0.bias"],
+             grad_enc_last=g["layers.6.block.3.weight"], grad_enc_mid_rows=g["layers.4.weight"][:8],
+             grad_dec_first_rows=g["G.layers.0.weight"][:8], grad_dec_last=g["G.layers.6.weight"],
+             grad_dec_last_bias=g["G.layers.6.bias"], grad_dec_ct1_rows=g["G.layers.4.weight"][:4],
+             grad_norms=np.array([float(v.norm()) for v in g.values()]),
+             grad_names=np.array(list(g.keys())),
+             **{"new." + k: v for k, v in st.items() if "ve.0." in k})
+
+    # G6 inference on the five example frames ------------------------------------------------------
+    from PIL import Image
+    imgs = np.stack([np.asarray(Image.open(os.path.join(REF, "example", "%d.png" % i)).convert("RGB"))
+                     for i in range(5)]).transpose(0, 3, 1, 2)              # (5,3,64,64) uint8
+    x01 = imgs.astype("float32") / 255.0
+    dealias_codebook(model.codebook, state0)
+    model.eval()
+    with torch.no_grad():
+        out = model([{"image_sequence": x01}], mode="inference")[0]
+        z_e6 = model.encoder(model.normalizer(torch.from_numpy(x01)))
+    save("g6_inference", seed=SEED, scale=zstd, frames_u8=imgs, latent=out["latent"],
+         reconstruction=out["reconstruction"], z_e=z_e6)
+
+
+# ------------------------------------------------------------------------------------------------
+def golden_vt():
+    from vidgen.modeling.meta_arch.build import build_model
+    import vidgen.modeling.meta_arch  # noqa: F401
+    from vidgen.modeling.autoregressive import vt_utils
+    from vidgen.modeling.autoregressive.vt_attention import PositionalEncoding
+    from vidgen.data.dataset_mapper import DatasetMapper
+    from vidgen.utils.events import EventStorage
+    import random
+
+    SEED = 4321
+    # G7 subscale helpers: DSFVT geometry (16,1,1)/(7,1,1) for all a, and a (4,2,2)/(3,3,3) one ------
+    vid = seeded.seeded_codes("g7.video", (1, 4, 16, 16, 16), SEED)
+    g7 = {"video": vid}
+    for a in range(16):
+        vm = vt_utils.visible_abc_mask(a, 0, 0, 16, 1, 1, 16, 16, 16, dtype=torch.bool)
+        ctx = vt_utils.ss_shift(vid.masked_fill(~vm, -1), a, 0, 0, 16, 1, 1, 16, 16, 16, 7, 1, 1, pad_value=-1)
+        g7["dsfvt_ctx_%d" % a] = ctx
+    vid2 = seeded.seeded_codes("g7.video2", (1, 2, 8, 8, 8), SEED)
+    g7["video2"] = vid2
+    for (a, b, c) in ((0, 0, 0), (1, 0, 1), (3, 1, 1), (2, 1, 0)):
+        sm = vt_utils.slice_mask(a, b, c, 4, 2, 2, 8, 8, 8, dtype=torch.bool)
+        vm = vt_utils.visible_abc_mask(a, b, c, 4, 2, 2, 8, 8, 8, dtype=torch.bool)
+        ctx = vt_utils.ss_shift(vid2.masked_fill(~vm, -1), a, b, c, 4, 2, 2, 8, 8, 8, 3, 3, 3, pad_value=-1)
+        g7["g422_smask_%d%d%d" % (a, b, c)] = sm
+        g7["g422_vmask_%d%d%d" % (a, b, c)] = vm
+        g7["g422_ctx_%d%d%d" % (a, b, c)] = ctx
+    save("g7_subscale", seed=SEED, **g7)
+
+    # G8 DatasetMapper prepare_slices for forced (a,b,c) ---------------------------------------------
+    cfg = ref_cfg("configs/vt/DSFVT.yaml")
+    mapper = DatasetMapper(cfg, True)
+    codes = seeded.seeded_codes("g8.codes", (16, 4, 16, 16), SEED).numpy()
+    g8 = {"codes": codes}
+    real_randint = random.randint
+    for a in (1, 2, 5, 9, 15):
+        seq = iter([0, a, 0, 0])  # start_end() draws first (dataset_mapper.py:44), then a, b, c
+        random.randint = lambda lo, hi: next(seq)
+        try:
+            d = mapper({"image_sequence": codes.copy()})
+        finally:
+            random.randint = real_randint
+        for k in ("context", "slice", "slice_idx", "ignore_mask"):
+            g8["a%d_%s" % (a, k)] = d[k]
+    save("g8_mapper", seed=SEED, **g8)
+
+    # model with seeded weights ------------------------------------------------------------------
+    model = build_model(cfg)
+    params = seeded.seeded_params(seeded.dsfvt_shapes(), SEED)
+    load_into(model.model, params)
+    vt = model.model
+
+    # G9 masked conv, positional table, get_B -----------------------------------------------------
+    xe = seeded.seeded_input("g9.x", (2, 128, 1, 16, 16), SEED, -1.0, 1.0)
+    with torch.no_grad():
+        yc = vt.decoder.conv(xe)
+        wmasked = vt.decoder.conv.conv.weight.detach().clone()
+        pe = PositionalEncoding(512)(torch.zeros(1, 512, 1, 16, 16))
+        pe3 = PositionalEncoding(48)(torch.zeros(1, 48, 3, 4, 5))
+        B = vt.decoder.block_local_attention[0].get_B()
+    save("g9_pieces", seed=SEED, x=xe, masked_conv_out=yc, masked_taps=wmasked[:4, :4],
+         pos_table=pe[0], pos_table_48_345=pe3[0], B_dec0_head3=B[3, 0], B_dec0_corner=B[:, 0, :4, :4])
+
+    # G10 one BlockLocalAttention layer, masked and unmasked, fwd + grads ---------------------------
+    for tag, layer in (("masked", vt.decoder.block_local_attention[0]),
+                       ("unmasked", vt.encoder.block_local_attention[0])):
+        x = seeded.seeded_input("g10.x." + tag, (2, 512, 1, 16, 16), SEED, -1.0, 1.0).requires_grad_(True)
+        gy = seeded.seeded_input("g10.gy." + tag, (2, 512, 1, 16, 16), SEED, -1.0, 1.0)
+        vt.zero_grad()
+        y = layer(x)
+        y.backward(gy)
+        save("g10_bla_" + tag, seed=SEED, x=x, gy=gy, y=y, grad_x=x.grad,
+             grad_w_q_h0=layer.mha.w_q.grad[0, :, :16], grad_w_v_h7=layer.mha.w_v.grad[7, :16],
+             grad_proj_rows=layer.mha.proj.weight.grad[:8], grad_dh_bank=layer.dh_bank.grad,
+             grad_dw_bank=layer.dw_bank.grad, grad_dt_bank=layer.dt_bank.grad,
+             grad_ln_w=layer.mha.layer_norm.weight.grad, grad_ln_b=layer.mha.layer_norm.bias.grad,
+             grad_ffn1_rows=layer.ffn[1].weight.grad[:8], grad_ffn3_b=layer.ffn[3].bias.grad,
+             grad_ffn0_w=layer.ffn[0].weight.grad)
+
+    # G11 channel predictor logits ----------------------------------------------------------------
+    sl = seeded.seeded_codes("g11.slice", (2, 4, 1, 16, 16), SEED)
+    yl = seeded.seeded_input("g11.yl", (2, 512, 1, 16, 16), SEED, -2.0, 2.0)
+    with torch.no_grad():
+        pred = vt.ch_predictor(sl, yl, mode="logits")
+    save("g11_chpred", seed=SEED, slice=sl, yl=yl, **{"logits_%d" % k: pred[k][:, :, 0, ::5, ::3] for k in range(4)},
+         logits_3_full_b0=pred[3][0])
+
+    # G12 full DSFVT supervised loss + grads at b=2 -------------------------------------------------
+    codes2 = [seeded.seeded_codes("g12.codes%d" % i, (16, 4, 16, 16), SEED).numpy() for i in range(2)]
+    data = []
+    for i, a in enumerate((3, 11)):
+        seq = iter([0, a, 0, 0])  # start_end() draws first (dataset_mapper.py:44), then a, b, c
+        random.randint = lambda lo, hi: next(seq)
+        try:
+            data.append(mapper({"image_sequence": codes2[i].copy()}))
+        finally:
+            random.randint = real_randint
+    model.train()
+    vt.zero_grad()
+    with EventStorage(0):
+        losses = model(data, mode="supervised")
+    losses["loss_cross_entropy"].backward()
+    with torch.no_grad():
+        ctx = torch.stack([d["context"] for d in data])
+        slc = torch.stack([d["slice"] for d in data])
+        sidx = torch.stack([d["slice_idx"] for d in data])
+        zl = vt.encoder(ctx, sidx)
+        yl2 = vt.decoder(slc, zl)
+        pred = vt.ch_predictor(slc, yl2, mode="logits")
+    names = [n for n, _ in vt.named_parameters()]
+    norms = np.array([float(p.grad.norm()) for _, p in vt.named_parameters()])
+    gd = dict(vt.named_parameters())
+    save("g12_dsfvt_loss", seed=SEED, codes=np.stack(codes2), a=np.array([3, 11]),
+         loss=losses["loss_cross_entropy"], zl_slice=zl[:, ::16, 0, ::4, ::4], yl_slice=yl2[:, ::16, 0, ::4, ::4],
+         logits0_slice=pred[0][:, ::8, 0, ::4, ::4], logits3_slice=pred[3][:, ::8, 0, ::4, ::4],
+         grad_names=np.array(names), grad_norms=norms,
+         grad_enc_conv_rows=gd["encoder.conv.weight"].grad[:2, :, :, 0, 0],
+         grad_slice_emb=gd["encoder.slice_embedding.weight"].grad,
+         grad_ch_emb0_rows=gd["decoder.ch_embedder.0.weight"].grad[:16],
+         grad_dec_conv_rows=gd["decoder.conv.conv.weight"].grad[:2],
+         grad_U3_rows=gd["ch_predictor.U.3.weight"].grad[:2],
+         grad_P0_bias=gd["ch_predictor.P.0.bias"].grad,
+         grad_dec7_dh=gd["decoder.block_local_attention.7.dh_bank"].grad,
+         grad_enc0_wq_h0=gd["encoder.block_local_attention.0.mha.w_q"].grad[0, :8])
+
+    # G13 sample_pixel probabilities for three pixels ----------------------------------------------
+    model.eval()
+    g13 = {}
+    with torch.no_grad():
+        b0 = 0
+        ctx1, sl1, si1 = ctx[b0:b0 + 1], slc[b0:b0 + 1].clone(), sidx[b0:b0 + 1]
+        zl1 = vt.encoder(ctx1, si1)
+        for (hi, wi) in ((0, 0), (7, 9), (15, 15)):
+            yl1 = vt.decoder(sl1, zl1)
+            y = vt.ch_predictor.layer_norm(yl1[:, :, 0, hi, wi])
+            # teacher-forced probabilities: feed the slice's own codes as the "previous draws"
+            oh = torch.nn.functional.one_hot(sl1[:, :, 0, hi, wi], 512).float().view(1, -1)
+            pr = []
+            for k in range(4):
+                inp = y if k == 0 else torch.cat((y, oh[:, :k * 512]), 1)
+                o = vt.ch_predictor.P[k](torch.relu(vt.ch_predictor.U[k](inp)))
+                pr.append(torch.softmax(o / 1.0, 1))
+            g13["probs_%d_%d" % (hi, wi)] = torch.stack(pr, 1)[0]
+    save("g13_sample_probs", seed=SEED, a=3, **g13)
+
+    # G14 logits for an entire video (BitsEvaluator input) -----------------------------------------
+    cfg2 = ref_cfg("configs/vt/DSFVT.yaml")
+    cfg2.TEST.EVALUATORS = "BitsEvaluator"
+    model.cfg = cfg2
+    with torch.no_grad():
+        out = model([{"image_sequence": torch.from_numpy(codes2[0])}], mode="inference")[0]
+    lg = out["logits"]                                                  # (4,512,16,16,16)
+    tgt = torch.from_numpy(codes2[0]).transpose(0, 1)                   # (4,16,16,16)
+    nll = torch.nn.functional.cross_entropy(lg.permute(1, 0, 2, 3, 4)[None], tgt[None], reduction="none")[0]
+    save("g14_video_logits", seed=SEED, logits_slice=lg[:, ::64, ::3, ::5, ::5], nll=nll,
+         ignore_mask=out["ignore_mask"])
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["vqvae", "vt"]
+    if "vqvae" in which:
+        golden_vqvae()
+    if "vt" in which:
+        golden_vt()
