@@ -1,0 +1,108 @@
+/*
+ * lvt_hip.h -- C ABI of liblvt_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the Latent Video
+ * Transformer hot path (VQ-VAE conv encoder/decoder + product vector-quantiser, DSFVT transformer).
+ *
+ * The reference (rakhimovv/lvt, python package `vidgen`) has NO native code and no FFI: its hot path
+ * dispatches torch ops.  Each entry point below replaces the torch
+ * op(s) named in its comment; `lvt_amd/hip/` binds them with ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative LVT_E* code; it never throws.  A message is
+ *     available from lvt_last_error().
+ *   - all pointers are DEVICE pointers to caller-owned, contiguous fp32 / int64 / int32 buffers;
+ *     nothing is allocated inside; scratch is a caller-provided workspace.
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*).
+ *   - activations are CHANNELS-LAST: (N, T, H, W, C) with C fastest; a frame batch is T == 1.
+ *   - arithmetic is fp32 with fp32 accumulation on the matrix cores (v_mfma_f32_32x32x2_f32).
+ */
+#ifndef LVT_HIP_H
+#define LVT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LVT_OK            0
+#define LVT_EINVAL      (-1)   /* bad argument (shape, alignment, null pointer)        */
+#define LVT_EWORKSPACE  (-2)   /* workspace too small                                  */
+#define LVT_ELAUNCH     (-3)   /* hipLaunchKernel / runtime error                      */
+#define LVT_ENODEVICE   (-4)   /* no gfx950 device visible                             */
+
+const char *lvt_last_error(void);
+int lvt_version(void);
+/* Device probe: name, CU count, clock (kHz), HBM bytes.  Returns LVT_ENODEVICE without a GPU. */
+int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long long *hbm_bytes);
+
+/* ---- epilogue flags shared by GEMM / conv ------------------------------------------------------ */
+#define LVT_EPI_BIAS        1   /* + bias[n]                                                  */
+#define LVT_EPI_RESIDUAL    2   /* + res[m][n]                                                 */
+#define LVT_EPI_RELU        4   /* max(.,0)                                                    */
+#define LVT_EPI_TANH        8   /* tanhf(.)                                                    */
+#define LVT_EPI_MASK       16   /* * (mask[m][n] > 0)   (ReLU backward with the saved output)  */
+#define LVT_EPI_ACCUM      32   /* C += result                                                 */
+
+/* ---- general batched fp32 GEMM  (torch addmm / bmm / matmul / linear: K14,K18,K20,K22-K25) -------
+ * C[z][m][n] = epilogue( alpha * sum_k A[z](m,k) * B[z](k,n) ),  z = zo*batch_inner + zi.
+ *   ta == 0: A(m,k) at A[m*lda + (k/a_kb)*a_skb + k%a_kb]   (k contiguous, optional 2-level k)
+ *   ta == 1: A(m,k) at A[k*lda + m]                         (m contiguous; M % 4 == 0)
+ *   tb == 0: B(k,n) at B[n*ldb + (k/b_kb)*b_skb + k%b_kb]   (k contiguous)
+ *   tb == 1: B(k,n) at B[k*ldb + n]                         (n contiguous; N % 4 == 0)
+ * K % 4 == 0, all leading dimensions % 4 == 0, pointers 16-byte aligned.
+ * splits > 1 partitions K; partial sums go to `workspace` and are reduced deterministically
+ * (epilogue flags other than ACCUM are then not allowed).                                         */
+typedef struct {
+    int M, N, K;
+    int ta, tb;
+    const float *A; long long lda; int a_kb; long long a_skb;
+    const float *B; long long ldb; int b_kb; long long b_skb;
+    float *C;       long long ldc;
+    int batch_outer, batch_inner;
+    long long sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
+    float alpha;
+    int flags;
+    const float *bias;
+    const float *res;  long long ldr;   /* batch strides of res / mask follow C's */
+    const float *mask; long long ldm;
+    int splits;
+} lvt_gemm_desc;
+size_t lvt_gemm_workspace_bytes(const lvt_gemm_desc *d);
+int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- 3-D convolution family, channels-last  (torch conv2d / conv3d / conv_transpose2d: K1-K6,K16) --
+ * Geometry of the *forward* convolution  y[n,to,ho,wo,co] = sum x[n,to*st-pt+kt, ...,ci] w[co,ci,kt,kh,kw].
+ * Ci / Co are the channel counts of the device buffers (multiples of 4; a 3-channel image is carried
+ * zero-padded to 4).  Packed weights wp are [Kt*Kh*Kw][Ci][Co] (lvt_conv3d_pack_weight).
+ * A ConvTranspose(in=a,out=b) layer is the bwd_data of the conv with Ci=b, Co=a (same weight tensor). */
+typedef struct {
+    int N, Ti, Hi, Wi, Ci;
+    int To, Ho, Wo, Co;
+    int Kt, Kh, Kw;
+    int st, sh, sw;
+    int pt, ph, pw;
+} lvt_conv_geom;
+/* w: [Co_real][Ci_real][Kt][Kh][Kw] (torch layout)  ->  wp: [taps][Ci][Co], zero padded.            */
+int lvt_conv3d_pack_weight(const lvt_conv_geom *g, const float *w, int Ci_real, int Co_real,
+                           float *wp, void *stream);
+/* y = epi( conv(x, wp) ); bias[Co]; res / y are (N,To,Ho,Wo,Co).  flags: BIAS|RESIDUAL|RELU|TANH.   */
+int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias,
+                   const float *res, float *y, int flags, void *stream);
+/* dx = epi( conv_transpose(dy, wp) ); res / mask / dx are (N,Ti,Hi,Wi,Ci).
+ * flags: BIAS (bias[Ci], used when this IS a ConvTranspose forward) | RESIDUAL | RELU | TANH | MASK.
+ * Requires Kt % st == 0 etc. and To*st == Ti-ish geometries produced by lvt_conv geometry helpers.  */
+int lvt_conv3d_bwd_data(const lvt_conv_geom *g, const float *dy, const float *wp, const float *bias,
+                        const float *res, const float *mask, float *dx, int flags, void *stream);
+/* dw[Co_real][Ci_real][Kt][Kh][Kw] = sum_pixels x (*) dy, deterministic split-K through workspace.  */
+size_t lvt_conv3d_bwd_weight_workspace_bytes(const lvt_conv_geom *g);
+int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, const float *dy, float *dw,
+                          int Ci_real, int Co_real, void *workspace, size_t workspace_bytes,
+                          void *stream);
+/* out[n] (+)= sum_m g[m*ld + n]  (bias gradients).  workspace >= lvt_colsum_workspace_bytes.        */
+size_t lvt_colsum_workspace_bytes(long long M, int N);
+int lvt_colsum(const float *g, long long M, int N, long long ld, float *out, void *workspace,
+               size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVT_HIP_H */

@@ -1,0 +1,781 @@
+// fp32 MFMA tile engine for gfx950: one LDS-tiled kernel template that serves
+//   * plain / batched GEMMs in NT, NN and TN form            (linear layers, QKV, attention matmuls)
+//   * implicit-GEMM 3-D convolution forward                  (im2col gather in the A loader)
+//   * convolution backward-data / ConvTranspose forward      (stride-phase decomposed gather)
+//   * convolution backward-weight                            (gather on the M side, split-K over pixels)
+//
+// Design (MI355X, wave64):
+//   - 256 threads = 4 waves per workgroup, 128x128 (or 128x32) output tile, BK = 32.
+//   - matrix core: v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles / SIMD).  A wave owns a 64x64
+//     sub-tile = 2x2 MFMA tiles = 64 accumulator registers.
+//   - both operands live in LDS "k-major" ([k][m], m contiguous) so that the per-MFMA operand
+//     fetch is one conflict-free ds_read_b32 per lane (lanes 0-31 -> 32 consecutive floats of row k,
+//     lanes 32-63 -> row k+1).  Row pads (+1 / +4 floats) make the transposing stores of the
+//     k-contiguous loaders conflict-free as well (cdna_hip_programming.md section 2).
+//   - global -> register -> LDS staging with the next tile's global loads issued before the MFMA
+//     block of the current tile (register prefetch); 16-byte loads along the contiguous dimension.
+//   - ~4 workgroups / CU resident (<=128 VGPR, 33 KiB LDS) hide the remaining latency.
+//   - split-K writes per-split partial tiles that a second kernel reduces in a fixed order, so
+//     weight gradients are bit-reproducible run to run (no float atomics).
+#include "lvt_common.h"
+#include <string.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 32
+#define NTHREADS 256
+
+enum { A_KPLAIN = 0, A_MPLAIN = 1, A_CONV_K = 2, A_CONVT_K = 3, A_CONV_M = 4 };
+enum { B_KPLAIN = 0, B_NPLAIN = 1, B_CONVT_W = 2 };
+
+struct KParams {
+    int M, N, K;
+    const float *A; long long lda; int a_kb; long long a_skb;
+    const float *B; long long ldb; int b_kb; long long b_skb;
+    float *C; long long ldc;
+    int batch_inner;
+    long long sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
+    float alpha; int flags;
+    const float *bias; const float *res; long long ldr; const float *mask; long long ldm;
+    int splits; int k_per_split; float *partial; long long partial_stride;
+    lvt_conv_geom g;
+    int Tq, Hq, Wq;          // A_CONVT_K: per-phase output extents
+    int jT, jH, jW;          // A_CONVT_K: taps per phase and dimension
+};
+
+__device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// ------------------------------------------------------------------------------------------------
+// A-side loaders.  K-contiguous modes fetch float4 along k and scatter 4 scalars into the k-major
+// LDS tile; M-contiguous modes fetch float4 along m and store it as one 16-byte LDS write.
+// ------------------------------------------------------------------------------------------------
+template <int MODE, int BM> struct ALoader;
+
+// ---- k-contiguous family: rows r0 + 32*i (i < BM/32), k quad kq = tid & 7 ------------------------
+template <int MODE, int BM> struct AKLoaderBase {
+    static constexpr int ITERS = BM / 32;
+    static constexpr int LD = BM + 1;
+    float4 v[ITERS];
+    int r0, kq;
+    __device__ __forceinline__ void store(float *lds) const {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int row = r0 + 32 * i;
+            lds[(kq * 4 + 0) * LD + row] = v[i].x;
+            lds[(kq * 4 + 1) * LD + row] = v[i].y;
+            lds[(kq * 4 + 2) * LD + row] = v[i].z;
+            lds[(kq * 4 + 3) * LD + row] = v[i].w;
+        }
+    }
+};
+
+template <int BM> struct ALoader<A_KPLAIN, BM> : AKLoaderBase<A_KPLAIN, BM> {
+    using Base = AKLoaderBase<A_KPLAIN, BM>;
+    const float *rowp[Base::ITERS];
+    bool rowok[Base::ITERS];
+    int kb; long long skb;
+    __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int) {
+        this->r0 = tid >> 3; this->kq = tid & 7;
+        kb = p.a_kb; skb = p.a_skb;
+#pragma unroll
+        for (int i = 0; i < Base::ITERS; ++i) {
+            const int m = m0 + this->r0 + 32 * i;
+            rowok[i] = m < p.M;
+            rowp[i] = A + (long long)m * p.lda;
+        }
+    }
+    __device__ __forceinline__ void fetch(int k0, int kend) {
+        const int k = k0 + this->kq * 4;
+        const bool kok = k < kend;
+        const long long koff = (long long)(k / kb) * skb + (k % kb);
+#pragma unroll
+        for (int i = 0; i < Base::ITERS; ++i)
+            this->v[i] = (kok && rowok[i]) ? ldg4(rowp[i] + koff) : zero4();
+    }
+};
+
+// forward convolution: row m -> (n,to,ho,wo); k -> (tap, ci)
+template <int BM> struct ALoader<A_CONV_K, BM> : AKLoaderBase<A_CONV_K, BM> {
+    using Base = AKLoaderBase<A_CONV_K, BM>;
+    long long nbase[Base::ITERS];
+    int ti0[Base::ITERS], hi0[Base::ITERS], wi0[Base::ITERS];
+    const float *x; lvt_conv_geom g;
+    __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int) {
+        this->r0 = tid >> 3; this->kq = tid & 7;
+        x = A; g = p.g;
+#pragma unroll
+        for (int i = 0; i < Base::ITERS; ++i) {
+            int m = m0 + this->r0 + 32 * i;
+            if (m < p.M) {
+                const int wo = m % g.Wo; m /= g.Wo;
+                const int ho = m % g.Ho; m /= g.Ho;
+                const int to = m % g.To; const int n = m / g.To;
+                ti0[i] = to * g.st - g.pt; hi0[i] = ho * g.sh - g.ph; wi0[i] = wo * g.sw - g.pw;
+                nbase[i] = (long long)n * g.Ti * g.Hi * g.Wi;
+            } else {
+                ti0[i] = -(1 << 28); hi0[i] = 0; wi0[i] = 0; nbase[i] = 0;
+            }
+        }
+    }
+    __device__ __forceinline__ void fetch(int k0, int kend) {
+        const int k = k0 + this->kq * 4;
+        const bool kok = k < kend;
+        int tap = k / g.Ci; const int ci = k - tap * g.Ci;
+        const int kw = tap % g.Kw; tap /= g.Kw;
+        const int kh = tap % g.Kh; const int kt = tap / g.Kh;
+#pragma unroll
+        for (int i = 0; i < Base::ITERS; ++i) {
+            const int ti = ti0[i] + kt, hi = hi0[i] + kh, wi = wi0[i] + kw;
+            const bool ok = kok && (unsigned)ti < (unsigned)g.Ti && (unsigned)hi < (unsigned)g.Hi &&
+                            (unsigned)wi < (unsigned)g.Wi;
+            const long long off = (nbase[i] + ((long long)ti * g.Hi + hi) * g.Wi + wi) * g.Ci + ci;
+            this->v[i] = ok ? ldg4(x + off) : zero4();
+        }
+    }
+};
+
+// backward-data / ConvTranspose forward.  Rows are dx positions of ONE stride phase (blockIdx.z):
+// i = s*q + r.  k -> (phase tap j, co); gathered dy position o = q + c - j per dimension.
+template <int BM> struct ALoader<A_CONVT_K, BM> : AKLoaderBase<A_CONVT_K, BM> {
+    using Base = AKLoaderBase<A_CONVT_K, BM>;
+    long long nbase[Base::ITERS];
+    int ot0[Base::ITERS], oh0[Base::ITERS], ow0[Base::ITERS];
+    const float *dy; lvt_conv_geom g; int jH, jW;
+    __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int cls) {
+        this->r0 = tid >> 3; this->kq = tid & 7;
+        dy = A; g = p.g; jH = p.jH; jW = p.jW;
+        const int fw = cls % g.sw, fh = (cls / g.sw) % g.sh, ft = cls / (g.sw * g.sh);
+        // r = (phi - p) mod s ; c = (r + p - phi) / s
+        const int rt = ((ft - g.pt) % g.st + g.st) % g.st, ct = (rt + g.pt - ft) / g.st;
+        const int rh = ((fh - g.ph) % g.sh + g.sh) % g.sh, ch = (rh + g.ph - fh) / g.sh;
+        const int rw = ((fw - g.pw) % g.sw + g.sw) % g.sw, cw = (rw + g.pw - fw) / g.sw;
+#pragma unroll
+        for (int i = 0; i < Base::ITERS; ++i) {
+            int m = m0 + this->r0 + 32 * i;
+            if (m < p.M) {
+                const int qw = m % p.Wq; m /= p.Wq;
+                const int qh = m % p.Hq; m /= p.Hq;
+                const int qt = m % p.Tq; const int n = m / p.Tq;
+                ot0[i] = qt + ct; oh0[i] = qh + ch; ow0[i] = qw + cw;
+                nbase[i] = (long long)n * g.To * g.Ho * g.Wo;
+            } else {
+                ot0[i] = -(1 << 28); oh0[i] = 0; ow0[i] = 0; nbase[i] = 0;
+            }
+        }
+    }
+    __device__ __forceinline__ void fetch(int k0, int kend) {
+        const int k = k0 + this->kq * 4;
+        const bool kok = k < kend;
+        int tap = k / g.Co; const int co = k - tap * g.Co;
+        const int jw = tap % jW; tap /= jW;
+        const int jh = tap % jH; const int jt = tap / jH;
+#pragma unroll
+        for (int i = 0; i < Base::ITERS; ++i) {
+            const int ot = ot0[i] - jt, oh = oh0[i] - jh, ow = ow0[i] - jw;
+            const bool ok = kok && (unsigned)ot < (unsigned)g.To && (unsigned)oh < (unsigned)g.Ho &&
+                            (unsigned)ow < (unsigned)g.Wo;
+            const long long off = (nbase[i] + ((long long)ot * g.Ho + oh) * g.Wo + ow) * g.Co + co;
+            this->v[i] = ok ? ldg4(dy + off) : zero4();
+        }
+    }
+};
+
+// ---- m-contiguous family: k rows kk0 + KPP*i, m quad mq -----------------------------------------
+template <int BM> struct AMLoaderBase {
+    static constexpr int UPK = BM / 4;              // float4 units per k row
+    static constexpr int KPP = NTHREADS / UPK;      // k rows per pass
+    static constexpr int ITERS = BK / KPP;
+    static constexpr int LD = BM + 4;
+    float4 v[ITERS];
+    int kk0, mq;
+    __device__ __forceinline__ void store(float *lds) const {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i)
+            *reinterpret_cast<float4 *>(&lds[(kk0 + KPP * i) * LD + mq * 4]) = v[i];
+    }
+};
+
+template <int BM> struct ALoader<A_MPLAIN, BM> : AMLoaderBase<BM> {
+    using Base = AMLoaderBase<BM>;
+    const float *colp; bool mok; long long lda;
+    __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int) {
+        this->kk0 = tid / Base::UPK; this->mq = tid % Base::UPK;
+        const int m = m0 + this->mq * 4;
+        mok = m < p.M; colp = A + m; lda = p.lda;
+    }
+    __device__ __forceinline__ void fetch(int k0, int kend) {
+#pragma unroll
+        for (int i = 0; i < Base::ITERS; ++i) {
+            const int k = k0 + this->kk0 + Base::KPP * i;
+            this->v[i] = (mok && k < kend) ? ldg4(colp + (long long)k * lda) : zero4();
+        }
+    }
+};
+
+// backward-weight: GEMM row = (tap, ci), GEMM k = output pixel (n,to,ho,wo)
+template <int BM> struct ALoader<A_CONV_M, BM> : AMLoaderBase<BM> {
+    using Base = AMLoaderBase<BM>;
+    const float *x; lvt_conv_geom g; bool mok; int kt, kh, kw, ci;
+    __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int) {
+        this->kk0 = tid / Base::UPK; this->mq = tid % Base::UPK;
+        x = A; g = p.g;
+        const int m = m0 + this->mq * 4;
+        mok = m < p.M;
+        int tap = m / g.Ci; ci = m - tap * g.Ci;
+        kw = tap % g.Kw; tap /= g.Kw;
+        kh = tap % g.Kh; kt = tap / g.Kh;
+    }
+    __device__ __forceinline__ void fetch(int k0, int kend) {
+#pragma unroll
+        for (int i = 0; i < Base::ITERS; ++i) {
+            int pix = k0 + this->kk0 + Base::KPP * i;
+            bool ok = mok && pix < kend;
+            const int wo = pix % g.Wo; pix /= g.Wo;
+            const int ho = pix % g.Ho; pix /= g.Ho;
+            const int to = pix % g.To; const int n = pix / g.To;
+            const int ti = to * g.st - g.pt + kt, hi = ho * g.sh - g.ph + kh, wi = wo * g.sw - g.pw + kw;
+            ok = ok && (unsigned)ti < (unsigned)g.Ti && (unsigned)hi < (unsigned)g.Hi &&
+                 (unsigned)wi < (unsigned)g.Wi;
+            const long long off = ((((long long)n * g.Ti + ti) * g.Hi + hi) * g.Wi + wi) * g.Ci + ci;
+            this->v[i] = ok ? ldg4(x + off) : zero4();
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// B-side loaders
+// ------------------------------------------------------------------------------------------------
+template <int MODE, int BN> struct BLoader;
+
+template <int BN> struct BKLoaderBase {
+    static constexpr int ITERS = (BN >= 32) ? BN / 32 : 1;
+    static constexpr int LD = BN + 1;
+    float4 v[ITERS];
+    int r0, kq;
+    __device__ __forceinline__ void store(float *lds) const {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int row = r0 + 32 * i;
+            lds[(kq * 4 + 0) * LD + row] = v[i].x;
+            lds[(kq * 4 + 1) * LD + row] = v[i].y;
+            lds[(kq * 4 + 2) * LD + row] = v[i].z;
+            lds[(kq * 4 + 3) * LD + row] = v[i].w;
+        }
+    }
+};
+
+template <int BN> struct BLoader<B_KPLAIN, BN> : BKLoaderBase<BN> {
+    using Base = BKLoaderBase<BN>;
+    const float *rowp[Base::ITERS]; bool rowok[Base::ITERS]; int kb; long long skb;
+    __device__ __forceinline__ void init(const KParams &p, int tid, int n0, const float *B, int) {
+        this->r0 = tid >> 3; this->kq = tid & 7;
+        kb = p.b_kb; skb = p.b_skb;
+#pragma unroll
+        for (int i = 0; i < Base::ITERS; ++i) {
+            const int n = n0 + this->r0 + 32 * i;
+            rowok[i] = n < p.N;
+            rowp[i] = B + (long long)n * p.ldb;
+        }
+    }
+    __device__ __forceinline__ void fetch(int k0, int kend) {
+        const int k = k0 + this->kq * 4;
+        const bool kok = k < kend;
+        const long long koff = (long long)(k / kb) * skb + (k % kb);
+#pragma unroll
+        for (int i = 0; i < Base::ITERS; ++i)
+            this->v[i] = (kok && rowok[i]) ? ldg4(rowp[i] + koff) : zero4();
+    }
+};
+
+// packed conv weights wp[tap][ci][co] read as B(k=(phase tap j, co), n=ci) for one stride phase
+template <int BN> struct BLoader<B_CONVT_W, BN> : BKLoaderBase<BN> {
+    using Base = BKLoaderBase<BN>;
+    const float *wp; lvt_conv_geom g; int jH, jW, ft, fh, fw;
+    int nrow[Base::ITERS]; bool rowok[Base::ITERS];
+    __device__ __forceinline__ void init(const KParams &p, int tid, int n0, const float *B, int cls) {
+        this->r0 = tid >> 3; this->kq = tid & 7;
+        wp = B; g = p.g; jH = p.jH; jW = p.jW;
+        fw = cls % g.sw; fh = (cls / g.sw) % g.sh; ft = cls / (g.sw * g.sh);
+#pragma unroll
+        for (int i = 0; i < Base::ITERS; ++i) {
+            nrow[i] = n0 + this->r0 + 32 * i;
+            rowok[i] = nrow[i] < p.N;
+        }
+    }
+    __device__ __forceinline__ void fetch(int k0, int kend) {
+        const int k = k0 + this->kq * 4;
+        const bool kok = k < kend;
+        int tap = k / g.Co; const int co = k - tap * g.Co;
+        const int jw = tap % jW; tap /= jW;
+        const int jh = tap % jH; const int jt = tap / jH;
+        const int kt = ft + g.st * jt, kh = fh + g.sh * jh, kw = fw + g.sw * jw;
+        const long long tapa = ((long long)kt * g.Kh + kh) * g.Kw + kw;
+#pragma unroll
+        for (int i = 0; i < Base::ITERS; ++i)
+            this->v[i] = (kok && rowok[i]) ? ldg4(wp + (tapa * g.Ci + nrow[i]) * g.Co + co) : zero4();
+    }
+};
+
+template <int BN> struct BLoader<B_NPLAIN, BN> {
+    static constexpr int UPK = BN / 4;
+    static constexpr int KPP = (NTHREADS / UPK) > BK ? BK : (NTHREADS / UPK);
+    static constexpr int ITERS = BK / KPP;
+    static constexpr int LD = BN + 4;
+    float4 v[ITERS];
+    int kk0, nq; bool active;
+    const float *colp; bool nok; long long ldb;
+    __device__ __forceinline__ void init(const KParams &p, int tid, int n0, const float *B, int) {
+        kk0 = tid / UPK; nq = tid % UPK;
+        active = kk0 < BK;
+        const int n = n0 + nq * 4;
+        nok = active && n < p.N; colp = B + n; ldb = p.ldb;
+    }
+    __device__ __forceinline__ void fetch(int k0, int kend) {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int k = k0 + kk0 + KPP * i;
+            v[i] = (nok && k < kend) ? ldg4(colp + (long long)k * ldb) : zero4();
+        }
+    }
+    __device__ __forceinline__ void store(float *lds) const {
+        if (!active) return;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i)
+            *reinterpret_cast<float4 *>(&lds[(kk0 + KPP * i) * LD + nq * 4]) = v[i];
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------------
+template <int AMODE, int BMODE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS) void lvt_gemm_kernel(const KParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    using AL = ALoader<AMODE, BM>;
+    using BL = BLoader<BMODE, BN>;
+    constexpr int LDA = AL::LD, LDB = BL::LD;
+    __shared__ __attribute__((aligned(16))) float lds[BK * LDA + BK * LDB + 8];
+    float *As = lds;
+    float *Bs = lds + ((BK * LDA + 3) & ~3);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // blockIdx.x -> (m tile, n tile): n fastest so that consecutive workgroups share the A panel
+    const int ntn = (p.N + BN - 1) / BN;
+    const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    int z = blockIdx.y;                 // batch (or conv phase class)
+    const int split = blockIdx.z;
+
+    const float *A = p.A, *B = p.B;
+    long long coff = 0;
+    int cls = 0;
+    if (AMODE == A_CONVT_K) {
+        cls = z;
+    } else {
+        const int zo = z / p.batch_inner, zi = z % p.batch_inner;
+        A += zo * p.sA_o + zi * p.sA_i;
+        B += zo * p.sB_o + zi * p.sB_i;
+        coff = zo * p.sC_o + zi * p.sC_i;
+    }
+
+    int kbeg = 0, kend = p.K;
+    if (p.splits > 1) {
+        kbeg = split * p.k_per_split;
+        kend = min(p.K, kbeg + p.k_per_split);
+    }
+
+    AL al; BL bl;
+    al.init(p, tid, m0, A, cls);
+    bl.init(p, tid, n0, B, cls);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kbeg < kend) {
+        al.fetch(kbeg, kend); bl.fetch(kbeg, kend);
+        al.store(As); bl.store(Bs);
+    }
+    __syncthreads();
+
+    const float *Ard = As + half * LDA + wm * (TM * 32) + l31;
+    const float *Brd = Bs + half * LDB + wn * (TN * 32) + l31;
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool has_next = k0 + BK < kend;
+        if (has_next) { al.fetch(k0 + BK, kend); bl.fetch(k0 + BK, kend); }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = Ard[kk * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Brd[kk * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (has_next) { al.store(As); bl.store(Bs); }
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    // ConvTranspose phase: decode the phase-ordered row into the channels-last dx row.
+    int fw = 0, fh = 0, ft = 0, rt = 0, rh = 0, rw = 0;
+    if (AMODE == A_CONVT_K) {
+        const lvt_conv_geom &g = p.g;
+        fw = cls % g.sw; fh = (cls / g.sw) % g.sh; ft = cls / (g.sw * g.sh);
+        rt = ((ft - g.pt) % g.st + g.st) % g.st;
+        rh = ((fh - g.ph) % g.sh + g.sh) % g.sh;
+        rw = ((fw - g.pw) % g.sw + g.sw) % g.sw;
+    }
+    const int flags = p.flags;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row >= p.M) continue;
+            long long orow = row;
+            if (AMODE == A_CONVT_K) {
+                const lvt_conv_geom &g = p.g;
+                int m = row;
+                const int qw = m % p.Wq; m /= p.Wq;
+                const int qh = m % p.Hq; m /= p.Hq;
+                const int qt = m % p.Tq; const int n = m / p.Tq;
+                orow = (((long long)n * g.Ti + (g.st * qt + rt)) * g.Hi + (g.sh * qh + rh)) * g.Wi +
+                       (g.sw * qw + rw);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (TN * 32) + j * 32 + l31;
+                if (col >= p.N) continue;
+                float v = acc[i][j][r];
+                if (p.splits > 1) {
+                    p.partial[split * p.partial_stride + (long long)z * p.M * p.N + orow * p.N + col] = v;
+                    continue;
+                }
+                v *= p.alpha;
+                if (flags & LVT_EPI_BIAS) v += p.bias[col];
+                if (flags & LVT_EPI_RESIDUAL) v += p.res[coff + orow * p.ldr + col];
+                if (flags & LVT_EPI_RELU) v = fmaxf(v, 0.f);
+                if (flags & LVT_EPI_TANH) v = tanhf(v);
+                if (flags & LVT_EPI_MASK) v = (p.mask[coff + orow * p.ldm + col] > 0.f) ? v : 0.f;
+                float *cp = p.C + coff + orow * p.ldc + col;
+                if (flags & LVT_EPI_ACCUM) v += *cp;
+                *cp = v;
+            }
+        }
+    }
+}
+
+// deterministic split-K reduction: out[i] (+)= sum_s partial[s][i]
+__global__ void lvt_reduce_splits_kernel(const float *__restrict__ partial, long long n4, long long stride,
+                                         int splits, float *__restrict__ out, int accumulate) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < n4; i += step) {
+        float4 s = ldg4(partial + i * 4);
+        for (int k = 1; k < splits; ++k) {
+            const float4 t = ldg4(partial + k * stride + i * 4);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        float4 *o = reinterpret_cast<float4 *>(out + i * 4);
+        if (accumulate) { const float4 c = *o; s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w; }
+        *o = s;
+    }
+}
+
+// conv weight pack / unpack -----------------------------------------------------------------------
+// w[co][ci][tap] -> wp[tap][ci_pad][co_pad]
+__global__ void lvt_pack_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int taps, int Ci,
+                                       int Co, int Ci_real, int Co_real) {
+    const long long total = (long long)taps * Ci * Co;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int co = i % Co; long long t = i / Co;
+        const int ci = t % Ci; const int tap = t / Ci;
+        float v = 0.f;
+        if (co < Co_real && ci < Ci_real) v = w[((long long)co * Ci_real + ci) * taps + tap];
+        wp[i] = v;
+    }
+}
+// partial[split][(tap,ci)][co] -> dw[co][ci][tap]   (fixed summation order over splits)
+__global__ void lvt_unpack_wgrad_kernel(const float *__restrict__ partial, long long stride, int splits,
+                                        float *__restrict__ dw, int taps, int Ci, int Co, int Ci_real,
+                                        int Co_real) {
+    const long long total = (long long)Co_real * Ci_real * taps;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int tap = i % taps; long long t = i / taps;
+        const int ci = t % Ci_real; const int co = t / Ci_real;
+        const long long src = ((long long)tap * Ci + ci) * Co + co;
+        float s = partial[src];
+        for (int k = 1; k < splits; ++k) s += partial[k * stride + src];
+        dw[i] = s;
+    }
+}
+
+// column sums (bias gradients): stage 1 partial[blk][n] over row chunks, stage 2 fixed-order reduce
+__global__ void lvt_colsum_kernel(const float *__restrict__ g, long long M, int N, long long ld,
+                                  long long rows_per_block, float *__restrict__ partial) {
+    const long long r0 = blockIdx.y * rows_per_block;
+    const long long r1 = min(M, r0 + rows_per_block);
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (long long r = r0; r < r1; ++r) s += g[r * ld + n];
+        partial[(long long)blockIdx.y * N + n] = s;
+    }
+}
+__global__ void lvt_colsum_final_kernel(const float *__restrict__ partial, int nblk, int N,
+                                        float *__restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * N + n];
+    out[n] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <int AMODE, int BMODE, int BM, int BN, int WM, int WN>
+static int launch_tile(const KParams &p, int zcount, hipStream_t s) {
+    const long long ntm = lvt_cdiv(p.M, BM), ntn = lvt_cdiv(p.N, BN);
+    if (ntm * ntn > 0x7fffffffLL || zcount > 65535 || p.splits > 65535) {
+        lvt_set_error("gemm: grid too large (%lld tiles, z=%d, splits=%d)", ntm * ntn, zcount, p.splits);
+        return LVT_EINVAL;
+    }
+    dim3 grid((unsigned)(ntm * ntn), (unsigned)zcount, (unsigned)(p.splits > 1 ? p.splits : 1));
+    hipLaunchKernelGGL((lvt_gemm_kernel<AMODE, BMODE, BM, BN, WM, WN>), grid, dim3(NTHREADS), 0, s, p);
+    LVT_CHECK_LAUNCH("lvt_gemm_kernel");
+    return LVT_OK;
+}
+
+static int choose_splits(long long tiles, int K, int min_k) {
+    // enough workgroups to cover the chip ~3x, but never less than min_k of reduction per split
+    int s = (int)lvt_cdiv(3 * LVT_NUM_CU, tiles);
+    const int maxs = K / min_k > 0 ? K / min_k : 1;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    return s;
+}
+
+static void kparams_from_desc(const lvt_gemm_desc *d, KParams &p) {
+    memset(&p, 0, sizeof(p));
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.A = d->A; p.lda = d->lda; p.a_kb = d->a_kb > 0 ? d->a_kb : d->K; p.a_skb = d->a_skb;
+    p.B = d->B; p.ldb = d->ldb; p.b_kb = d->b_kb > 0 ? d->b_kb : d->K; p.b_skb = d->b_skb;
+    p.C = d->C; p.ldc = d->ldc;
+    p.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;
+    p.sA_o = d->sA_o; p.sA_i = d->sA_i; p.sB_o = d->sB_o; p.sB_i = d->sB_i; p.sC_o = d->sC_o; p.sC_i = d->sC_i;
+    p.alpha = d->alpha; p.flags = d->flags; p.bias = d->bias; p.res = d->res; p.ldr = d->ldr;
+    p.mask = d->mask; p.ldm = d->ldm;
+    p.splits = d->splits > 1 ? d->splits : 1;
+}
+
+static int gemm_batch(const lvt_gemm_desc *d) {
+    return (d->batch_outer > 0 ? d->batch_outer : 1) * (d->batch_inner > 0 ? d->batch_inner : 1);
+}
+
+extern "C" size_t lvt_gemm_workspace_bytes(const lvt_gemm_desc *d) {
+    if (!d || d->splits <= 1) return 0;
+    return (size_t)d->splits * gemm_batch(d) * (size_t)d->M * d->N * sizeof(float);
+}
+
+extern "C" int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t workspace_bytes, void *stream) {
+    LVT_REQUIRE(d && d->A && d->B && d->C, "gemm: null pointer");
+    LVT_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: bad shape %d %d %d", d->M, d->N, d->K);
+    LVT_REQUIRE(d->K % 4 == 0, "gemm: K=%d must be a multiple of 4", d->K);
+    LVT_REQUIRE(d->lda % 4 == 0 && d->ldb % 4 == 0, "gemm: lda/ldb must be multiples of 4");
+    LVT_REQUIRE(lvt_aligned16(d->A) && lvt_aligned16(d->B), "gemm: A/B must be 16-byte aligned");
+    LVT_REQUIRE(d->ta == 0 || d->M % 4 == 0, "gemm: ta=1 needs M %% 4 == 0");
+    LVT_REQUIRE(d->tb == 0 || d->N % 4 == 0, "gemm: tb=1 needs N %% 4 == 0");
+    LVT_REQUIRE(d->a_kb <= 0 || (d->a_kb % 4 == 0 && d->a_skb % 4 == 0), "gemm: a_kb/a_skb %% 4");
+    LVT_REQUIRE(d->b_kb <= 0 || (d->b_kb % 4 == 0 && d->b_skb % 4 == 0), "gemm: b_kb/b_skb %% 4");
+    LVT_REQUIRE(!(d->ta == 1 && d->tb == 0), "gemm: (ta=1, tb=0) is not instantiated");
+    LVT_REQUIRE(!(d->flags & LVT_EPI_BIAS) || d->bias, "gemm: BIAS flag without bias");
+    LVT_REQUIRE(!(d->flags & LVT_EPI_RESIDUAL) || d->res, "gemm: RESIDUAL flag without res");
+    LVT_REQUIRE(!(d->flags & LVT_EPI_MASK) || d->mask, "gemm: MASK flag without mask");
+    hipStream_t s = (hipStream_t)stream;
+    KParams p; kparams_from_desc(d, p);
+    const int zc = gemm_batch(d);
+    if (p.splits > 1) {
+        LVT_REQUIRE((d->flags & ~LVT_EPI_ACCUM) == 0 && d->alpha == 1.0f, "gemm: split-K allows only ACCUM");
+        LVT_REQUIRE(d->ldc == d->N && (zc == 1 || (d->sC_i == (long long)d->M * d->N)),
+                    "gemm: split-K needs a dense C (ldc == N)");
+        LVT_REQUIRE(((long long)d->M * d->N) % 4 == 0 && lvt_aligned16(d->C), "gemm: split-K C alignment");
+        const size_t need = lvt_gemm_workspace_bytes(d);
+        if (workspace_bytes < need || !workspace) {
+            lvt_set_error("gemm: workspace %zu < %zu", workspace_bytes, need);
+            return LVT_EWORKSPACE;
+        }
+        p.k_per_split = (int)(lvt_cdiv(lvt_cdiv(p.K, p.splits), BK) * BK);
+        p.partial = (float *)workspace;
+        p.partial_stride = (long long)zc * d->M * d->N;
+    }
+    int rc;
+    if (d->ta == 0 && d->tb == 0) rc = launch_tile<A_KPLAIN, B_KPLAIN, 128, 128, 2, 2>(p, zc, s);
+    else if (d->ta == 0 && d->tb == 1) rc = launch_tile<A_KPLAIN, B_NPLAIN, 128, 128, 2, 2>(p, zc, s);
+    else rc = launch_tile<A_MPLAIN, B_NPLAIN, 128, 128, 2, 2>(p, zc, s);
+    if (rc != LVT_OK) return rc;
+    if (p.splits > 1) {
+        const long long n4 = p.partial_stride / 4;
+        const int blocks = (int)(lvt_cdiv(n4, 256) < 2048 ? lvt_cdiv(n4, 256) : 2048);
+        // batches are laid out z-major in the partial buffer exactly like a dense C
+        hipLaunchKernelGGL(lvt_reduce_splits_kernel, dim3(blocks), dim3(256), 0, s, p.partial, n4,
+                           p.partial_stride, p.splits, d->C, (d->flags & LVT_EPI_ACCUM) ? 1 : 0);
+        LVT_CHECK_LAUNCH("lvt_reduce_splits_kernel");
+    }
+    return LVT_OK;
+}
+
+// ---- convolution entry points -------------------------------------------------------------------
+static int check_geom(const lvt_conv_geom *g, const char *who) {
+    LVT_REQUIRE(g, "%s: null geometry", who);
+    LVT_REQUIRE(g->N > 0 && g->Ti > 0 && g->Hi > 0 && g->Wi > 0 && g->To > 0 && g->Ho > 0 && g->Wo > 0,
+                "%s: bad extents", who);
+    LVT_REQUIRE(g->Ci > 0 && g->Co > 0 && g->Ci % 4 == 0 && g->Co % 4 == 0, "%s: Ci=%d/Co=%d must be multiples of 4",
+                who, g->Ci, g->Co);
+    LVT_REQUIRE(g->Kt > 0 && g->Kh > 0 && g->Kw > 0 && g->st > 0 && g->sh > 0 && g->sw > 0, "%s: bad kernel/stride", who);
+    return LVT_OK;
+}
+
+extern "C" int lvt_conv3d_pack_weight(const lvt_conv_geom *g, const float *w, int Ci_real, int Co_real,
+                                      float *wp, void *stream) {
+    int rc = check_geom(g, "pack_weight"); if (rc) return rc;
+    LVT_REQUIRE(w && wp && Ci_real <= g->Ci && Co_real <= g->Co, "pack_weight: bad args");
+    const int taps = g->Kt * g->Kh * g->Kw;
+    const long long total = (long long)taps * g->Ci * g->Co;
+    const int blocks = (int)(lvt_cdiv(total, 256) < 4096 ? lvt_cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(lvt_pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, taps,
+                       g->Ci, g->Co, Ci_real, Co_real);
+    LVT_CHECK_LAUNCH("lvt_pack_weight_kernel");
+    return LVT_OK;
+}
+
+extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias,
+                              const float *res, float *y, int flags, void *stream) {
+    int rc = check_geom(g, "conv3d_fwd"); if (rc) return rc;
+    LVT_REQUIRE(x && wp && y, "conv3d_fwd: null pointer");
+    LVT_REQUIRE(!(flags & LVT_EPI_BIAS) || bias, "conv3d_fwd: BIAS without bias");
+    LVT_REQUIRE(!(flags & LVT_EPI_RESIDUAL) || res, "conv3d_fwd: RESIDUAL without res");
+    LVT_REQUIRE(!(flags & (LVT_EPI_MASK | LVT_EPI_ACCUM)), "conv3d_fwd: unsupported flag");
+    const long long M = (long long)g->N * g->To * g->Ho * g->Wo;
+    LVT_REQUIRE(M < 0x7fffffffLL, "conv3d_fwd: too many output positions");
+    KParams p; memset(&p, 0, sizeof(p));
+    p.M = (int)M; p.N = g->Co; p.K = g->Kt * g->Kh * g->Kw * g->Ci;
+    p.A = x; p.B = wp; p.ldb = g->Co; p.C = y; p.ldc = g->Co; p.batch_inner = 1;
+    p.alpha = 1.f; p.flags = flags; p.bias = bias; p.res = res; p.ldr = g->Co; p.splits = 1; p.g = *g;
+    if (g->Co <= 32) return launch_tile<A_CONV_K, B_NPLAIN, 128, 32, 4, 1>(p, 1, (hipStream_t)stream);
+    return launch_tile<A_CONV_K, B_NPLAIN, 128, 128, 2, 2>(p, 1, (hipStream_t)stream);
+}
+
+extern "C" int lvt_conv3d_bwd_data(const lvt_conv_geom *g, const float *dy, const float *wp, const float *bias,
+                                   const float *res, const float *mask, float *dx, int flags, void *stream) {
+    int rc = check_geom(g, "conv3d_bwd_data"); if (rc) return rc;
+    LVT_REQUIRE(dy && wp && dx, "conv3d_bwd_data: null pointer");
+    LVT_REQUIRE(g->Kt % g->st == 0 && g->Kh % g->sh == 0 && g->Kw % g->sw == 0,
+                "conv3d_bwd_data: kernel extents must be multiples of the strides");
+    LVT_REQUIRE(g->Ti % g->st == 0 && g->Hi % g->sh == 0 && g->Wi % g->sw == 0,
+                "conv3d_bwd_data: input extents must be multiples of the strides");
+    LVT_REQUIRE(!(flags & LVT_EPI_BIAS) || bias, "conv3d_bwd_data: BIAS without bias");
+    LVT_REQUIRE(!(flags & LVT_EPI_RESIDUAL) || res, "conv3d_bwd_data: RESIDUAL without res");
+    LVT_REQUIRE(!(flags & LVT_EPI_MASK) || mask, "conv3d_bwd_data: MASK without mask");
+    LVT_REQUIRE(!(flags & LVT_EPI_ACCUM), "conv3d_bwd_data: unsupported flag");
+    KParams p; memset(&p, 0, sizeof(p));
+    p.Tq = g->Ti / g->st; p.Hq = g->Hi / g->sh; p.Wq = g->Wi / g->sw;
+    p.jT = g->Kt / g->st; p.jH = g->Kh / g->sh; p.jW = g->Kw / g->sw;
+    const long long M = (long long)g->N * p.Tq * p.Hq * p.Wq;
+    LVT_REQUIRE(M < 0x7fffffffLL, "conv3d_bwd_data: too many positions");
+    p.M = (int)M; p.N = g->Ci; p.K = p.jT * p.jH * p.jW * g->Co;
+    p.A = dy; p.B = wp; p.C = dx; p.ldc = g->Ci; p.batch_inner = 1;
+    p.alpha = 1.f; p.flags = flags; p.bias = bias; p.res = res; p.ldr = g->Ci; p.mask = mask; p.ldm = g->Ci;
+    p.splits = 1; p.g = *g;
+    const int ncls = g->st * g->sh * g->sw;
+    if (g->Ci <= 32) return launch_tile<A_CONVT_K, B_CONVT_W, 128, 32, 4, 1>(p, ncls, (hipStream_t)stream);
+    return launch_tile<A_CONVT_K, B_CONVT_W, 128, 128, 2, 2>(p, ncls, (hipStream_t)stream);
+}
+
+static int bwd_weight_splits(const lvt_conv_geom *g) {
+    const long long Mg = (long long)g->Kt * g->Kh * g->Kw * g->Ci;
+    const long long tiles = lvt_cdiv(Mg, 128) * lvt_cdiv(g->Co, 128);
+    const long long pix = (long long)g->N * g->To * g->Ho * g->Wo;
+    const int s = choose_splits(tiles, (int)(pix < 0x7fffffffLL ? pix : 0x7fffffff), 512);
+    return s < 2 ? 2 : s;   // always go through the partial buffer (the unpack kernel reduces it)
+}
+
+extern "C" size_t lvt_conv3d_bwd_weight_workspace_bytes(const lvt_conv_geom *g) {
+    if (!g) return 0;
+    const long long Mg = (long long)g->Kt * g->Kh * g->Kw * g->Ci;
+    return (size_t)bwd_weight_splits(g) * Mg * g->Co * sizeof(float);
+}
+
+extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, const float *dy, float *dw,
+                                     int Ci_real, int Co_real, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
+    int rc = check_geom(g, "conv3d_bwd_weight"); if (rc) return rc;
+    LVT_REQUIRE(x && dy && dw && Ci_real <= g->Ci && Co_real <= g->Co, "conv3d_bwd_weight: bad args");
+    const size_t need = lvt_conv3d_bwd_weight_workspace_bytes(g);
+    if (!workspace || workspace_bytes < need) {
+        lvt_set_error("conv3d_bwd_weight: workspace %zu < %zu", workspace_bytes, need);
+        return LVT_EWORKSPACE;
+    }
+    const long long pix = (long long)g->N * g->To * g->Ho * g->Wo;
+    LVT_REQUIRE(pix < 0x7fffffffLL, "conv3d_bwd_weight: too many positions");
+    const int taps = g->Kt * g->Kh * g->Kw;
+    KParams p; memset(&p, 0, sizeof(p));
+    p.M = taps * g->Ci; p.N = g->Co; p.K = (int)pix;
+    p.A = x; p.B = dy; p.ldb = g->Co; p.batch_inner = 1; p.alpha = 1.f; p.g = *g;
+    p.splits = bwd_weight_splits(g);
+    p.k_per_split = (int)(lvt_cdiv(lvt_cdiv(p.K, p.splits), BK) * BK);
+    p.partial = (float *)workspace;
+    p.partial_stride = (long long)p.M * p.N;
+    hipStream_t s = (hipStream_t)stream;
+    rc = launch_tile<A_CONV_M, B_NPLAIN, 128, 128, 2, 2>(p, 1, s);
+    if (rc) return rc;
+    const long long total = (long long)Co_real * Ci_real * taps;
+    const int blocks = (int)(lvt_cdiv(total, 256) < 4096 ? lvt_cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(lvt_unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, s, p.partial, p.partial_stride,
+                       p.splits, dw, taps, g->Ci, g->Co, Ci_real, Co_real);
+    LVT_CHECK_LAUNCH("lvt_unpack_wgrad_kernel");
+    return LVT_OK;
+}
+
+extern "C" size_t lvt_colsum_workspace_bytes(long long M, int N) {
+    const long long nblk = lvt_cdiv(M, 256) < 512 ? lvt_cdiv(M, 256) : 512;
+    return (size_t)(nblk > 0 ? nblk : 1) * N * sizeof(float);
+}
+
+extern "C" int lvt_colsum(const float *g, long long M, int N, long long ld, float *out, void *workspace,
+                          size_t workspace_bytes, void *stream) {
+    LVT_REQUIRE(g && out && M > 0 && N > 0, "colsum: bad args");
+    long long nblk = lvt_cdiv(M, 256) < 512 ? lvt_cdiv(M, 256) : 512;
+    if (nblk < 1) nblk = 1;
+    if (!workspace || workspace_bytes < (size_t)nblk * N * sizeof(float)) {
+        lvt_set_error("colsum: workspace too small");
+        return LVT_EWORKSPACE;
+    }
+    const long long rpb = lvt_cdiv(M, nblk);
+    nblk = lvt_cdiv(M, rpb);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(lvt_colsum_kernel, dim3((unsigned)lvt_cdiv(N, 256), (unsigned)nblk), dim3(256), 0, s, g, M, N,
+                       ld, rpb, (float *)workspace);
+    LVT_CHECK_LAUNCH("lvt_colsum_kernel");
+    hipLaunchKernelGGL(lvt_colsum_final_kernel, dim3((unsigned)lvt_cdiv(N, 256)), dim3(256), 0, s,
+                       (const float *)workspace, (int)nblk, N, out);
+    LVT_CHECK_LAUNCH("lvt_colsum_final_kernel");
+    return LVT_OK;
+}

@@ -1,0 +1,252 @@
+// Product vector quantiser kernels (reference: vidgen/modeling/vq/vq_utils.py:5-65,
+// vq_embedding.py:9-99).
+//
+//   lvt_vq_nearest      idx[n][g][p] = argmin_k ( |e_k|^2 + |x|^2 - 2 x.e_k ), lowest k on ties
+//   lvt_vq_gather       out[row][g*D+d] = E[g][idx][d]            (z_q_st, z_q_bar, mode "emb")
+//   lvt_vq_ema_accumulate   stats[g][k][0..D-1] += x rows, stats[g][k][D] += 1
+//   lvt_vq_ema_finalize     decay-lerp of running_size / running_sum, Laplace smoothing, new codebook
+//
+// vq_nearest on MI355X: one codebook group (512 x 64 fp32 = 128 KiB) is made LDS-resident
+// ([dim][code], conflict-free operand reads) by a persistent 8-wave workgroup; each wave walks
+// 32-row tiles, keeps its 32x64 activation fragment in VGPRs, runs the distance product on the fp32
+// matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 FMA chain) and folds a running (min, argmin)
+// per row in registers; a 5-step wave shuffle finishes the row reduction.  z_e is read exactly once
+// and only the int64 indices are written: 270,336 algorithmic bytes per 64x64 frame.
+#include "lvt_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define VQ_D 64
+#define VQ_THREADS 512
+
+template <int KC>
+__global__ __launch_bounds__(VQ_THREADS) void lvt_vq_nearest_kernel(
+    const float *__restrict__ z, long long rows, int ldz, int num, const float *__restrict__ codebooks,
+    long long *__restrict__ idx_out, int P, int blocks_per_group) {
+    constexpr int LDC = KC + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Es = smem;                 // [VQ_D][LDC]
+    float *cbsq = smem + VQ_D * LDC;  // [KC]
+
+    const int g = blockIdx.x / blocks_per_group;
+    const int bg = blockIdx.x % blocks_per_group;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const float *E = codebooks + (long long)g * KC * VQ_D;
+
+    // codebook -> LDS, transposed to [dim][code]
+    for (int u = tid; u < KC * (VQ_D / 4); u += VQ_THREADS) {
+        const int code = u / (VQ_D / 4), dq = u % (VQ_D / 4);
+        const float4 v = *reinterpret_cast<const float4 *>(E + (long long)code * VQ_D + dq * 4);
+        Es[(dq * 4 + 0) * LDC + code] = v.x;
+        Es[(dq * 4 + 1) * LDC + code] = v.y;
+        Es[(dq * 4 + 2) * LDC + code] = v.z;
+        Es[(dq * 4 + 3) * LDC + code] = v.w;
+    }
+    __syncthreads();
+    for (int c = tid; c < KC; c += VQ_THREADS) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < VQ_D; ++d) { const float e = Es[d * LDC + c]; s = fmaf(e, e, s); }
+        cbsq[c] = s;
+    }
+    __syncthreads();
+
+    const long long ntiles = (rows + 31) / 32;
+    const int wpb = VQ_THREADS / 64;
+    for (long long tile = (long long)bg * wpb + wave; tile < ntiles; tile += (long long)blocks_per_group * wpb) {
+        const long long row = tile * 32 + l31;
+        const bool rok = row < rows;
+        // MFMA k-slot pairing: step j consumes dims (j, j+32): lanes 0-31 hold dims 0..31 of their
+        // row, lanes 32-63 dims 32..63 -> 8 contiguous 16-byte loads per lane.
+        float a[32];
+        const float *zp = z + (rok ? row : 0) * (long long)ldz + g * VQ_D + 32 * half;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 v = rok ? *reinterpret_cast<const float4 *>(zp + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a[q * 4 + 0] = v.x; a[q * 4 + 1] = v.y; a[q * 4 + 2] = v.z; a[q * 4 + 3] = v.w;
+        }
+        float xs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) xs = fmaf(a[j], a[j], xs);
+        xs += __shfl_xor(xs, 32);
+        float xsr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xsr[r] = __shfl(xs, (r & 3) + 8 * (r >> 2) + 4 * half);
+
+        float best[16]; int bidx[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { best[r] = 3.4e38f; bidx[r] = 0; }
+
+        const float *Erd = Es + (32 * half) * LDC + l31;
+        for (int nt = 0; nt < KC / 32; ++nt) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], Erd[j * LDC + nt * 32], acc, 0, 0, 0);
+            const int code = nt * 32 + l31;
+            const float cs = cbsq[code];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // (|e|^2 + |x|^2) + (-2) * (x.e): same algebraic form as torch.addmm(beta=1, alpha=-2)
+                const float dist = fmaf(-2.0f, acc[r], cs + xsr[r]);
+                if (dist < best[r]) { best[r] = dist; bidx[r] = code; }
+            }
+        }
+        // reduce over the 32 lanes (columns) of each half; ties -> lowest code (torch.min semantics)
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ob = __shfl_xor(best[r], off);
+                const int oi = __shfl_xor(bidx[r], off);
+                if (ob < best[r] || (ob == best[r] && oi < bidx[r])) { best[r] = ob; bidx[r] = oi; }
+            }
+        }
+        if (l31 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long rr = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (rr < rows) idx_out[((rr / P) * num + g) * (long long)P + rr % P] = bidx[r];
+            }
+        }
+    }
+}
+
+// out[row][g*D + d] = E[g][idx[n][g][p]][d]; one wave per (row, g) pair, d = lane (D == 64)
+__global__ void lvt_vq_gather_kernel(const long long *__restrict__ idx, const float *__restrict__ codebooks,
+                                     long long rows, int num, int KC, int P, float *__restrict__ out, int ldo) {
+    const long long pairs = rows * num;
+    const int lane = threadIdx.x & 63;
+    for (long long pr = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; pr < pairs;
+         pr += ((long long)gridDim.x * blockDim.x) >> 6) {
+        const long long row = pr / num; const int g = pr % num;
+        const long long k = idx[((row / P) * num + g) * (long long)P + row % P];
+        out[row * ldo + g * VQ_D + lane] = codebooks[((long long)g * KC + k) * VQ_D + lane];
+    }
+}
+
+// stats[g][k][0..D-1] += z[row][g*D..], stats[g][k][D] += 1   (fp32 HW atomics; counts stay exact)
+__global__ void lvt_vq_ema_accumulate_kernel(const long long *__restrict__ idx, const float *__restrict__ z,
+                                             long long rows, int ldz, int num, int KC, int P,
+                                             float *__restrict__ stats) {
+    const long long pairs = rows * num;
+    const int lane = threadIdx.x & 63;
+    for (long long pr = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; pr < pairs;
+         pr += ((long long)gridDim.x * blockDim.x) >> 6) {
+        const long long row = pr / num; const int g = pr % num;
+        const long long k = idx[((row / P) * num + g) * (long long)P + row % P];
+        float *dst = stats + ((long long)g * KC + k) * (VQ_D + 1);
+        atomicAdd(dst + lane, z[row * ldz + g * VQ_D + lane]);
+        if (lane == 0) atomicAdd(dst + VQ_D, 1.0f);
+    }
+}
+
+// one workgroup per codebook group (vq_embedding.py:48-59)
+__global__ __launch_bounds__(512) void lvt_vq_ema_finalize_kernel(const float *__restrict__ stats, int KC,
+                                                                  float decay, float one_minus_decay, float eps,
+                                                                  float *__restrict__ running_size,
+                                                                  float *__restrict__ running_sum,
+                                                                  float *__restrict__ weight) {
+    __shared__ float red[512];
+    __shared__ float ntot;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    float *rs = running_size + (long long)g * KC;
+    float *rsum = running_sum + (long long)g * KC * VQ_D;
+    float *w = weight + (long long)g * KC * VQ_D;
+    const float *st = stats + (long long)g * KC * (VQ_D + 1);
+    float part = 0.f;
+    for (int k = tid; k < KC; k += blockDim.x) {
+        const float v = rs[k] * decay + one_minus_decay * st[k * (VQ_D + 1) + VQ_D];
+        rs[k] = v;
+        part += v;
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) ntot = red[0];
+    __syncthreads();
+    const float n = ntot;
+    for (int i = tid; i < KC * VQ_D; i += blockDim.x) {
+        const int k = i / VQ_D, d = i % VQ_D;
+        const float s = rsum[i] * decay + one_minus_decay * st[k * (VQ_D + 1) + d];
+        rsum[i] = s;
+        const float size_ = (rs[k] + eps) / (n + KC * eps) * n;
+        w[i] = s / size_;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static int vq_smem_bytes(int KC) { return (VQ_D * (KC + 1) + KC) * (int)sizeof(float); }
+
+extern "C" int lvt_vq_nearest(const float *z, long long rows, int ldz, int num, int D, int KC,
+                              const float *codebooks, long long *idx_out, int P, void *stream) {
+    LVT_REQUIRE(z && codebooks && idx_out, "vq_nearest: null pointer");
+    LVT_REQUIRE(D == VQ_D, "vq_nearest: only D=%d per codebook is instantiated (got %d)", VQ_D, D);
+    LVT_REQUIRE(KC == 512 || KC == 256 || KC == 128, "vq_nearest: codebook size %d not instantiated", KC);
+    LVT_REQUIRE(rows > 0 && num > 0 && P > 0 && rows % P == 0, "vq_nearest: bad rows/P");
+    LVT_REQUIRE(ldz % 4 == 0 && ldz >= num * D && lvt_aligned16(z) && lvt_aligned16(codebooks),
+                "vq_nearest: alignment / ldz");
+    const long long ntiles = (rows + 31) / 32;
+    int bpg = LVT_NUM_CU / num;                       // one workgroup per CU (LDS-bound)
+    const long long need = lvt_cdiv(ntiles, VQ_THREADS / 64);
+    if (bpg > need) bpg = (int)need;
+    if (bpg < 1) bpg = 1;
+    const int smem = vq_smem_bytes(KC);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+#define VQ_LAUNCH(KCV)                                                                                          \
+    e = hipFuncSetAttribute((const void *)lvt_vq_nearest_kernel<KCV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            smem);                                                                              \
+    if (e != hipSuccess) { lvt_set_error("vq_nearest: cannot get %d B LDS: %s", smem, hipGetErrorString(e));    \
+        return LVT_ELAUNCH; }                                                                                   \
+    hipLaunchKernelGGL(lvt_vq_nearest_kernel<KCV>, dim3(bpg * num), dim3(VQ_THREADS), smem, s, z, rows, ldz, num, \
+                       codebooks, idx_out, P, bpg);
+    if (KC == 512) { VQ_LAUNCH(512) } else if (KC == 256) { VQ_LAUNCH(256) } else { VQ_LAUNCH(128) }
+#undef VQ_LAUNCH
+    LVT_CHECK_LAUNCH("lvt_vq_nearest_kernel");
+    return LVT_OK;
+}
+
+extern "C" int lvt_vq_gather(const long long *idx, const float *codebooks, long long rows, int num, int D, int KC,
+                             int P, float *out, int ldo, void *stream) {
+    LVT_REQUIRE(idx && codebooks && out && D == VQ_D && rows > 0 && rows % P == 0, "vq_gather: bad args");
+    const long long pairs = rows * num;
+    const int blocks = (int)(lvt_cdiv(pairs, 4) < 8192 ? lvt_cdiv(pairs, 4) : 8192);
+    hipLaunchKernelGGL(lvt_vq_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, idx, codebooks, rows,
+                       num, KC, P, out, ldo);
+    LVT_CHECK_LAUNCH("lvt_vq_gather_kernel");
+    return LVT_OK;
+}
+
+extern "C" int lvt_vq_ema_accumulate(const long long *idx, const float *z, long long rows, int ldz, int num, int D,
+                                     int KC, int P, float *stats, void *stream) {
+    LVT_REQUIRE(idx && z && stats && D == VQ_D && rows > 0 && rows % P == 0, "vq_ema_accumulate: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(stats, 0, (size_t)num * KC * (D + 1) * sizeof(float), s) != hipSuccess) {
+        lvt_set_error("vq_ema_accumulate: memset failed");
+        return LVT_ELAUNCH;
+    }
+    const long long pairs = rows * num;
+    const int blocks = (int)(lvt_cdiv(pairs, 4) < 8192 ? lvt_cdiv(pairs, 4) : 8192);
+    hipLaunchKernelGGL(lvt_vq_ema_accumulate_kernel, dim3(blocks), dim3(256), 0, s, idx, z, rows, ldz, num, KC, P,
+                       stats);
+    LVT_CHECK_LAUNCH("lvt_vq_ema_accumulate_kernel");
+    return LVT_OK;
+}
+
+extern "C" int lvt_vq_ema_finalize(const float *stats, int num, int D, int KC, float decay, float eps,
+                                   float *running_size, float *running_sum, float *weight, void *stream) {
+    LVT_REQUIRE(stats && running_size && running_sum && weight && D == VQ_D, "vq_ema_finalize: bad args");
+    // the reference evaluates (1 - decay) in double precision python and hands it to add_(alpha=...)
+    const float omd = (float)(1.0 - (double)decay);
+    hipLaunchKernelGGL(lvt_vq_ema_finalize_kernel, dim3(num), dim3(512), 0, (hipStream_t)stream, stats, KC, decay,
+                       omd, eps, running_size, running_sum, weight);
+    LVT_CHECK_LAUNCH("lvt_vq_ema_finalize_kernel");
+    return LVT_OK;
+}

@@ -1,0 +1,129 @@
+"""ctypes binding of liblvt_hip.so (C ABI declared in include/lvt_hip.h).
+
+The shared library is built in-tree by `__graft_entry__.build()` / `make -C lvt_amd/csrc`.
+There is NO fallback: if the library is missing, or an op is called on a non-GPU tensor, the call
+raises.  PyTorch is used only for device memory, streams and autograd plumbing.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "liblvt_hip.so")
+
+EPI_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_TANH, EPI_MASK, EPI_ACCUM = 1, 2, 4, 8, 16, 32
+
+
+class LvtError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("ta", C.c_int), ("tb", C.c_int),
+        ("A", C.c_void_p), ("lda", C.c_longlong), ("a_kb", C.c_int), ("a_skb", C.c_longlong),
+        ("B", C.c_void_p), ("ldb", C.c_longlong), ("b_kb", C.c_int), ("b_skb", C.c_longlong),
+        ("C", C.c_void_p), ("ldc", C.c_longlong),
+        ("batch_outer", C.c_int), ("batch_inner", C.c_int),
+        ("sA_o", C.c_longlong), ("sA_i", C.c_longlong), ("sB_o", C.c_longlong), ("sB_i", C.c_longlong),
+        ("sC_o", C.c_longlong), ("sC_i", C.c_longlong),
+        ("alpha", C.c_float), ("flags", C.c_int),
+        ("bias", C.c_void_p), ("res", C.c_void_p), ("ldr", C.c_longlong),
+        ("mask", C.c_void_p), ("ldm", C.c_longlong), ("splits", C.c_int),
+    ]
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("N", "Ti", "Hi", "Wi", "Ci", "To", "Ho", "Wo", "Co", "Kt", "Kh", "Kw",
+                 "st", "sh", "sw", "pt", "ph", "pw")]
+
+    def key(self):
+        return tuple(getattr(self, n) for n, _ in self._fields_)
+
+
+_lib = None
+
+
+def _declare(lib):
+    vp, ci, cll, cf, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+    P = C.POINTER
+    sigs = {
+        "lvt_last_error": (C.c_char_p, []),
+        "lvt_version": (ci, []),
+        "lvt_device_info": (ci, [C.c_char_p, ci, P(ci), P(ci), P(cll)]),
+        "lvt_gemm_workspace_bytes": (sz, [P(GemmDesc)]),
+        "lvt_gemm_f32": (ci, [P(GemmDesc), vp, sz, vp]),
+        "lvt_conv3d_pack_weight": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
+        "lvt_conv3d_fwd": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, ci, vp]),
+        "lvt_conv3d_bwd_data": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
+        "lvt_conv3d_bwd_weight_workspace_bytes": (sz, [P(ConvGeom)]),
+        "lvt_conv3d_bwd_weight": (ci, [P(ConvGeom), vp, vp, vp, ci, ci, vp, sz, vp]),
+        "lvt_colsum_workspace_bytes": (sz, [cll, ci]),
+        "lvt_colsum": (ci, [vp, cll, ci, cll, vp, vp, sz, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return sigs
+
+
+def available():
+    return os.path.exists(_LIB_PATH)
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises LvtError if the library was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise LvtError("liblvt_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` (or `make -C lvt_amd/csrc`); there is no CPU fallback" % _LIB_PATH)
+        handle = C.CDLL(_LIB_PATH)
+        handle._lvt_sigs = _declare(handle)
+        _lib = handle
+    return _lib
+
+
+def declared_symbols():
+    return sorted(lib()._lvt_sigs.keys())
+
+
+def require(*tensors):
+    """All tensors must be contiguous CUDA(HIP) tensors; the product path never runs on CPU."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise LvtError("lvt_amd kernels need tensors on a MI355X (got device %s); there is no CPU "
+                           "fallback" % t.device)
+        if not t.is_contiguous():
+            raise LvtError("lvt_amd kernels need contiguous tensors")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise LvtError("%s failed (rc=%d): %s" % (what, rc, lib().lvt_last_error().decode()))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+_ws = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """Grow-only scratch buffer per (device, tag), reused across calls on the same stream."""
+    key = (device, tag)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf

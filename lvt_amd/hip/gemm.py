@@ -1,0 +1,106 @@
+"""Thin typed wrappers over lvt_gemm_f32 / lvt_conv3d_* / lvt_colsum."""
+import ctypes as C
+
+import torch
+
+from . import binding as L
+
+
+def gemm(A, B, C_out, M, N, K, ta=0, tb=0, lda=None, ldb=None, ldc=None, a_kb=0, a_skb=0, b_kb=0,
+         b_skb=0, batch_outer=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, flags=0,
+         bias=None, res=None, ldr=0, mask=None, ldm=0, splits=1):
+    """C = epi(alpha * A @ B); see include/lvt_hip.h for the addressing rules."""
+    L.require(A, B, C_out, bias, res, mask)
+    d = L.GemmDesc()
+    d.M, d.N, d.K, d.ta, d.tb = M, N, K, ta, tb
+    d.A, d.lda, d.a_kb, d.a_skb = A.data_ptr(), (lda if lda is not None else (K if ta == 0 else M)), a_kb, a_skb
+    d.B, d.ldb, d.b_kb, d.b_skb = B.data_ptr(), (ldb if ldb is not None else (K if tb == 0 else N)), b_kb, b_skb
+    d.C, d.ldc = C_out.data_ptr(), (ldc if ldc is not None else N)
+    d.batch_outer, d.batch_inner = batch_outer, batch_inner
+    d.sA_o, d.sA_i = sA
+    d.sB_o, d.sB_i = sB
+    d.sC_o, d.sC_i = sC
+    d.alpha, d.flags = alpha, flags
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.res = res.data_ptr() if res is not None else None
+    d.ldr = ldr if res is not None and ldr else d.ldc
+    d.mask = mask.data_ptr() if mask is not None else None
+    d.ldm = ldm if mask is not None and ldm else d.ldc
+    d.splits = splits
+    lib = L.lib()
+    ws, nws = None, 0
+    if splits > 1:
+        nws = lib.lvt_gemm_workspace_bytes(C.byref(d))
+        ws = L.workspace(nws, A.device, "gemm")
+    L.check(lib.lvt_gemm_f32(C.byref(d), L.ptr(ws), nws, L.stream_ptr()), "lvt_gemm_f32")
+    return C_out
+
+
+def conv_geom(N, Ti, Hi, Wi, Ci, Co, kernel, stride, pad, out=None):
+    """Forward-conv geometry; `pad` is the FRONT padding per dim; `out` overrides (To,Ho,Wo)
+    (needed for asymmetric padding such as the causal conv)."""
+    g = L.ConvGeom()
+    g.N, g.Ti, g.Hi, g.Wi, g.Ci, g.Co = N, Ti, Hi, Wi, Ci, Co
+    g.Kt, g.Kh, g.Kw = kernel
+    g.st, g.sh, g.sw = stride
+    g.pt, g.ph, g.pw = pad
+    if out is None:
+        out = tuple((i + 2 * p - k) // s + 1 for i, p, k, s in zip((Ti, Hi, Wi), pad, kernel, stride))
+    g.To, g.Ho, g.Wo = out
+    return g
+
+
+def pack_weight(g, w, Ci_real, Co_real):
+    L.require(w)
+    wp = torch.empty(g.Kt * g.Kh * g.Kw, g.Ci, g.Co, dtype=torch.float32, device=w.device)
+    L.check(L.lib().lvt_conv3d_pack_weight(C.byref(g), L.ptr(w), Ci_real, Co_real, L.ptr(wp), L.stream_ptr()),
+            "lvt_conv3d_pack_weight")
+    return wp
+
+
+def conv_fwd(g, x, wp, bias=None, res=None, flags=0):
+    L.require(x, wp, bias, res)
+    y = torch.empty(g.N, g.To, g.Ho, g.Wo, g.Co, dtype=torch.float32, device=x.device)
+    if bias is not None:
+        flags |= L.EPI_BIAS
+    if res is not None:
+        flags |= L.EPI_RESIDUAL
+    L.check(L.lib().lvt_conv3d_fwd(C.byref(g), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(y), flags,
+                                   L.stream_ptr()), "lvt_conv3d_fwd")
+    return y
+
+
+def conv_bwd_data(g, dy, wp, bias=None, res=None, mask=None, flags=0):
+    L.require(dy, wp, bias, res, mask)
+    dx = torch.empty(g.N, g.Ti, g.Hi, g.Wi, g.Ci, dtype=torch.float32, device=dy.device)
+    if bias is not None:
+        flags |= L.EPI_BIAS
+    if res is not None:
+        flags |= L.EPI_RESIDUAL
+    if mask is not None:
+        flags |= L.EPI_MASK
+    L.check(L.lib().lvt_conv3d_bwd_data(C.byref(g), L.ptr(dy), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(mask),
+                                        L.ptr(dx), flags, L.stream_ptr()), "lvt_conv3d_bwd_data")
+    return dx
+
+
+def conv_bwd_weight(g, x, dy, Ci_real, Co_real):
+    L.require(x, dy)
+    lib = L.lib()
+    dw = torch.empty(Co_real, Ci_real, g.Kt, g.Kh, g.Kw, dtype=torch.float32, device=x.device)
+    nws = lib.lvt_conv3d_bwd_weight_workspace_bytes(C.byref(g))
+    ws = L.workspace(nws, x.device, "wgrad")
+    L.check(lib.lvt_conv3d_bwd_weight(C.byref(g), L.ptr(x), L.ptr(dy), L.ptr(dw), Ci_real, Co_real, L.ptr(ws),
+                                      nws, L.stream_ptr()), "lvt_conv3d_bwd_weight")
+    return dw
+
+
+def colsum(gmat, M, N, ld=None):
+    L.require(gmat)
+    lib = L.lib()
+    out = torch.empty(N, dtype=torch.float32, device=gmat.device)
+    nws = lib.lvt_colsum_workspace_bytes(M, N)
+    ws = L.workspace(nws, gmat.device, "colsum")
+    L.check(lib.lvt_colsum(L.ptr(gmat), M, N, ld if ld is not None else N, L.ptr(out), L.ptr(ws), nws,
+                           L.stream_ptr()), "lvt_colsum")
+    return out

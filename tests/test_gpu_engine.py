@@ -1,0 +1,186 @@
+"""GPU parity of the fp32 MFMA tile engine (GEMM / conv fwd / bwd-data / bwd-weight) against plain
+torch-CPU fp32 ops (the ops the oracle is made of).  Tolerances: fp32 accumulate in a different
+order -> max-abs error relative to the output scale < 2e-5 (stated per test)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _rand(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.rand(*shape, generator=g) * 2 - 1
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 512), (1000, 132, 68), (4096, 512, 512)])
+def test_gemm_nt_bias_relu_residual(M, N, K):
+    from lvt_amd.hip import gemm as G, binding as L
+    a, w, b, r = _rand(M, K), _rand(N, K, seed=1), _rand(N, seed=2), _rand(M, N, seed=3)
+    ref = torch.relu(a @ w.t() + b + r)
+    d = _dev()
+    out = torch.empty(M, N, device=d)
+    G.gemm(a.to(d), w.to(d), out, M, N, K, ta=0, tb=0, flags=L.EPI_BIAS | L.EPI_RESIDUAL | L.EPI_RELU,
+           bias=b.to(d), res=r.to(d))
+    assert rel_err(out, ref) < TOL
+
+
+def test_gemm_nn_batched_heads():
+    """QKV-style: x[M,512] @ w[h][512][128] -> out[M][h*128+j] (K20)."""
+    from lvt_amd.hip import gemm as G
+    M, d_, h, da = 512, 512, 8, 128
+    x, w = _rand(M, d_), _rand(h, d_, da, seed=1) * 0.1
+    ref = torch.einsum("md,hdj->mhj", x, w).reshape(M, h * da)
+    dev = _dev()
+    out = torch.empty(M, h * da, device=dev)
+    G.gemm(x.to(dev), w.to(dev), out, M, da, d_, ta=0, tb=1, ldb=da, ldc=h * da, batch_inner=h,
+           sB=(0, d_ * da), sC=(0, da))
+    assert rel_err(out, ref) < TOL
+
+
+def test_gemm_nt_two_level_k_accumulate():
+    """QKV backward-data style: dX += dq[M][h*128+j] @ w[h][d][j]^T."""
+    from lvt_amd.hip import gemm as G, binding as L
+    M, d_, h, da = 256, 512, 8, 128
+    dq, w, base = _rand(M, h * da), _rand(h, d_, da, seed=1) * 0.1, _rand(M, d_, seed=2)
+    ref = base + torch.einsum("mhj,hdj->md", dq.view(M, h, da), w)
+    dev = _dev()
+    out = base.to(dev).clone()
+    G.gemm(dq.to(dev), w.to(dev), out, M, d_, h * da, ta=0, tb=0, ldb=da, b_kb=da, b_skb=d_ * da,
+           flags=L.EPI_ACCUM)
+    assert rel_err(out, ref) < TOL
+
+
+@pytest.mark.parametrize("splits", [1, 7])
+def test_gemm_tn_splitk(splits):
+    """weight-gradient style: dW[N,K] = dY[M,N]^T @ X[M,K]."""
+    from lvt_amd.hip import gemm as G
+    M, N, K = 4096, 256, 384
+    dy, x = _rand(M, N), _rand(M, K, seed=1)
+    ref = dy.t() @ x
+    dev = _dev()
+    out = torch.empty(N, K, device=dev)
+    G.gemm(dy.to(dev), x.to(dev), out, N, K, M, ta=1, tb=1, lda=N, ldb=K, splits=splits)
+    assert rel_err(out, ref) < TOL
+
+
+def test_gemm_batched_attention_shapes():
+    """scores = q k^T / sqrt(da) with (b, s, h, da) token-major operands; out (b,h,s,s)."""
+    from lvt_amd.hip import gemm as G
+    b, s, h, da = 2, 256, 8, 128
+    q, k = _rand(b, s, h, da), _rand(b, s, h, da, seed=1)
+    ref = torch.einsum("bqhd,bkhd->bhqk", q, k) / 128 ** 0.5
+    dev = _dev()
+    out = torch.empty(b, h, s, s, device=dev)
+    G.gemm(q.to(dev), k.to(dev), out, s, s, da, ta=0, tb=0, lda=h * da, ldb=h * da, ldc=s, batch_outer=b,
+           batch_inner=h, sA=(s * h * da, da), sB=(s * h * da, da), sC=(h * s * s, s * s), alpha=1.0 / 128 ** 0.5)
+    assert rel_err(out, ref) < TOL
+
+
+def _nhwc(x):   # (N,C,H,W) -> (N,1,H,W,C) contiguous
+    return x.permute(0, 2, 3, 1).contiguous().unsqueeze(1)
+
+
+def _nchw(y):   # (N,1,H,W,C) -> (N,C,H,W)
+    return y.squeeze(1).permute(0, 3, 1, 2).contiguous()
+
+
+CONVS = [  # Ci, Co, k, s, p, H
+    (4, 128, 4, 2, 1, 64),      # K1 (3 channels carried as 4)
+    (128, 256, 4, 2, 1, 32),    # K2
+    (256, 256, 3, 1, 1, 16),    # K3
+    (256, 128, 3, 1, 1, 16),    # K4a
+    (128, 256, 1, 1, 0, 16),    # K4b
+]
+
+
+@pytest.mark.parametrize("Ci,Co,k,s,p,H", CONVS)
+def test_conv_fwd_bwd(Ci, Co, k, s, p, H):
+    from lvt_amd.hip import gemm as G, binding as L
+    N = 3
+    x, w, b = _rand(N, Ci, H, H), _rand(Co, Ci, k, k, seed=1) * 0.1, _rand(Co, seed=2)
+    x.requires_grad_(True); w.requires_grad_(True)
+    y = torch.relu(F.conv2d(x, w, b, stride=s, padding=p))
+    gy = _rand(*y.shape, seed=3)
+    gmask = gy * (y > 0)
+    y.backward(gy)
+    dev = _dev()
+    g = G.conv_geom(N, 1, H, H, Ci, Co, (1, k, k), (1, s, s), (0, p, p))
+    wp = G.pack_weight(g, w.detach().to(dev), Ci, Co)
+    xd = _nhwc(x.detach()).to(dev)
+    yd = G.conv_fwd(g, xd, wp, bias=b.to(dev), flags=L.EPI_RELU)
+    assert rel_err(_nchw(yd), y) < TOL
+    gd = _nhwc(gmask).to(dev)
+    dx = G.conv_bwd_data(g, gd, wp)
+    assert rel_err(_nchw(dx), x.grad) < TOL
+    dw = G.conv_bwd_weight(g, xd, gd, Ci, Co)
+    assert rel_err(dw.squeeze(2), w.grad) < 5e-5
+    db = G.colsum(gd.view(-1, Co), gd.numel() // Co, Co)
+    assert rel_err(db, gmask.sum((0, 2, 3))) < 5e-5
+
+
+@pytest.mark.parametrize("Cin,Cout,H", [(256, 128, 16), (128, 4, 32)])
+def test_conv_transpose_as_bwd_data(Cin, Cout, H):
+    """ConvTranspose2d(Cin->Cout, k4 s2 p1) forward == bwd_data of the conv (Ci=Cout, Co=Cin) (K5, K6)."""
+    from lvt_amd.hip import gemm as G, binding as L
+    N = 2
+    x, w, b = _rand(N, Cin, H, H), _rand(Cin, Cout, 4, 4, seed=1) * 0.1, _rand(Cout, seed=2)
+    x.requires_grad_(True); w.requires_grad_(True)
+    y = torch.tanh(F.conv_transpose2d(x, w, b, stride=2, padding=1))
+    gy = _rand(*y.shape, seed=3)
+    y.backward(gy)
+    gpre = gy * (1 - y.detach() ** 2)
+    dev = _dev()
+    g = G.conv_geom(N, 1, 2 * H, 2 * H, Cout, Cin, (1, 4, 4), (1, 2, 2), (0, 1, 1))
+    assert (g.Ho, g.Wo) == (H, H)
+    wp = G.pack_weight(g, w.detach().to(dev), Cout, Cin)
+    xd = _nhwc(x.detach()).to(dev)
+    yd = G.conv_bwd_data(g, xd, wp, bias=b.to(dev), flags=L.EPI_TANH)
+    assert rel_err(_nchw(yd), y) < TOL
+    # ConvT backward-data == conv forward; backward-weight == conv bwd_weight(x := d_out, dy := x)
+    gd = _nhwc(gpre).to(dev)
+    dx = G.conv_fwd(g, gd, wp)
+    assert rel_err(_nchw(dx), x.grad) < TOL
+    dw = G.conv_bwd_weight(g, gd, xd, Cout, Cin)
+    assert rel_err(dw.squeeze(2), w.grad) < 5e-5
+
+
+def test_conv_bwd_data_residual_and_mask():
+    from lvt_amd.hip import gemm as G
+    N, C, H = 2, 128, 16
+    gy, w, res, msrc = _rand(N, 256, H, H), _rand(256, C, 3, 3, seed=1) * 0.1, _rand(N, C, H, H, seed=2), _rand(N, C, H, H, seed=3)
+    ref = (F.conv_transpose2d(gy, w, stride=1, padding=1) + res) * (msrc > 0)
+    dev = _dev()
+    g = G.conv_geom(N, 1, H, H, C, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    wp = G.pack_weight(g, w.to(dev), C, 256)
+    dx = G.conv_bwd_data(g, _nhwc(gy).to(dev), wp, res=_nhwc(res).to(dev), mask=_nhwc(msrc).to(dev))
+    assert rel_err(_nchw(dx), ref) < TOL
+
+
+def test_conv3d_causal_geometry():
+    """MaskedConv3d geometry (K16): kernel 3x3x3, front pads (2,2,1), T=2 to exercise the t taps."""
+    from lvt_amd.hip import gemm as G
+    N, Ci, Co, T, H, W = 2, 128, 256, 2, 8, 8
+    x, w, b = _rand(N, Ci, T, H, W), _rand(Co, Ci, 3, 3, 3, seed=1) * 0.1, _rand(Co, seed=2)
+    x.requires_grad_(True); w.requires_grad_(True)
+    y = F.conv3d(F.pad(x, [1, 1, 2, 0, 2, 0]), w, b)
+    gy = _rand(*y.shape, seed=3)
+    y.backward(gy)
+    dev = _dev()
+    g = G.conv_geom(N, T, H, W, Ci, Co, (3, 3, 3), (1, 1, 1), (2, 2, 1), out=(T, H, W))
+    wp = G.pack_weight(g, w.detach().to(dev), Ci, Co)
+    xd = x.detach().permute(0, 2, 3, 4, 1).contiguous().to(dev)
+    yd = G.conv_fwd(g, xd, wp, bias=b.to(dev))
+    assert rel_err(yd.permute(0, 4, 1, 2, 3), y) < TOL
+    gd = gy.permute(0, 2, 3, 4, 1).contiguous().to(dev)
+    dx = G.conv_bwd_data(g, gd, wp)
+    assert rel_err(dx.permute(0, 4, 1, 2, 3), x.grad) < TOL
+    dw = G.conv_bwd_weight(g, xd, gd, Ci, Co)
+    assert rel_err(dw, w.grad) < 5e-5
