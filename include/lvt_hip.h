@@ -84,9 +84,9 @@ typedef struct {
 /* w: [Co_real][Ci_real][Kt][Kh][Kw] (torch layout)  ->  wp: [taps][Ci][Co], zero padded.            */
 int lvt_conv3d_pack_weight(const lvt_conv_geom *g, const float *w, int Ci_real, int Co_real,
                            float *wp, void *stream);
-/* y = epi( conv(x, wp) ); bias[Co]; res / y are (N,To,Ho,Wo,Co).  flags: BIAS|RESIDUAL|RELU|TANH.   */
+/* y = epi( conv(x, wp) ); bias[Co]; res / y are (N,To,Ho,Wo,Co).  flags: BIAS|RESIDUAL|RELU|TANH|MASK */
 int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias,
-                   const float *res, float *y, int flags, void *stream);
+                   const float *res, const float *mask, float *y, int flags, void *stream);
 /* dx = epi( conv_transpose(dy, wp) ); res / mask / dx are (N,Ti,Hi,Wi,Ci).
  * flags: BIAS (bias[Ci], used when this IS a ConvTranspose forward) | RESIDUAL | RELU | TANH | MASK.
  * Requires Kt % st == 0 etc. and To*st == Ti-ish geometries produced by lvt_conv geometry helpers.  */
@@ -101,6 +101,55 @@ int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, const float *d
 size_t lvt_colsum_workspace_bytes(long long M, int N);
 int lvt_colsum(const float *g, long long M, int N, long long ld, float *out, void *workspace,
                size_t workspace_bytes, void *stream);
+
+/* ---- product vector quantiser (vidgen/modeling/vq/vq_utils.py:5-65, vq_embedding.py:9-99; K7-K9) ----
+ * z: [rows][ldz] channels-last activations, group g owns columns [g*D, (g+1)*D).  codebooks: [num][KC][D].
+ * idx: int64 [rows/P][num][P]  (== the reference's (N, num, H, W) layout with P = H*W).
+ * lvt_vq_nearest: idx = argmin_k |e_k|^2 + |x|^2 - 2 x.e_k in fp32, lowest k on ties (torch.min).     */
+int lvt_vq_nearest(const float *z, long long rows, int ldz, int num, int D, int KC,
+                   const float *codebooks, long long *idx, int P, void *stream);
+/* out[row][g*D+d] = codebooks[g][idx][d]   (index_select / embedding: z_q_st, z_q_bar, mode "emb")   */
+int lvt_vq_gather(const long long *idx, const float *codebooks, long long rows, int num, int D, int KC,
+                  int P, float *out, int ldo, void *stream);
+/* stats[num][KC][D+1]: per-code sum of assigned rows and (last column) their count; zeroed inside.
+ * Kept separate from finalize so that a data-parallel all-reduce of `stats` can sit in between.      */
+int lvt_vq_ema_accumulate(const long long *idx, const float *z, long long rows, int ldz, int num, int D,
+                          int KC, int P, float *stats, void *stream);
+/* running_size[num][KC], running_sum/weight[num][KC][D] updated in place (vq_embedding.py:48-59).    */
+int lvt_vq_ema_finalize(const float *stats, int num, int D, int KC, float decay, float eps,
+                        float *running_size, float *running_sum, float *weight, void *stream);
+
+/* ---- boundary layout conversion + input (de)normalisation (ae.py:32-37,151-168; K12) --------------
+ * to_channels_last : in [B][C][R] -> out [B][R][ldo] (columns >= C zero); mode 1: (x - a[c]) / s[c]
+ * to_channels_first: in [B][R][ldi] -> out [B][C][R];  mode 2: clamp(x * s[c] + a[c], lo, hi)          */
+int lvt_to_channels_last(const float *in, int B, int C, long long R, int ldo, int mode, const float *a,
+                         const float *s, float *out, void *stream);
+int lvt_to_channels_first(const float *in, int B, int C, long long R, int ldi, int mode, const float *a,
+                          const float *s, float lo, float hi, float *out, void *stream);
+
+/* ---- losses / glue (F.mse_loss: K11) ----------------------------------------------------------------*/
+size_t lvt_reduce_workspace_bytes(void);
+/* out[0] = scale * sum((a-b)^2) / denom, fixed summation order                                        */
+int lvt_mse_fwd(const float *a, const float *b, long long n, double denom, float scale, float *out,
+                void *workspace, size_t workspace_bytes, void *stream);
+/* out = add + gout[0] * (2*scale/denom) * (a-b) [* (1-a^2) if tanh_of_a]; gout/add may be NULL        */
+int lvt_mse_bwd(const float *a, const float *b, long long n, double denom, float scale,
+                const float *gout_dev, const float *add, int tanh_of_a, float *out, void *stream);
+int lvt_tanh_bwd(const float *g, const float *y, long long n, float *out, void *stream);
+/* out = alpha * alpha_dev[0] * x (+ add)                                                              */
+int lvt_axpy(const float *x, const float *add, long long n, const float *alpha_dev, float alpha,
+             float *out, void *stream);
+/* x[r][:] += table[r % P][:]  (3-D sinusoidal position signal, vt_attention.py:25-50; K17)            */
+int lvt_add_periodic(float *x, const float *table, long long rows, int P, int d, void *stream);
+
+/* ---- LayerNorm over the last dim, eps inside the sqrt (F.layer_norm; K19) ---------------------------*/
+int lvt_layernorm_fwd(const float *x, long long rows, int d, float eps, const float *w, const float *b,
+                      float *y, float *mean, float *rstd, void *stream);
+size_t lvt_layernorm_bwd_workspace_bytes(int d);
+/* dx = LN'(dy) (+ add); dw[d], db[d] reduced in a fixed order                                        */
+int lvt_layernorm_bwd(const float *dy, const float *x, const float *mean, const float *rstd,
+                      const float *w, long long rows, int d, const float *add, float *dx, float *dw,
+                      float *db, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,374 @@
+// HBM-bound helper kernels of the LVT hot path: layout conversion at the model boundary, losses,
+// LayerNorm, attention softmax with the learned relative-position bias, embedding bags and
+// cross-entropy.  All of them are 16-byte vectorised where the layout allows, one wave (64 lanes)
+// per row for the row reductions, and every cross-workgroup reduction is two-stage with a fixed
+// summation order (bit-reproducible run to run) unless stated otherwise.
+#include "lvt_common.h"
+
+static inline int grid_for(long long n, int per_block, int cap = 8192) {
+    long long b = lvt_cdiv(n, per_block);
+    if (b < 1) b = 1;
+    return (int)(b < cap ? b : cap);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout: (B, R, C) -> (B, C, R) with channel padding and a per-channel affine (ae.py:36-37,151-168)
+//   mode 0: y = x                      mode 1: y = (x - a[c]) / s[c]       (normalizer)
+//   mode 2: y = clamp(x * s[c] + a[c]) (back_normalizer + clamp_)
+// in is [B][R][ldi] (only the first C columns are read), out is [B][C_out][R] or, with to_last=1,
+// in is [B][C][R] and out is [B][R][ldo] (columns C..ldo-1 zero-filled).
+// ------------------------------------------------------------------------------------------------
+__global__ void lvt_to_channels_last_kernel(const float *__restrict__ in, int B, int C, long long R, int ldo,
+                                            int mode, const float *__restrict__ a, const float *__restrict__ s,
+                                            float *__restrict__ out) {
+    const long long total = (long long)B * R * ldo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = i % ldo; const long long t = i / ldo;
+        const long long r = t % R; const long long b = t / R;
+        float v = 0.f;
+        if (c < C) {
+            v = in[(b * C + c) * R + r];
+            if (mode == 1) v = (v - a[c]) / s[c];
+        }
+        out[i] = v;
+    }
+}
+__global__ void lvt_to_channels_first_kernel(const float *__restrict__ in, int B, int C, long long R, int ldi,
+                                             int mode, const float *__restrict__ a, const float *__restrict__ s,
+                                             float lo, float hi, float *__restrict__ out) {
+    const long long total = (long long)B * C * R;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i % R; const long long t = i / R;
+        const int c = t % C; const long long b = t / C;
+        float v = in[(b * R + r) * ldi + c];
+        if (mode == 2) { v = v * s[c] + a[c]; v = fminf(fmaxf(v, lo), hi); }
+        out[i] = v;
+    }
+}
+
+extern "C" int lvt_to_channels_last(const float *in, int B, int C, long long R, int ldo, int mode, const float *a,
+                                    const float *s, float *out, void *stream) {
+    LVT_REQUIRE(in && out && B > 0 && C > 0 && R > 0 && ldo >= C, "to_channels_last: bad args");
+    LVT_REQUIRE(mode == 0 || (a && s), "to_channels_last: affine tables missing");
+    hipLaunchKernelGGL(lvt_to_channels_last_kernel, dim3(grid_for((long long)B * R * ldo, 256)), dim3(256), 0,
+                       (hipStream_t)stream, in, B, C, R, ldo, mode, a, s, out);
+    LVT_CHECK_LAUNCH("lvt_to_channels_last_kernel");
+    return LVT_OK;
+}
+extern "C" int lvt_to_channels_first(const float *in, int B, int C, long long R, int ldi, int mode, const float *a,
+                                     const float *s, float lo, float hi, float *out, void *stream) {
+    LVT_REQUIRE(in && out && B > 0 && C > 0 && R > 0 && ldi >= C, "to_channels_first: bad args");
+    LVT_REQUIRE(mode == 0 || (a && s), "to_channels_first: affine tables missing");
+    hipLaunchKernelGGL(lvt_to_channels_first_kernel, dim3(grid_for((long long)B * C * R, 256)), dim3(256), 0,
+                       (hipStream_t)stream, in, B, C, R, ldi, mode, a, s, lo, hi, out);
+    LVT_CHECK_LAUNCH("lvt_to_channels_first_kernel");
+    return LVT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// squared-error loss (F.mse_loss; vqvae.py:79,86 / loss.py:19) -- fixed-order two-stage sum
+// ------------------------------------------------------------------------------------------------
+#define RED_BLOCKS 1024
+__global__ void lvt_sqdiff_partial_kernel(const float *__restrict__ a, const float *__restrict__ b, long long n4,
+                                          float *__restrict__ partial) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float4 x = reinterpret_cast<const float4 *>(a)[i];
+        const float4 y = reinterpret_cast<const float4 *>(b)[i];
+        const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+        s += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void lvt_scalar_finish_kernel(const float *__restrict__ partial, int n, float scale,
+                                         const float *__restrict__ denom_dev, float *__restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double v = red[0] * (double)scale;
+        if (denom_dev) v /= (double)fmaxf(denom_dev[0], 1.0f);
+        out[0] = (float)v;
+    }
+}
+extern "C" size_t lvt_reduce_workspace_bytes(void) { return (size_t)RED_BLOCKS * sizeof(float) * 2; }
+
+// out[0] = scale * sum((a-b)^2) / denom
+extern "C" int lvt_mse_fwd(const float *a, const float *b, long long n, double denom, float scale, float *out,
+                           void *workspace, size_t workspace_bytes, void *stream) {
+    LVT_REQUIRE(a && b && out && n > 0 && n % 4 == 0 && denom > 0, "mse_fwd: bad args");
+    LVT_REQUIRE(workspace && workspace_bytes >= lvt_reduce_workspace_bytes(), "mse_fwd: workspace");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = grid_for(n / 4, 256 * 4, RED_BLOCKS);
+    hipLaunchKernelGGL(lvt_sqdiff_partial_kernel, dim3(blocks), dim3(256), 0, s, a, b, n / 4, (float *)workspace);
+    LVT_CHECK_LAUNCH("lvt_sqdiff_partial_kernel");
+    hipLaunchKernelGGL(lvt_scalar_finish_kernel, dim3(1), dim3(256), 0, s, (const float *)workspace, blocks,
+                       (float)((double)scale / denom), (const float *)nullptr, out);
+    LVT_CHECK_LAUNCH("lvt_scalar_finish_kernel");
+    return LVT_OK;
+}
+
+// out = add + g * (2*scale/denom) * (a - b) [* (1 - a^2)]      g = gout_dev[0] (or 1)
+__global__ void lvt_mse_bwd_kernel(const float *__restrict__ a, const float *__restrict__ b, long long n4, float c,
+                                   const float *__restrict__ gout, const float *__restrict__ add, int tanh_of_a,
+                                   float *__restrict__ out) {
+    const float g = (gout ? gout[0] : 1.0f) * c;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float4 x = reinterpret_cast<const float4 *>(a)[i];
+        const float4 y = reinterpret_cast<const float4 *>(b)[i];
+        float4 r = make_float4(g * (x.x - y.x), g * (x.y - y.y), g * (x.z - y.z), g * (x.w - y.w));
+        if (tanh_of_a) {
+            r.x *= 1.f - x.x * x.x; r.y *= 1.f - x.y * x.y; r.z *= 1.f - x.z * x.z; r.w *= 1.f - x.w * x.w;
+        }
+        if (add) {
+            const float4 z = reinterpret_cast<const float4 *>(add)[i];
+            r.x += z.x; r.y += z.y; r.z += z.z; r.w += z.w;
+        }
+        reinterpret_cast<float4 *>(out)[i] = r;
+    }
+}
+extern "C" int lvt_mse_bwd(const float *a, const float *b, long long n, double denom, float scale,
+                           const float *gout_dev, const float *add, int tanh_of_a, float *out, void *stream) {
+    LVT_REQUIRE(a && b && out && n > 0 && n % 4 == 0 && denom > 0, "mse_bwd: bad args");
+    hipLaunchKernelGGL(lvt_mse_bwd_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b,
+                       n / 4, (float)(2.0 * (double)scale / denom), gout_dev, add, tanh_of_a, out);
+    LVT_CHECK_LAUNCH("lvt_mse_bwd_kernel");
+    return LVT_OK;
+}
+
+// y = alpha * x (+ add)   -- small glue (gradient scaling / accumulation)
+__global__ void lvt_axpy_kernel(const float *__restrict__ x, const float *__restrict__ add, long long n,
+                                const float *__restrict__ alpha_dev, float alpha, float *__restrict__ out) {
+    const float a = alpha * (alpha_dev ? alpha_dev[0] : 1.0f);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        out[i] = a * x[i] + (add ? add[i] : 0.f);
+}
+extern "C" int lvt_axpy(const float *x, const float *add, long long n, const float *alpha_dev, float alpha,
+                        float *out, void *stream) {
+    LVT_REQUIRE(x && out && n > 0, "axpy: bad args");
+    hipLaunchKernelGGL(lvt_axpy_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, add, n,
+                       alpha_dev, alpha, out);
+    LVT_CHECK_LAUNCH("lvt_axpy_kernel");
+    return LVT_OK;
+}
+
+// out = g * (1 - y^2)   (tanh backward at the end of the decoder chain)
+__global__ void lvt_tanh_bwd_kernel(const float *__restrict__ g, const float *__restrict__ y, long long n4,
+                                    float *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float4 a = reinterpret_cast<const float4 *>(g)[i];
+        const float4 t = reinterpret_cast<const float4 *>(y)[i];
+        reinterpret_cast<float4 *>(out)[i] = make_float4(a.x * (1.f - t.x * t.x), a.y * (1.f - t.y * t.y),
+                                                         a.z * (1.f - t.z * t.z), a.w * (1.f - t.w * t.w));
+    }
+}
+extern "C" int lvt_tanh_bwd(const float *g, const float *y, long long n, float *out, void *stream) {
+    LVT_REQUIRE(g && y && out && n > 0 && n % 4 == 0, "tanh_bwd: bad args");
+    hipLaunchKernelGGL(lvt_tanh_bwd_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, g, y,
+                       n / 4, out);
+    LVT_CHECK_LAUNCH("lvt_tanh_bwd_kernel");
+    return LVT_OK;
+}
+
+// x[r][:] += table[r % P][:]   (positional encoding, vt_attention.py:25-50)
+__global__ void lvt_add_periodic_kernel(float *__restrict__ x, const float *__restrict__ table, long long rows,
+                                        int P, int d4) {
+    const long long total = rows * d4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / d4; const int c = i % d4;
+        float4 v = reinterpret_cast<float4 *>(x)[i];
+        const float4 t = reinterpret_cast<const float4 *>(table)[(r % P) * d4 + c];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        reinterpret_cast<float4 *>(x)[i] = v;
+    }
+}
+extern "C" int lvt_add_periodic(float *x, const float *table, long long rows, int P, int d, void *stream) {
+    LVT_REQUIRE(x && table && rows > 0 && P > 0 && d % 4 == 0, "add_periodic: bad args");
+    hipLaunchKernelGGL(lvt_add_periodic_kernel, dim3(grid_for(rows * (d / 4), 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, table, rows, P, d / 4);
+    LVT_CHECK_LAUNCH("lvt_add_periodic_kernel");
+    return LVT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (F.layer_norm, eps 1e-5; vt_attention.py:121,138; videotransformer.py:142)
+// one wave per row, row kept in registers (d <= 1024), two-pass mean / variance
+// ------------------------------------------------------------------------------------------------
+#define LN_MAXV 4   // float4 per lane -> d <= 1024
+__global__ void lvt_layernorm_fwd_kernel(const float *__restrict__ x, long long rows, int d, float eps,
+                                         const float *__restrict__ w, const float *__restrict__ b,
+                                         float *__restrict__ y, float *__restrict__ mean_out,
+                                         float *__restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int d4 = d / 4;
+    for (long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < rows;
+         row += ((long long)gridDim.x * blockDim.x) >> 6) {
+        const float4 *xp = reinterpret_cast<const float4 *>(x + row * d);
+        float4 v[LN_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < d4 ? xp[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        const float mean = wave_sum(s) / d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            if (lane + 64 * i < d4) {
+                const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / d + eps);
+        float4 *yp = reinterpret_cast<float4 *>(y + row * d);
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < d4) {
+                const float4 ww = reinterpret_cast<const float4 *>(w)[c];
+                const float4 bb = reinterpret_cast<const float4 *>(b)[c];
+                float4 o;
+                o.x = (v[i].x - mean) * rstd * ww.x + bb.x; o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
+                o.z = (v[i].z - mean) * rstd * ww.z + bb.z; o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
+                yp[c] = o;
+            }
+        }
+        if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    }
+}
+extern "C" int lvt_layernorm_fwd(const float *x, long long rows, int d, float eps, const float *w, const float *b,
+                                 float *y, float *mean, float *rstd, void *stream) {
+    LVT_REQUIRE(x && w && b && y && rows > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "layernorm_fwd: bad args (d=%d)", d);
+    hipLaunchKernelGGL(lvt_layernorm_fwd_kernel, dim3(grid_for(rows, 4, 16384)), dim3(256), 0, (hipStream_t)stream,
+                       x, rows, d, eps, w, b, y, mean, rstd);
+    LVT_CHECK_LAUNCH("lvt_layernorm_fwd_kernel");
+    return LVT_OK;
+}
+
+// dx = rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat)) (+ add);  partial dw/db per workgroup
+#define LN_BWD_BLOCKS 512
+__global__ __launch_bounds__(256) void lvt_layernorm_bwd_kernel(
+    const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ w, long long rows, int d, const float *__restrict__ add,
+    float *__restrict__ dx, float *__restrict__ pdw, float *__restrict__ pdb) {
+    __shared__ float sdw[4][256 * LN_MAXV];   // per-wave column partials, combined in wave order
+    __shared__ float sdb[4][256 * LN_MAXV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d4 = d / 4;
+    float4 adw[LN_MAXV], adb[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) { adw[i] = make_float4(0.f, 0.f, 0.f, 0.f); adb[i] = adw[i]; }
+    const long long rows_per_block = lvt_cdiv(rows, gridDim.x);
+    const long long r0 = blockIdx.x * rows_per_block;
+    const long long r1 = min(rows, r0 + rows_per_block);
+    for (long long row = r0 + wave; row < r1; row += 4) {
+        const float m = mean[row], rs = rstd[row];
+        const float4 *xp = reinterpret_cast<const float4 *>(x + row * d);
+        const float4 *gp = reinterpret_cast<const float4 *>(dy + row * d);
+        float4 xh[LN_MAXV], gw[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < d4) {
+                const float4 xv = xp[c], gv = gp[c], ww = reinterpret_cast<const float4 *>(w)[c];
+                xh[i] = make_float4((xv.x - m) * rs, (xv.y - m) * rs, (xv.z - m) * rs, (xv.w - m) * rs);
+                gw[i] = make_float4(gv.x * ww.x, gv.y * ww.y, gv.z * ww.z, gv.w * ww.w);
+                s1 += (gw[i].x + gw[i].y) + (gw[i].z + gw[i].w);
+                s2 += (gw[i].x * xh[i].x + gw[i].y * xh[i].y) + (gw[i].z * xh[i].z + gw[i].w * xh[i].w);
+                adw[i].x += gv.x * xh[i].x; adw[i].y += gv.y * xh[i].y; adw[i].z += gv.z * xh[i].z; adw[i].w += gv.w * xh[i].w;
+                adb[i].x += gv.x; adb[i].y += gv.y; adb[i].z += gv.z; adb[i].w += gv.w;
+            }
+        }
+        const float m1 = wave_sum(s1) / d, m2 = wave_sum(s2) / d;
+        float4 *op = reinterpret_cast<float4 *>(dx + row * d);
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < d4) {
+                float4 o;
+                o.x = rs * (gw[i].x - m1 - xh[i].x * m2); o.y = rs * (gw[i].y - m1 - xh[i].y * m2);
+                o.z = rs * (gw[i].z - m1 - xh[i].z * m2); o.w = rs * (gw[i].w - m1 - xh[i].w * m2);
+                if (add) {
+                    const float4 z = reinterpret_cast<const float4 *>(add + row * d)[c];
+                    o.x += z.x; o.y += z.y; o.z += z.z; o.w += z.w;
+                }
+                op[c] = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < d4) {
+            reinterpret_cast<float4 *>(sdw[wave])[c] = adw[i];
+            reinterpret_cast<float4 *>(sdb[wave])[c] = adb[i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        pdw[(long long)blockIdx.x * d + c] = ((sdw[0][c] + sdw[1][c]) + sdw[2][c]) + sdw[3][c];
+        pdb[(long long)blockIdx.x * d + c] = ((sdb[0][c] + sdb[1][c]) + sdb[2][c]) + sdb[3][c];
+    }
+}
+__global__ void lvt_rowsum_partials_kernel(const float *__restrict__ partial, int nblk, int n,
+                                           float *__restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * n + c];
+    out[c] = s;
+}
+extern "C" size_t lvt_layernorm_bwd_workspace_bytes(int d) { return (size_t)2 * LN_BWD_BLOCKS * d * sizeof(float); }
+extern "C" int lvt_layernorm_bwd(const float *dy, const float *x, const float *mean, const float *rstd,
+                                 const float *w, long long rows, int d, const float *add, float *dx, float *dw,
+                                 float *db, void *workspace, size_t workspace_bytes, void *stream) {
+    LVT_REQUIRE(dy && x && mean && rstd && w && dx && dw && db && rows > 0 && d % 4 == 0 && d <= 256 * LN_MAXV,
+                "layernorm_bwd: bad args");
+    LVT_REQUIRE(workspace && workspace_bytes >= lvt_layernorm_bwd_workspace_bytes(d), "layernorm_bwd: workspace");
+    hipStream_t s = (hipStream_t)stream;
+    int blocks = (int)(lvt_cdiv(rows, 8) < LN_BWD_BLOCKS ? lvt_cdiv(rows, 8) : LN_BWD_BLOCKS);
+    const long long rpb = lvt_cdiv(rows, blocks);
+    blocks = (int)lvt_cdiv(rows, rpb);
+    float *pdw = (float *)workspace, *pdb = pdw + (size_t)LN_BWD_BLOCKS * d;
+    hipLaunchKernelGGL(lvt_layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, s, dy, x, mean, rstd, w, rows, d, add,
+                       dx, pdw, pdb);
+    LVT_CHECK_LAUNCH("lvt_layernorm_bwd_kernel");
+    hipLaunchKernelGGL(lvt_rowsum_partials_kernel, dim3((d + 255) / 256), dim3(256), 0, s, pdw, blocks, d, dw);
+    hipLaunchKernelGGL(lvt_rowsum_partials_kernel, dim3((d + 255) / 256), dim3(256), 0, s, pdb, blocks, d, db);
+    LVT_CHECK_LAUNCH("lvt_rowsum_partials_kernel");
+    return LVT_OK;
+}

@@ -667,18 +667,20 @@ extern "C" int lvt_conv3d_pack_weight(const lvt_conv_geom *g, const float *w, in
 }
 
 extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias,
-                              const float *res, float *y, int flags, void *stream) {
+                              const float *res, const float *mask, float *y, int flags, void *stream) {
     int rc = check_geom(g, "conv3d_fwd"); if (rc) return rc;
     LVT_REQUIRE(x && wp && y, "conv3d_fwd: null pointer");
     LVT_REQUIRE(!(flags & LVT_EPI_BIAS) || bias, "conv3d_fwd: BIAS without bias");
     LVT_REQUIRE(!(flags & LVT_EPI_RESIDUAL) || res, "conv3d_fwd: RESIDUAL without res");
-    LVT_REQUIRE(!(flags & (LVT_EPI_MASK | LVT_EPI_ACCUM)), "conv3d_fwd: unsupported flag");
+    LVT_REQUIRE(!(flags & LVT_EPI_MASK) || mask, "conv3d_fwd: MASK without mask");
+    LVT_REQUIRE(!(flags & LVT_EPI_ACCUM), "conv3d_fwd: unsupported flag");
     const long long M = (long long)g->N * g->To * g->Ho * g->Wo;
     LVT_REQUIRE(M < 0x7fffffffLL, "conv3d_fwd: too many output positions");
     KParams p; memset(&p, 0, sizeof(p));
     p.M = (int)M; p.N = g->Co; p.K = g->Kt * g->Kh * g->Kw * g->Ci;
     p.A = x; p.B = wp; p.ldb = g->Co; p.C = y; p.ldc = g->Co; p.batch_inner = 1;
-    p.alpha = 1.f; p.flags = flags; p.bias = bias; p.res = res; p.ldr = g->Co; p.splits = 1; p.g = *g;
+    p.alpha = 1.f; p.flags = flags; p.bias = bias; p.res = res; p.ldr = g->Co; p.mask = mask; p.ldm = g->Co;
+    p.splits = 1; p.g = *g;
     if (g->Co <= 32) return launch_tile<A_CONV_K, B_NPLAIN, 128, 32, 4, 1>(p, 1, (hipStream_t)stream);
     return launch_tile<A_CONV_K, B_NPLAIN, 128, 128, 2, 2>(p, 1, (hipStream_t)stream);
 }

@@ -25,7 +25,7 @@ void lvt_set_error(const char *fmt, ...);
     } while (0)
 
 static inline bool lvt_aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
-static inline long long lvt_cdiv(long long a, long long b) { return (a + b - 1) / b; }
+static inline __host__ __device__ long long lvt_cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
 // 256 CUs x 8 XCDs on MI355X; used only to size grids / split-K, never for correctness.
 #define LVT_NUM_CU 256

@@ -56,12 +56,27 @@ def _declare(lib):
         "lvt_gemm_workspace_bytes": (sz, [P(GemmDesc)]),
         "lvt_gemm_f32": (ci, [P(GemmDesc), vp, sz, vp]),
         "lvt_conv3d_pack_weight": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
-        "lvt_conv3d_fwd": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, ci, vp]),
+        "lvt_conv3d_fwd": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
         "lvt_conv3d_bwd_data": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
         "lvt_conv3d_bwd_weight_workspace_bytes": (sz, [P(ConvGeom)]),
         "lvt_conv3d_bwd_weight": (ci, [P(ConvGeom), vp, vp, vp, ci, ci, vp, sz, vp]),
         "lvt_colsum_workspace_bytes": (sz, [cll, ci]),
         "lvt_colsum": (ci, [vp, cll, ci, cll, vp, vp, sz, vp]),
+        "lvt_vq_nearest": (ci, [vp, cll, ci, ci, ci, ci, vp, vp, ci, vp]),
+        "lvt_vq_gather": (ci, [vp, vp, cll, ci, ci, ci, ci, vp, ci, vp]),
+        "lvt_vq_ema_accumulate": (ci, [vp, vp, cll, ci, ci, ci, ci, ci, vp, vp]),
+        "lvt_vq_ema_finalize": (ci, [vp, ci, ci, ci, cf, cf, vp, vp, vp, vp]),
+        "lvt_to_channels_last": (ci, [vp, ci, ci, cll, ci, ci, vp, vp, vp, vp]),
+        "lvt_to_channels_first": (ci, [vp, ci, ci, cll, ci, ci, vp, vp, cf, cf, vp, vp]),
+        "lvt_reduce_workspace_bytes": (sz, []),
+        "lvt_mse_fwd": (ci, [vp, vp, cll, C.c_double, cf, vp, vp, sz, vp]),
+        "lvt_mse_bwd": (ci, [vp, vp, cll, C.c_double, cf, vp, vp, ci, vp, vp]),
+        "lvt_tanh_bwd": (ci, [vp, vp, cll, vp, vp]),
+        "lvt_axpy": (ci, [vp, vp, cll, vp, cf, vp, vp]),
+        "lvt_add_periodic": (ci, [vp, vp, cll, ci, ci, vp]),
+        "lvt_layernorm_fwd": (ci, [vp, cll, ci, cf, vp, vp, vp, vp, vp, vp]),
+        "lvt_layernorm_bwd_workspace_bytes": (sz, [ci]),
+        "lvt_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, cll, ci, vp, vp, vp, vp, vp, sz, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)

@@ -1,0 +1,127 @@
+"""Fused conv-stack executor: runs a chain of (transposed) convolutions with bias / ReLU / tanh /
+residual epilogues on the implicit-GEMM engine, and its hand-scheduled backward.
+
+Every activation is stored once, post-activation and channels-last.  ReLU backward is folded into
+the epilogue of the kernel that produces the upstream gradient (mask = saved post-ReLU output) and
+residual gradients are added in the same epilogue, so the backward chain is exactly three engine
+launches per layer (bwd-data, bwd-weight, bias column-sum) with no stand-alone elementwise pass.
+"""
+import torch
+
+from . import binding as L
+from . import gemm as G
+from . import ew
+
+
+class Layer:
+    """One conv / ConvTranspose layer of a stack.
+
+    kind: "conv" | "convT".  For convT the geometry is that of the equivalent forward conv whose
+    backward-data IS this layer (Ci = out channels of the ConvTranspose, Co = its in channels).
+    act: "" | "relu" | "tanh".  res_from: index of an earlier output added before the activation
+    (-1: none).  ci_real / co_real: channel counts of the torch-layout weight (pads excluded).
+    """
+
+    def __init__(self, kind, kernel, stride, pad, cin, cout, act="", res_from=-1):
+        self.kind, self.kernel, self.stride, self.pad = kind, kernel, stride, pad
+        self.cin, self.cout, self.act, self.res_from = cin, cout, act, res_from
+
+    @staticmethod
+    def pad4(c):
+        return (c + 3) // 4 * 4
+
+
+def _geom(layer, x_shape):
+    """Geometry of the forward conv the engine sees, given the channels-last input shape."""
+    N, T, H, W, _ = x_shape
+    ci, co = Layer.pad4(layer.cin), Layer.pad4(layer.cout)
+    if layer.kind == "conv":
+        return G.conv_geom(N, T, H, W, ci, co, layer.kernel, layer.stride, layer.pad)
+    # ConvTranspose: output extent = (in - 1) * s - 2p + k ; equivalent conv maps output -> input
+    To, Ho, Wo = [(i - 1) * s - 2 * p + k for i, s, p, k in zip((T, H, W), layer.stride, layer.pad, layer.kernel)]
+    g = G.conv_geom(N, To, Ho, Wo, co, ci, layer.kernel, layer.stride, layer.pad)
+    assert (g.To, g.Ho, g.Wo) == (T, H, W), "ConvTranspose geometry mismatch"
+    return g
+
+
+def _padded_bias(layer, b):
+    co = Layer.pad4(layer.cout)
+    if b is None or b.numel() == co:
+        return b
+    return torch.cat([b, b.new_zeros(co - b.numel())])
+
+
+def _act_flag(act):
+    return {"": 0, "relu": L.EPI_RELU, "tanh": L.EPI_TANH}[act]
+
+
+def stack_forward(layers, x, params):
+    """x: (N,T,H,W,C) channels-last.  params: [(weight, bias)] in torch layout.
+    Returns (outs, saved) where outs[i] is the post-activation output of layer i."""
+    outs, geoms, packed = [], [], []
+    cur = x
+    for i, (ly, (w, b)) in enumerate(zip(layers, params)):
+        g = _geom(ly, cur.shape)
+        if ly.kind == "conv":
+            wp = G.pack_weight(g, w, ly.cin, ly.cout)
+        else:
+            wp = G.pack_weight(g, w, ly.cout, ly.cin)   # ConvTranspose weight is (in, out, k..) == conv (Co, Ci)
+        res = outs[ly.res_from] if ly.res_from >= 0 else None
+        bias = _padded_bias(ly, b)
+        if ly.kind == "conv":
+            y = G.conv_fwd(g, cur, wp, bias=bias, res=res, flags=_act_flag(ly.act))
+        else:
+            y = G.conv_bwd_data(g, cur, wp, bias=bias, res=res, flags=_act_flag(ly.act))
+        outs.append(y)
+        geoms.append(g)
+        packed.append(wp)
+        cur = y
+    return outs, (geoms, packed)
+
+
+def stack_backward(layers, x, outs, saved, grad_out, need_input_grad=False):
+    """grad_out: dL/d(outs[-1]) (post-activation).  Returns (grad_x or None, [(dw, db)])."""
+    geoms, packed = saved
+    n = len(layers)
+    # g_pre of the last layer
+    last = layers[-1]
+    if last.act == "tanh":
+        gpre = ew.tanh_bwd(grad_out, outs[-1])
+    elif last.act == "relu":
+        raise L.LvtError("a ReLU-terminated stack is not used by the reference architectures")
+    else:
+        gpre = grad_out
+    # residual consumers: res_grad[j] = g_pre of the layer that used outs[j] as its residual
+    res_user = {ly.res_from: i for i, ly in enumerate(layers) if ly.res_from >= 0}
+    gpres = [None] * n
+    gpres[n - 1] = gpre
+    grads = [None] * n
+    for i in range(n - 1, -1, -1):
+        ly, g, wp = layers[i], geoms[i], packed[i]
+        inp = outs[i - 1] if i > 0 else x
+        gp = gpres[i]
+        # parameter gradients
+        co = Layer.pad4(ly.cout)
+        if ly.kind == "conv":
+            dw = G.conv_bwd_weight(g, inp, gp, ly.cin, ly.cout)
+        else:
+            dw = G.conv_bwd_weight(g, gp, inp, ly.cout, ly.cin)
+        db = G.colsum(gp, gp.numel() // co, co)[:ly.cout]
+        grads[i] = (dw, db)      # dw is (Co, Ci, Kt, Kh, Kw); callers view it as the parameter shape
+        # gradient w.r.t. the layer input == g_pre of layer i-1 (mask / residual folded in)
+        if i == 0 and not need_input_grad:
+            break
+        prev = layers[i - 1] if i > 0 else None
+        res = gpres[res_user[i - 1]] if (i - 1) in res_user else None
+        mask = outs[i - 1] if (prev is not None and prev.act == "relu") else None
+        if prev is not None and prev.act == "tanh":
+            raise L.LvtError("tanh is only supported on the last layer of a stack")
+        if ly.kind == "conv":
+            gin = G.conv_bwd_data(g, gp, wp, res=res, mask=mask)
+        else:
+            gin = G.conv_fwd(g, gp, wp, res=res, mask=mask)
+        if i > 0:
+            gpres[i - 1] = gin
+        else:
+            return gin, grads
+    return None, grads

@@ -1,0 +1,101 @@
+"""Typed wrappers over the HBM-bound helper kernels (csrc/elementwise.hip)."""
+import ctypes as C
+
+import torch
+
+from . import binding as L
+
+
+def _f32(*shape, like):
+    return torch.empty(*shape, dtype=torch.float32, device=like.device)
+
+
+def to_channels_last(x_bcr, ldo, mode=0, a=None, s=None):
+    """(B, C, R) -> (B, R, ldo) with zero-padded channels; mode 1 applies (x - a[c]) / s[c]."""
+    L.require(x_bcr, a, s)
+    B, Cc, R = x_bcr.shape
+    out = _f32(B, R, ldo, like=x_bcr)
+    L.check(L.lib().lvt_to_channels_last(L.ptr(x_bcr), B, Cc, R, ldo, mode, L.ptr(a), L.ptr(s), L.ptr(out),
+                                         L.stream_ptr()), "lvt_to_channels_last")
+    return out
+
+
+def to_channels_first(x_brc, Cc, mode=0, a=None, s=None, lo=0.0, hi=0.0):
+    """(B, R, ldi) -> (B, C, R); mode 2 applies clamp(x * s[c] + a[c], lo, hi)."""
+    L.require(x_brc, a, s)
+    B, R, ldi = x_brc.shape
+    out = _f32(B, Cc, R, like=x_brc)
+    L.check(L.lib().lvt_to_channels_first(L.ptr(x_brc), B, Cc, R, ldi, mode, L.ptr(a), L.ptr(s), lo, hi,
+                                          L.ptr(out), L.stream_ptr()), "lvt_to_channels_first")
+    return out
+
+
+def _red_ws(dev):
+    n = L.lib().lvt_reduce_workspace_bytes()
+    return L.workspace(n, dev, "reduce"), n
+
+
+def mse_fwd(a, b, denom, scale=1.0):
+    L.require(a, b)
+    out = _f32(1, like=a)
+    ws, n = _red_ws(a.device)
+    L.check(L.lib().lvt_mse_fwd(L.ptr(a), L.ptr(b), a.numel(), float(denom), scale, L.ptr(out), L.ptr(ws), n,
+                                L.stream_ptr()), "lvt_mse_fwd")
+    return out.view(())
+
+
+def mse_bwd(a, b, denom, scale=1.0, gout=None, add=None, tanh_of_a=False):
+    L.require(a, b, gout, add)
+    out = torch.empty_like(a)
+    L.check(L.lib().lvt_mse_bwd(L.ptr(a), L.ptr(b), a.numel(), float(denom), scale, L.ptr(gout), L.ptr(add),
+                                1 if tanh_of_a else 0, L.ptr(out), L.stream_ptr()), "lvt_mse_bwd")
+    return out
+
+
+def tanh_bwd(g, y):
+    L.require(g, y)
+    out = torch.empty_like(g)
+    L.check(L.lib().lvt_tanh_bwd(L.ptr(g), L.ptr(y), g.numel(), L.ptr(out), L.stream_ptr()), "lvt_tanh_bwd")
+    return out
+
+
+def axpy(x, alpha=1.0, alpha_dev=None, add=None):
+    L.require(x, alpha_dev, add)
+    out = torch.empty_like(x)
+    L.check(L.lib().lvt_axpy(L.ptr(x), L.ptr(add), x.numel(), L.ptr(alpha_dev), alpha, L.ptr(out), L.stream_ptr()),
+            "lvt_axpy")
+    return out
+
+
+def add_periodic_(x, table, P):
+    L.require(x, table)
+    d = x.shape[-1]
+    L.check(L.lib().lvt_add_periodic(L.ptr(x), L.ptr(table), x.numel() // d, P, d, L.stream_ptr()),
+            "lvt_add_periodic")
+    return x
+
+
+def layernorm_fwd(x, w, b, eps=1e-5, save_stats=True):
+    L.require(x, w, b)
+    d = x.shape[-1]
+    rows = x.numel() // d
+    y = torch.empty_like(x)
+    mean = _f32(rows, like=x) if save_stats else None
+    rstd = _f32(rows, like=x) if save_stats else None
+    L.check(L.lib().lvt_layernorm_fwd(L.ptr(x), rows, d, eps, L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(mean),
+                                      L.ptr(rstd), L.stream_ptr()), "lvt_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, w, add=None):
+    L.require(dy, x, mean, rstd, w, add)
+    d = x.shape[-1]
+    rows = x.numel() // d
+    dx = torch.empty_like(x)
+    dw, db = _f32(d, like=x), _f32(d, like=x)
+    n = L.lib().lvt_layernorm_bwd_workspace_bytes(d)
+    ws = L.workspace(n, x.device, "ln")
+    L.check(L.lib().lvt_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(w), rows, d, L.ptr(add),
+                                      L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws), n, L.stream_ptr()),
+            "lvt_layernorm_bwd")
+    return dx, dw, db

@@ -58,15 +58,17 @@ def pack_weight(g, w, Ci_real, Co_real):
     return wp
 
 
-def conv_fwd(g, x, wp, bias=None, res=None, flags=0):
-    L.require(x, wp, bias, res)
+def conv_fwd(g, x, wp, bias=None, res=None, mask=None, flags=0):
+    L.require(x, wp, bias, res, mask)
     y = torch.empty(g.N, g.To, g.Ho, g.Wo, g.Co, dtype=torch.float32, device=x.device)
     if bias is not None:
         flags |= L.EPI_BIAS
     if res is not None:
         flags |= L.EPI_RESIDUAL
-    L.check(L.lib().lvt_conv3d_fwd(C.byref(g), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(y), flags,
-                                   L.stream_ptr()), "lvt_conv3d_fwd")
+    if mask is not None:
+        flags |= L.EPI_MASK
+    L.check(L.lib().lvt_conv3d_fwd(C.byref(g), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(mask), L.ptr(y),
+                                   flags, L.stream_ptr()), "lvt_conv3d_fwd")
     return y
 
 

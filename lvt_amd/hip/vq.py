@@ -1,0 +1,45 @@
+"""Typed wrappers over the vector-quantiser kernels (csrc/vq.hip)."""
+import torch
+
+from . import binding as L
+
+
+def nearest(z, codebooks, P):
+    """z (rows, ldz) channels-last, codebooks (num, K, D) -> idx int64 (rows/P, num, P)."""
+    L.require(z, codebooks)
+    rows, ldz = z.shape
+    num, K, D = codebooks.shape
+    idx = torch.empty(rows // P, num, P, dtype=torch.int64, device=z.device)
+    L.check(L.lib().lvt_vq_nearest(L.ptr(z), rows, ldz, num, D, K, L.ptr(codebooks), L.ptr(idx), P, L.stream_ptr()),
+            "lvt_vq_nearest")
+    return idx
+
+
+def gather(idx, codebooks):
+    """idx (n, num, P) int64 -> (n*P, num*D) channels-last rows of selected code vectors."""
+    L.require(idx, codebooks)
+    n, num, P = idx.shape
+    _, K, D = codebooks.shape
+    out = torch.empty(n * P, num * D, dtype=torch.float32, device=idx.device)
+    L.check(L.lib().lvt_vq_gather(L.ptr(idx), L.ptr(codebooks), n * P, num, D, K, P, L.ptr(out), num * D,
+                                  L.stream_ptr()), "lvt_vq_gather")
+    return out
+
+
+def ema_accumulate(idx, z, K):
+    """-> stats (num, K, D+1): per-code sums and counts of the rows assigned to each code."""
+    L.require(idx, z)
+    n, num, P = idx.shape
+    rows, ldz = z.shape
+    D = ldz // num
+    stats = torch.empty(num, K, D + 1, dtype=torch.float32, device=z.device)
+    L.check(L.lib().lvt_vq_ema_accumulate(L.ptr(idx), L.ptr(z), rows, ldz, num, D, K, P, L.ptr(stats),
+                                          L.stream_ptr()), "lvt_vq_ema_accumulate")
+    return stats
+
+
+def ema_finalize(stats, running_size, running_sum, weight, decay=0.99, eps=1e-5):
+    L.require(stats, running_size, running_sum, weight)
+    num, K, D = weight.shape
+    L.check(L.lib().lvt_vq_ema_finalize(L.ptr(stats), num, D, K, decay, eps, L.ptr(running_size),
+                                        L.ptr(running_sum), L.ptr(weight), L.stream_ptr()), "lvt_vq_ema_finalize")

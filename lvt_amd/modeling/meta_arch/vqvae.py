@@ -1,0 +1,91 @@
+"""VQ-VAE meta-architecture (reference: vidgen/modeling/meta_arch/vqvae.py:17-124).
+
+supervised step:  x -> ResEncoder -> z_e -> DVQ "st" (indices, z_q_st from the pre-update codebook,
+EMA update, z_q_bar from the post-update codebook) -> ResDecoder -> x_tilde;
+losses: lambda * mse(x_tilde, x)  and  beta * mse(z_e, sg(z_q_bar)).
+"""
+import os
+
+from ...solver import build_lr_scheduler, build_optimizer
+from ...utils.checkpoint import Checkpointer
+from ..loss import PixelLoss
+from ..loss.loss import mse
+from ..vq import DVQEmbedding
+from .ae import AutoEncoderModel
+from .build import META_ARCH_REGISTRY
+
+
+@META_ARCH_REGISTRY.register()
+class VQVAEModel(AutoEncoderModel):
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        cb = cfg.MODEL.CODEBOOK
+        self.use_codebook_ema = cb.EMA
+        if cb.NUM == 1:
+            raise NotImplementedError("single-codebook VQEmbedding (CODEBOOK.NUM 1) is not used by the shipped "
+                                      "configs; the HIP quantiser handles the product form")
+        self.codebook = DVQEmbedding(cb.NUM, cb.SIZE, cb.DIM, self.use_codebook_ema)
+        if self.use_codebook_ema:
+            self._set_requires_grad(self.codebook.parameters(), False)
+        self.pixel_loss = PixelLoss(cfg)
+        self.beta = cb.BETA
+        self.to(self.device)
+
+    def train(self, mode=True):
+        super().train(mode)
+        self.codebook.train(mode)
+        return self
+
+    def _generator_parameters(self):
+        params = super()._generator_parameters()
+        if not self.use_codebook_ema:
+            params += list(self.codebook.parameters())
+        return params
+
+    def forward(self, data, mode="inference"):
+        return super().forward(data, mode)
+
+    # ---- channels-last internals --------------------------------------------------------------------
+    def _latent_cl(self, x):
+        return self.codebook.indices_cl(self.encoder.forward_cl(x))          # (N,num,h,w) int64
+
+    def _latent_public(self, latent):
+        return latent
+
+    def _decode_cl(self, latent):
+        return self.generator.forward_cl(self.codebook.embed_cl(latent))
+
+    def _supervised_loss_cl(self, x, return_x=False):
+        z_e = self.encoder.forward_cl(x)
+        z_q_st, z_q_bar = self.codebook.straight_through_cl(z_e)
+        x_tilde = self.generator.forward_cl(z_q_st)
+        c = len(self.cfg.MODEL.PIXEL_MEAN)
+        loss = {
+            "loss_reconstruction": self.pixel_loss(x_tilde, x, denom=x.numel() // x.shape[-1] * c),
+            "loss_commitment": mse(z_e, z_q_bar, scale=self.beta),
+        }
+        return (loss, x, x_tilde) if return_x else loss
+
+    def _generator_loss_cl(self, x):
+        return self._supervised_loss_cl(x)
+
+    # ---- reference tensor-level API (vqvae.py:61-106) ----------------------------------------------
+    def compute_supervised_loss(self, x, return_x=False):
+        return self._supervised_loss_cl(self._as_cl(x), return_x)
+
+    def decode(self, latents):
+        """(N,num,h,w) int64 codes -> (N,C,H,W) in normalised space."""
+        from .. import convstack
+        self._require_gpu()
+        y = self._decode_cl(latents.to(self.device))
+        return convstack.cl_to_nchw(y, self.generator.out_channels)
+
+    def configure_optimizers_and_checkpointers(self):
+        o, c = super().configure_optimizers_and_checkpointers()
+        if not self.use_codebook_ema:
+            opt = build_optimizer(self.codebook, self.cfg, suffix="_G")
+            o.append({"optimizer": opt, "scheduler": build_lr_scheduler(self.cfg, opt), "type": "generator"})
+        os.makedirs(os.path.join(self.cfg.OUTPUT_DIR, "netC"), exist_ok=True)
+        c.append({"checkpointer": Checkpointer(self.codebook, os.path.join(self.cfg.OUTPUT_DIR, "netC")),
+                  "pretrained": self.cfg.MODEL.CODEBOOK.WEIGHTS})
+        return o, c

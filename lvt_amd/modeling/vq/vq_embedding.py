@@ -1,0 +1,127 @@
+"""Product vector quantiser with EMA codebooks (reference: vidgen/modeling/vq/vq_embedding.py:9-99,
+vq_utils.py:5-65).
+
+State layout is the reference's (`ve.i.embedding.weight`, `ve.i.running_size`, `ve.i.running_sum`)
+but the tensors are views into three flat device buffers (num, K, D) so that all `num` codebooks
+are quantised, gathered and EMA-updated by single kernel launches.
+
+Deliberate, documented deviations:
+  * `running_sum` owns its storage.  The reference registers it as `weight.detach()`, which on CPU
+    aliases the codebook; on a GPU `.to(device)` de-aliases.  GPU semantics are kept.
+  * multi-GPU EMA statistics are summed with ONE all-reduce of a packed (num, K, D+1) buffer instead of
+    2*num all_gather+sum round trips (vq_embedding.py:46-47, 53-54); the sum is the same.
+"""
+import torch
+from torch import nn
+
+from ...hip import binding as L
+from ...hip import ew, vq
+from ...layers import all_reduce_sum_
+from .. import convstack
+
+
+class VQEmbedding(nn.Module):
+    """One codebook: parameter / buffer container (vq_embedding.py:9-21)."""
+
+    def __init__(self, K, D, ema):
+        super().__init__()
+        self.embedding = nn.Embedding(K, D)
+        self.embedding.weight.data.uniform_(-1.0 / K, 1.0 / K)
+        self.K, self.D, self.ema = K, D, ema
+        if ema:
+            self.eps, self.decay = 1e-5, 0.99
+            self.register_buffer("running_size", torch.zeros(K))
+            self.register_buffer("running_sum", self.embedding.weight.detach().clone())
+
+
+class _StraightThroughFn(torch.autograd.Function):
+    """vq_st + EMA + z_q_bar gather as one autograd node (vq_utils.py:34-65, vq_embedding.py:35-66)."""
+
+    @staticmethod
+    def forward(ctx, z2d, owner, P):
+        w, rsize, rsum = owner._flat()
+        idx = vq.nearest(z2d, w, P)
+        z_q_st = vq.gather(idx, w)                       # from the PRE-update codebook
+        if owner.ema:
+            stats = vq.ema_accumulate(idx, z2d, owner.K)
+            all_reduce_sum_(stats)
+            vq.ema_finalize(stats, rsize, rsum, w, owner.decay, owner.eps)
+        z_q_bar = vq.gather(idx, w)                      # from the POST-update codebook
+        ctx.mark_non_differentiable(z_q_bar, idx)
+        return z_q_st, z_q_bar, idx
+
+    @staticmethod
+    def backward(ctx, g_st, g_bar, g_idx):
+        return g_st, None, None                          # straight-through (vq_utils.py:52-54)
+
+
+class DVQEmbedding(nn.Module):
+    def __init__(self, num, K, D, ema):
+        super().__init__()
+        assert D % num == 0
+        if D // num != 64:
+            raise NotImplementedError("the HIP quantiser is instantiated for 64-d sub-vectors (got %d)" % (D // num))
+        if not ema:
+            raise NotImplementedError("non-EMA codebooks are not used by any shipped config")
+        self.num, self.D, self.K, self.ema = num, D, K, ema
+        self.decay, self.eps = 0.99, 1e-5
+        self.ve = nn.ModuleList([VQEmbedding(K, D // num, ema) for _ in range(num)])
+        self._flat_w = self._flat_rs = self._flat_rsum = None
+
+    # ---- flat storage ----------------------------------------------------------------------------
+    def _flat(self):
+        """(weights (num,K,d), running_size (num,K), running_sum (num,K,d)) whose slices ARE the
+        per-codebook parameters / buffers.  Rebuilt whenever a `.to()` / load replaced the storage."""
+        w0 = self.ve[0].embedding.weight
+        fw = self._flat_w
+        ok = fw is not None and fw.device == w0.device and all(
+            self.ve[i].embedding.weight.data_ptr() == fw[i].data_ptr()
+            and self.ve[i].running_size.data_ptr() == self._flat_rs[i].data_ptr()
+            and self.ve[i].running_sum.data_ptr() == self._flat_rsum[i].data_ptr() for i in range(self.num))
+        if not ok:
+            with torch.no_grad():
+                fw = torch.stack([v.embedding.weight.data for v in self.ve]).contiguous()
+                frs = torch.stack([v.running_size for v in self.ve]).contiguous()
+                frsum = torch.stack([v.running_sum for v in self.ve]).contiguous()
+                for i, v in enumerate(self.ve):
+                    v.embedding.weight.data = fw[i]
+                    v.running_size = frs[i]
+                    v.running_sum = frsum[i]
+            self._flat_w, self._flat_rs, self._flat_rsum = fw, frs, frsum
+        return self._flat_w, self._flat_rs, self._flat_rsum
+
+    # ---- channels-last fast paths (used by VQVAEModel) -----------------------------------------------
+    def indices_cl(self, z_cl):
+        """(N,1,H,W,D) -> (N,num,H,W) int64."""
+        n, _, h, w, d = z_cl.shape
+        L.require(z_cl)
+        idx = vq.nearest(z_cl.view(n * h * w, d), self._flat()[0], h * w)
+        return idx.view(n, self.num, h, w)
+
+    def straight_through_cl(self, z_cl):
+        """(N,1,H,W,D) -> (z_q_st, z_q_bar) channels-last; updates the EMA state (vq_embedding.py:35-66)."""
+        n, _, h, w, d = z_cl.shape
+        L.require(z_cl)
+        z_q_st, z_q_bar, idx = _StraightThroughFn.apply(z_cl.view(n * h * w, d), self, h * w)
+        self.last_indices = idx.view(n, self.num, h, w)      # kept for evaluators / tests
+        return z_q_st.view(n, 1, h, w, d), z_q_bar.view(n, 1, h, w, d)
+
+    def embed_cl(self, latents):
+        """(N,num,H,W) int64 -> (N,1,H,W,D) channels-last."""
+        n, num, h, w = latents.shape
+        L.require(latents)
+        out = vq.gather(latents.contiguous().view(n, num, h * w), self._flat()[0])
+        return out.view(n, 1, h, w, self.D)
+
+    # ---- the reference's call contract (vq_embedding.py:77-99) ------------------------------------
+    def forward(self, z_e_x, mode=""):
+        if mode == "":
+            assert z_e_x.dim() == 4
+            return self.indices_cl(convstack._LayoutIn.apply(z_e_x))
+        if mode == "st":
+            assert z_e_x.dim() == 4
+            st, bar = self.straight_through_cl(convstack._LayoutIn.apply(z_e_x))
+            return convstack._LayoutOut.apply(st, self.D), convstack._LayoutOut.apply(bar, self.D)
+        if mode == "emb":
+            return self.embed_cl(z_e_x).squeeze(1)       # (N,H,W,D), as torch.cat(..., dim=-1) yields
+        raise ValueError

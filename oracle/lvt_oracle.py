@@ -141,7 +141,8 @@ def vq_straight_through(x_last, codebook):
 # --------------------------------------------------------------------------------------------
 # A5  EMA codebook update                      (vq/vq_embedding.py:35-66)
 # --------------------------------------------------------------------------------------------
-def vq_ema_step(state, z_e_part, decay=0.99, eps=1e-5, all_reduce=None, alias_running_sum=False):
+def vq_ema_step(state, z_e_part, decay=0.99, eps=1e-5, all_reduce=None, alias_running_sum=False,
+                force_idx=None):
     """One `_straight_through` call of VQEmbedding with ema=True.
 
     state: dict with 'embedding.weight' (K,D), 'running_size' (K,), 'running_sum' (K,D).
@@ -158,6 +159,10 @@ def vq_ema_step(state, z_e_part, decay=0.99, eps=1e-5, all_reduce=None, alias_ru
     k = w.size(0)
     x = z_e_part.permute(0, 2, 3, 1).contiguous()
     codes, idx = vq_straight_through(x, w)
+    if force_idx is not None:
+        # test hook: continue with externally chosen indices (isolates tie-breaking from the rest)
+        idx = force_idx.reshape(-1)
+        codes = torch.index_select(w, 0, idx).view_as(x)
     z_q_st = codes.permute(0, 3, 1, 2).contiguous()
 
     size = torch.zeros(k, dtype=torch.int64)
@@ -203,13 +208,14 @@ def dvq_indices(state, z_e, num=4):
     return torch.stack(out, dim=1)
 
 
-def dvq_straight_through(state, z_e, num=4, all_reduce=None, alias_running_sum=False):
+def dvq_straight_through(state, z_e, num=4, all_reduce=None, alias_running_sum=False, force_idx=None):
     """mode "st" (vq_embedding.py:84-91).  Returns (z_q_st, z_q_bar, new_state, idx (num, N*H*W))."""
     assert z_e.dim() == 4 and z_e.size(1) % num == 0
     r1, r2, idxs, new_state = [], [], [], {}
     for i, part in enumerate(z_e.split(z_e.size(1) // num, dim=1)):
         a, b, ns, idx = vq_ema_step(_split_state(state, i), part, all_reduce=all_reduce,
-                                    alias_running_sum=alias_running_sum)
+                                    alias_running_sum=alias_running_sum,
+                                    force_idx=None if force_idx is None else force_idx[:, i])
         r1.append(a)
         r2.append(b)
         idxs.append(idx)
@@ -240,7 +246,7 @@ class _StraightThrough(torch.autograd.Function):
 
 
 def vqvae_supervised_loss(enc, dec, cb_state, x, beta=1.0, lam=1.0, num=4, all_reduce=None,
-                          alias_running_sum=False):
+                          alias_running_sum=False, force_idx=None):
     """compute_supervised_loss (vqvae.py:66-91).  x already normalised, (N,3,H,W) or (B,T,3,H,W).
 
     Returns (loss_dict, new_codebook_state, aux) with aux = dict(z_e, z_q_st, x_tilde, idx).
@@ -250,7 +256,7 @@ def vqvae_supervised_loss(enc, dec, cb_state, x, beta=1.0, lam=1.0, num=4, all_r
         x = x.reshape(b * t, c, h, w)
     z_e = res_encoder(enc, x)
     z_q_st_val, z_q_bar, new_state, idx = dvq_straight_through(
-        cb_state, z_e.detach(), num, all_reduce, alias_running_sum)
+        cb_state, z_e.detach(), num, all_reduce, alias_running_sum, force_idx)
     z_q_st = _StraightThrough.apply(z_e, z_q_st_val)
     x_tilde = res_decoder(dec, z_q_st)
     losses = {
