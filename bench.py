@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""Headline benchmark: PR-DVQVAE2 train step on synthetic BAIR-shaped clips (64x64x16), batch 32 clips
+per GPU, fp32, on N MI355X of one node (BASELINE.json `configs[1]`, metric video-clips/s/node).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward + backward + Adam step of the whole VQ-VAE (encoder, 4x512 EMA codebooks, decoder) on
+one batch that is already resident in HBM.  One process per GPU; gradients are averaged with a bucketed
+RCCL all-reduce overlapped with backward, EMA statistics with one fused all-reduce.  Weak scaling.
+Rank 0 prints ONE JSON line; `roofline` describes the dominant kernel (the fp32-MFMA implicit-GEMM engine,
+timed per launch with HIP events on the launch stream inside the timed region) and `cpu_baseline` is the
+CPU oracle (a port of the reference's PyTorch-CPU path) timed on the host cores of the same box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+CLIP_FRAMES = 16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-clips", type=int, default=32, help="clips per GPU per step (BASELINE: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def build_vqvae(device, seed):
+    from lvt_amd.config import get_cfg
+    from lvt_amd.modeling import build_model
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs/vqvae/PR-DVQVAE2.yaml"))
+    cfg.MODEL.DEVICE = device
+    cfg.OUTPUT_DIR = "/tmp/lvt_bench_out"
+    torch.manual_seed(seed)
+    model = build_model(cfg)
+    model.train()
+    return cfg, model
+
+
+def vqvae_step(model, optimizers, data, storage_iter):
+    from lvt_amd.utils.events import EventStorage
+    with EventStorage(storage_iter):
+        losses = model(data, mode="supervised")
+    total = sum(losses.values())
+    total.backward()
+    if hasattr(model, "finish_gradient_sync"):
+        model.finish_gradient_sync()
+    for o in optimizers:
+        o["optimizer"].step()
+    for o in optimizers:
+        o["optimizer"].zero_grad()
+    return losses
+
+
+def cpu_baseline(batch_clips, budget_s):
+    """Time the CPU oracle's VQ-VAE train step (fwd + bwd + Adam) on this host's cores."""
+    import seeded
+    from oracle import lvt_oracle as O
+    seed = 29871897
+    enc = {k: v.requires_grad_(True) for k, v in seeded.seeded_params(seeded.VQVAE_ENCODER_SHAPES, seed, "enc.").items()}
+    dec = {k: v.requires_grad_(True) for k, v in seeded.seeded_params(seeded.VQVAE_DECODER_SHAPES, seed, "dec.").items()}
+    state = {"st": seeded.seeded_codebook_state(seed, scale=0.05)}
+    opt = torch.optim.Adam(list(enc.values()) + list(dec.values()), 3e-4, betas=(0.9, 0.9))
+    clips = 2
+    x = O.normalize(seeded.seeded_input("cpu", (clips * CLIP_FRAMES, 3, 64, 64), seed), (0.5,) * 3, (0.5,) * 3)
+
+    def step():
+        t0 = time.perf_counter()
+        losses, state["st"], _ = O.vqvae_supervised_loss(enc, dec, state["st"], x)
+        sum(losses.values()).backward()
+        opt.step()
+        opt.zero_grad()
+        return time.perf_counter() - t0
+
+    # PyTorch-CPU does not scale to every hardware thread on these small convolutions: calibrate the
+    # thread count (one step each, after one warm-up step) and time the best one.
+    ncpu = os.cpu_count() or 1
+    t_start = time.perf_counter()
+    best, best_t = None, None
+    for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
+        if time.perf_counter() - t_start > budget_s * 0.5 and best is not None:
+            break
+        torch.set_num_threads(nt)
+        step()
+        dt = step()
+        if best_t is None or dt < best_t:
+            best, best_t = nt, dt
+    cores = best
+    torch.set_num_threads(cores)
+    times = []
+    while len(times) < 10 and (time.perf_counter() - t_start < budget_s or len(times) < 3):
+        times.append(step())
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": clips / med, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "oracle (PyTorch-CPU fp32 restatement of the reference path) VQ-VAE train step, "
+                      "%d clips = %d frames per step, median of %d steps, %d threads (best of a 8..128 thread "
+                      "calibration on %d logical CPUs)" % (clips, clips * CLIP_FRAMES, len(times), cores, ncpu)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+
+    from lvt_amd.hip import binding as L
+    cfg, model = build_vqvae(device, 29871897 + rank)
+    optimizers, _ = model.configure_optimizers_and_checkpointers()
+    if world > 1:
+        model.wrap_parallel(device_ids=[local_rank], broadcast_buffers=False)
+
+    # synthetic clips, resident in HBM before the timed region
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    clips = torch.rand(args.batch_clips, CLIP_FRAMES, 3, 64, 64, generator=g).to(device)
+    data = [{"image_sequence": clips[i]} for i in range(args.batch_clips)]
+
+    for i in range(args.warmup):
+        vqvae_step(model, optimizers, data, i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    L.TIMER = L.KernelTimer()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = vqvae_step(model, optimizers, data, args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer, L.TIMER = L.TIMER, None
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = args.batch_clips * world * args.steps / elapsed
+        summ = timer.summary()
+        eng = {k: v for k, v in summ.items() if k.startswith("conv_") or k.startswith("gemm_")}
+        tot_ms = sum(v["ms"] for v in eng.values())
+        tot_fl = sum(v["flops"] for v in eng.values())
+        launches = sum(v["launches"] for v in eng.values())
+        achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        per_kind = {k: {"launches": v["launches"], "avg_us": round(v["ms"] / v["launches"] * 1e3, 1),
+                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in sorted(eng.items())}
+        out = {
+            "metric": "video-clips/sec/node (VQ-VAE PR-DVQVAE2 train step, BAIR 64x64x16)",
+            "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PR-DVQVAE2 train step (fwd+bwd+Adam), %d clips x 16 frames x 3x64x64 per GPU, "
+                                   "4x512 EMA codebooks" % args.batch_clips,
+                       "global_batch_clips": args.batch_clips * world, "parallelism": "dp%d" % world,
+                       "loss": {k: round(float(v.detach()), 6) for k, v in losses.items()}},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "lvt_gemm_kernel<*> (fp32 MFMA implicit-GEMM engine: conv fwd / bwd-data / "
+                                   "bwd-weight), %d launches, %.2f ms of %.2f ms per step"
+                                   % (launches // args.steps, tot_ms / args.steps, ms),
+                         "per_kind": per_kind},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.batch_clips, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

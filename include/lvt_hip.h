@@ -151,6 +151,46 @@ int lvt_layernorm_bwd(const float *dy, const float *x, const float *mean, const 
                       const float *w, long long rows, int d, const float *add, float *dx, float *dw,
                       float *db, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- attention softmax with learned relative-position bias (vt_attention.py:59-81,142-174; K21,K22) ----
+ * scores (B,H,S,S) in place:  softmax_j( s/temper + (dt[h][di_t] + dh[h][di_h]) + dw[h][di_w] ), with the
+ * causal fill (`fill` where j > i, the reference uses -1e4) when masked != 0.  Banks: dt (H,2bt-1) etc.,
+ * S == bt*bh*bw, S % 64 == 0, S <= 1024.                                                              */
+int lvt_attn_softmax_fwd(float *scores, int B, int H, int S, float temper, const float *dt,
+                         const float *dh, const float *dw, int bt, int bh, int bw, int masked, float fill,
+                         void *stream);
+/* dP (B,H,S,S) is overwritten with dS = P*(dP - sum_j P dP)/temper; ddt/ddh/ddw receive the bank
+ * gradients (batch-reduced in a fixed order through the (H,S,S) scratch G).                           */
+int lvt_attn_softmax_bwd(const float *P, float *dP, int B, int H, int S, float temper, int bt, int bh,
+                         int bw, float *G, float *ddt, float *ddh, float *ddw, void *stream);
+
+/* ---- embedding bags: the one-hot Conv3d / Embedding sums / one-hot Linear inputs as gathers (K13,K15,K25)
+ * out[b*P+pos][:] = bias + btable[bindex[b]] + sum_s table[tab_row[s] + idx[b*bstride + off[s] + pos]][:]
+ * (negative indices, i.e. PAD_VALUE, contribute nothing).                                             */
+int lvt_embbag_fwd(const long long *idx, long long bstride, int P, long long rows, int nslots,
+                   const int *slot_off, const int *tab_row, const float *table, int D, const float *bias,
+                   const float *btable, const long long *bindex, float *out, void *stream);
+/* gradient of the tables: out[(s*V + code)][n] = sum_rows [idx(row,s) == code] * dout[row][n], executed as a
+ * transposed one-hot GEMM on the matrix cores (deterministic split-K), idx(row,s) =
+ * idx[b*bstride + off[s] + pos*pstride], row = b*P + pos.                                              */
+size_t lvt_onehot_tn_workspace_bytes(int nslots, int V, int N, long long rows);
+int lvt_onehot_tn_gemm(const long long *idx, int nslots, int V, const int *slot_off, long long bstride,
+                       long long pstride, int P, long long rows, const float *dout, long long ldb, int N,
+                       float *out, void *workspace, size_t workspace_bytes, void *stream);
+/* out (n0,n1,n2) contiguous <- in[i0*s0 + i1*s1 + i2*s2]  (weight re-layouts)                         */
+int lvt_permute3(const float *in, long long s0, long long s1, long long s2, int n0, int n1, int n2,
+                 float *out, void *stream);
+
+/* ---- cross entropy with ignore_index (F.cross_entropy; vt.py:305-313; K26) ---------------------------
+ * rows = B*P rows of V logits; target(b,pos) = target[b*tstride_b + pos*tstride_pos].
+ * loss[0] = scale * mean_{non-ignored}(lse - logit[target]); count[0] = #non-ignored.                  */
+size_t lvt_xent_workspace_bytes(void);
+int lvt_xent_fwd(const float *logits, const long long *target, long long tstride_b, long long tstride_pos,
+                 int P, long long rows, int V, long long ignore, float scale, float *row_loss, float *lse,
+                 float *loss, float *count, void *workspace, size_t workspace_bytes, void *stream);
+int lvt_xent_bwd(const float *logits, const long long *target, long long tstride_b, long long tstride_pos,
+                 int P, long long rows, int V, long long ignore, const float *lse, const float *count,
+                 const float *gout, float scale, float *dlogits, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

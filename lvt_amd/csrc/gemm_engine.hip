@@ -25,7 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define BK 32
 #define NTHREADS 256
 
-enum { A_KPLAIN = 0, A_MPLAIN = 1, A_CONV_K = 2, A_CONVT_K = 3, A_CONV_M = 4 };
+enum { A_KPLAIN = 0, A_MPLAIN = 1, A_CONV_K = 2, A_CONVT_K = 3, A_CONV_M = 4, A_ONEHOT_M = 5 };
 enum { B_KPLAIN = 0, B_NPLAIN = 1, B_CONVT_W = 2 };
 
 struct KParams {
@@ -41,6 +41,9 @@ struct KParams {
     lvt_conv_geom g;
     int Tq, Hq, Wq;          // A_CONVT_K: per-phase output extents
     int jT, jH, jW;          // A_CONVT_K: taps per phase and dimension
+    // A_ONEHOT_M: A(m = slot*V + code, k = row) = (idx[b*bstride + off[slot] + pos*pstride] == code),
+    // row = b*P + pos.  The transpose of a one-hot matrix, generated on the fly (never materialised).
+    const long long *oh_idx; long long oh_bstride, oh_pstride; int oh_P, oh_V; int oh_off[32];
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -239,6 +242,35 @@ template <int BM> struct ALoader<A_CONV_M, BM> : AMLoaderBase<BM> {
                  (unsigned)wi < (unsigned)g.Wi;
             const long long off = ((((long long)n * g.Ti + ti) * g.Hi + hi) * g.Wi + wi) * g.Ci + ci;
             this->v[i] = ok ? ldg4(x + off) : zero4();
+        }
+    }
+};
+
+// scatter-add as a GEMM: dTable[(slot, code)][:] = sum_rows onehot(row, slot)[code] * dOut[row][:]
+template <int BM> struct ALoader<A_ONEHOT_M, BM> : AMLoaderBase<BM> {
+    using Base = AMLoaderBase<BM>;
+    const long long *ip; long long bstride, pstride; int P, code0; bool mok;
+    __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *, int) {
+        this->kk0 = tid / Base::UPK; this->mq = tid % Base::UPK;
+        const int m = m0 + this->mq * 4;
+        mok = m < p.M;
+        const int slot = mok ? m / p.oh_V : 0;
+        code0 = m - slot * p.oh_V;
+        ip = p.oh_idx + p.oh_off[slot];
+        bstride = p.oh_bstride; pstride = p.oh_pstride; P = p.oh_P;
+    }
+    __device__ __forceinline__ void fetch(int k0, int kend) {
+#pragma unroll
+        for (int i = 0; i < Base::ITERS; ++i) {
+            const int row = k0 + this->kk0 + Base::KPP * i;
+            float4 v = zero4();
+            if (mok && row < kend) {
+                const int b = row / P, pos = row - b * P;
+                const int d = (int)(ip[b * bstride + pos * pstride]) - code0;
+                v.x = d == 0 ? 1.f : 0.f; v.y = d == 1 ? 1.f : 0.f;
+                v.z = d == 2 ? 1.f : 0.f; v.w = d == 3 ? 1.f : 0.f;
+            }
+            this->v[i] = v;
         }
     }
 };
@@ -512,40 +544,59 @@ __global__ void lvt_pack_weight_kernel(const float *__restrict__ w, float *__res
         wp[i] = v;
     }
 }
-// partial[split][(tap,ci)][co] -> dw[co][ci][tap]   (fixed summation order over splits)
+// partial[split][(tap,ci)][co] -> dw[co][ci][tap]   (fixed summation order over splits).
+// Threads walk the SOURCE layout (co fastest) so that the splits-times-repeated reads are coalesced;
+// the one scattered write per element is the cheap side.
 __global__ void lvt_unpack_wgrad_kernel(const float *__restrict__ partial, long long stride, int splits,
                                         float *__restrict__ dw, int taps, int Ci, int Co, int Ci_real,
                                         int Co_real) {
-    const long long total = (long long)Co_real * Ci_real * taps;
+    const long long total = (long long)taps * Ci * Co;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int tap = i % taps; long long t = i / taps;
-        const int ci = t % Ci_real; const int co = t / Ci_real;
-        const long long src = ((long long)tap * Ci + ci) * Co + co;
-        float s = partial[src];
-        for (int k = 1; k < splits; ++k) s += partial[k * stride + src];
-        dw[i] = s;
+        const int co = i % Co; long long t = i / Co;
+        const int ci = t % Ci; const int tap = t / Ci;
+        if (co >= Co_real || ci >= Ci_real) continue;
+        float s = partial[i];
+        for (int k = 1; k < splits; ++k) s += partial[k * stride + i];
+        dw[((long long)co * Ci_real + ci) * taps + tap] = s;
     }
 }
 
-// column sums (bias gradients): stage 1 partial[blk][n] over row chunks, stage 2 fixed-order reduce
-__global__ void lvt_colsum_kernel(const float *__restrict__ g, long long M, int N, long long ld,
-                                  long long rows_per_block, float *__restrict__ partial) {
-    const long long r0 = blockIdx.y * rows_per_block;
+// column sums (bias gradients).  One workgroup reduces a chunk of rows for ALL columns: thread
+// (rl, c4) owns the float4 column group c4 and rows rl, rl+RL, ...; the RL row-lanes are combined
+// through LDS in a fixed order.  Applied recursively (chunk partials -> final) so the result is
+// bit-reproducible and every stage reads fully coalesced 16-byte lanes.
+#define CS_THREADS 256
+__global__ __launch_bounds__(CS_THREADS) void lvt_colsum_kernel(const float *__restrict__ g, long long M, int N,
+                                                                long long ld, long long rows_per_block,
+                                                                float *__restrict__ partial) {
+    __shared__ float4 red[CS_THREADS];
+    const int n4 = N / 4;
+    const int rl_count = CS_THREADS / n4 > 0 ? CS_THREADS / n4 : 1;   // row lanes (N <= 1024)
+    const long long r0 = blockIdx.x * rows_per_block;
     const long long r1 = min(M, r0 + rows_per_block);
-    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (long long r = r0; r < r1; ++r) s += g[r * ld + n];
-        partial[(long long)blockIdx.y * N + n] = s;
+    for (int cbase = 0; cbase < n4; cbase += CS_THREADS) {
+        const int c4 = cbase + (int)(threadIdx.x % (n4 < CS_THREADS ? n4 : CS_THREADS));
+        const int rl = threadIdx.x / (n4 < CS_THREADS ? n4 : CS_THREADS);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 < n4 && rl < rl_count) {
+            for (long long r = r0 + rl; r < r1; r += rl_count) {
+                const float4 v = *reinterpret_cast<const float4 *>(g + r * ld + c4 * 4);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        }
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (rl == 0 && c4 < n4) {
+            const int w = n4 < CS_THREADS ? n4 : CS_THREADS;
+            for (int k = 1; k < rl_count; ++k) {
+                const float4 v = red[k * w + threadIdx.x];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            *reinterpret_cast<float4 *>(partial + (long long)blockIdx.x * N + c4 * 4) = s;
+        }
+        __syncthreads();
     }
-}
-__global__ void lvt_colsum_final_kernel(const float *__restrict__ partial, int nblk, int N,
-                                        float *__restrict__ out) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * N + n];
-    out[n] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -756,28 +807,73 @@ extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, con
     return LVT_OK;
 }
 
+#define CS_ROWS 512
+// ---- one-hot transposed GEMM (embedding / one-hot-linear weight gradients) ----------------------------
+static int onehot_splits(int M, int N, long long rows) {
+    const long long tiles = lvt_cdiv(M, 128) * lvt_cdiv(N, 128);
+    const int s = choose_splits(tiles, (int)rows, 512);
+    return s < 2 ? 2 : s;
+}
+extern "C" size_t lvt_onehot_tn_workspace_bytes(int nslots, int V, int N, long long rows) {
+    return (size_t)onehot_splits(nslots * V, N, rows) * nslots * V * (size_t)N * sizeof(float);
+}
+extern "C" int lvt_onehot_tn_gemm(const long long *idx, int nslots, int V, const int *slot_off, long long bstride,
+                                  long long pstride, int P, long long rows, const float *dout, long long ldb, int N,
+                                  float *out, void *workspace, size_t workspace_bytes, void *stream) {
+    LVT_REQUIRE(idx && slot_off && dout && out && nslots > 0 && nslots <= 32 && V > 0 && V % 4 == 0,
+                "onehot_tn_gemm: bad args");
+    LVT_REQUIRE(rows > 0 && rows < 0x7fffffffLL && P > 0 && rows % P == 0 && N % 4 == 0 && ldb % 4 == 0,
+                "onehot_tn_gemm: bad shape");
+    const size_t need = lvt_onehot_tn_workspace_bytes(nslots, V, N, rows);
+    if (!workspace || workspace_bytes < need) {
+        lvt_set_error("onehot_tn_gemm: workspace %zu < %zu", workspace_bytes, need);
+        return LVT_EWORKSPACE;
+    }
+    KParams p; memset(&p, 0, sizeof(p));
+    p.M = nslots * V; p.N = N; p.K = (int)rows;
+    p.B = dout; p.ldb = ldb; p.batch_inner = 1; p.alpha = 1.f;
+    p.oh_idx = idx; p.oh_bstride = bstride; p.oh_pstride = pstride; p.oh_P = P; p.oh_V = V;
+    for (int i = 0; i < nslots; ++i) p.oh_off[i] = slot_off[i];
+    p.splits = onehot_splits(p.M, N, rows);
+    p.k_per_split = (int)(lvt_cdiv(lvt_cdiv(p.K, p.splits), BK) * BK);
+    p.partial = (float *)workspace;
+    p.partial_stride = (long long)p.M * N;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_tile<A_ONEHOT_M, B_NPLAIN, 128, 128, 2, 2>(p, 1, s);
+    if (rc) return rc;
+    const long long n4 = p.partial_stride / 4;
+    const int blocks = (int)(lvt_cdiv(n4, 256) < 2048 ? lvt_cdiv(n4, 256) : 2048);
+    hipLaunchKernelGGL(lvt_reduce_splits_kernel, dim3(blocks), dim3(256), 0, s, p.partial, n4, p.partial_stride,
+                       p.splits, out, 0);
+    LVT_CHECK_LAUNCH("lvt_reduce_splits_kernel");
+    return LVT_OK;
+}
+
 extern "C" size_t lvt_colsum_workspace_bytes(long long M, int N) {
-    const long long nblk = lvt_cdiv(M, 256) < 512 ? lvt_cdiv(M, 256) : 512;
-    return (size_t)(nblk > 0 ? nblk : 1) * N * sizeof(float);
+    const long long b1 = lvt_cdiv(M, CS_ROWS), b2 = lvt_cdiv(b1, CS_ROWS);
+    return (size_t)(b1 + b2 + 2) * N * sizeof(float);
 }
 
 extern "C" int lvt_colsum(const float *g, long long M, int N, long long ld, float *out, void *workspace,
                           size_t workspace_bytes, void *stream) {
-    LVT_REQUIRE(g && out && M > 0 && N > 0, "colsum: bad args");
-    long long nblk = lvt_cdiv(M, 256) < 512 ? lvt_cdiv(M, 256) : 512;
-    if (nblk < 1) nblk = 1;
-    if (!workspace || workspace_bytes < (size_t)nblk * N * sizeof(float)) {
+    LVT_REQUIRE(g && out && M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0 && lvt_aligned16(g), "colsum: bad args");
+    if (!workspace || workspace_bytes < lvt_colsum_workspace_bytes(M, N)) {
         lvt_set_error("colsum: workspace too small");
         return LVT_EWORKSPACE;
     }
-    const long long rpb = lvt_cdiv(M, nblk);
-    nblk = lvt_cdiv(M, rpb);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(lvt_colsum_kernel, dim3((unsigned)lvt_cdiv(N, 256), (unsigned)nblk), dim3(256), 0, s, g, M, N,
-                       ld, rpb, (float *)workspace);
-    LVT_CHECK_LAUNCH("lvt_colsum_kernel");
-    hipLaunchKernelGGL(lvt_colsum_final_kernel, dim3((unsigned)lvt_cdiv(N, 256)), dim3(256), 0, s,
-                       (const float *)workspace, (int)nblk, N, out);
-    LVT_CHECK_LAUNCH("lvt_colsum_final_kernel");
+    const float *src = g;
+    long long rows = M, lds_ = ld;
+    float *buf = (float *)workspace;
+    // stages: rows -> ceil(rows / CS_ROWS) until one row is left; the last stage writes `out`
+    while (true) {
+        const long long nblk = lvt_cdiv(rows, CS_ROWS);
+        float *dst = (nblk == 1) ? out : buf;
+        hipLaunchKernelGGL(lvt_colsum_kernel, dim3((unsigned)nblk), dim3(CS_THREADS), 0, s, src, rows, N, lds_,
+                           (long long)CS_ROWS, dst);
+        LVT_CHECK_LAUNCH("lvt_colsum_kernel");
+        if (nblk == 1) break;
+        src = dst; rows = nblk; lds_ = N; buf = dst + nblk * N;
+    }
     return LVT_OK;
 }

@@ -1,0 +1,357 @@
+// Latent-video-transformer specific HBM-bound kernels:
+//   attention softmax with the learned relative-position bias banks and causal fill (vt_attention.py:59-81,
+//   :142-174), its backward with the batch-reduced bias-bank gradient, embedding bags (the one-hot
+//   Conv3d / Embedding sums / one-hot Linear inputs of videotransformer.py:41-57, 80-89, 139-160 executed as
+//   gathers), and the fused cross-entropy (vt.py:305-313).
+#include "lvt_common.h"
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+#define SM_MAXE 16   // row length S <= 1024
+
+struct BiasGeom { int bt, bh, bw; };   // attention block extents; S == bt*bh*bw
+
+// P[b][h][i][:] = softmax_j( s/temper + (dt[h][..] + dh[h][..]) + dw[h][..]  |  fill where j > i )
+__global__ void lvt_attn_softmax_fwd_kernel(float *__restrict__ scores, int B, int H, int S, float temper,
+                                            const float *__restrict__ dt, const float *__restrict__ dh,
+                                            const float *__restrict__ dw, BiasGeom g, int masked, float fill) {
+    const int lane = threadIdx.x & 63;
+    const long long nrows = (long long)B * H * S;
+    const int ne = S / 64;
+    for (long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < nrows;
+         row += ((long long)gridDim.x * blockDim.x) >> 6) {
+        const int i = row % S; const int h = (row / S) % H;
+        const int wi = i % g.bw, hi = (i / g.bw) % g.bh, ti = i / (g.bw * g.bh);
+        const float *bt = dt + h * (2 * g.bt - 1), *bhp = dh + h * (2 * g.bh - 1), *bwp = dw + h * (2 * g.bw - 1);
+        float *p = scores + row * S;
+        float v[SM_MAXE];
+        float m = -3.4e38f;
+#pragma unroll
+        for (int e = 0; e < SM_MAXE; ++e) {
+            if (e < ne) {
+                const int j = lane + 64 * e;
+                const int wj = j % g.bw, hj = (j / g.bw) % g.bh, tj = j / (g.bw * g.bh);
+                const float bias = (bt[ti - tj + g.bt - 1] + bhp[hi - hj + g.bh - 1]) + bwp[wi - wj + g.bw - 1];
+                float x = p[j] / temper + bias;
+                if (masked && j > i) x = fill;
+                v[e] = x;
+                m = fmaxf(m, x);
+            }
+        }
+        m = wmax(m);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < SM_MAXE; ++e)
+            if (e < ne) { v[e] = expf(v[e] - m); s += v[e]; }
+        s = wsum(s);
+#pragma unroll
+        for (int e = 0; e < SM_MAXE; ++e)
+            if (e < ne) p[lane + 64 * e] = v[e] / s;
+    }
+}
+
+// For one (h, i): loop over the batch; g = P * (dP - sum_j P dP); dS = g / temper (written over dP);
+// G[h][i][:] = sum_b g  (gradient w.r.t. the bias matrix B, batch-reduced in a fixed order).
+__global__ void lvt_attn_softmax_bwd_kernel(const float *__restrict__ P, float *__restrict__ dP, int B, int H, int S,
+                                            float temper, float *__restrict__ G) {
+    const int lane = threadIdx.x & 63;
+    const int ne = S / 64;
+    const long long nrows = (long long)H * S;
+    for (long long hr = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; hr < nrows;
+         hr += ((long long)gridDim.x * blockDim.x) >> 6) {
+        float acc[SM_MAXE];
+#pragma unroll
+        for (int e = 0; e < SM_MAXE; ++e) acc[e] = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const long long off = ((long long)b * H * S + hr) * S;
+            float pv[SM_MAXE], gv[SM_MAXE];
+            float dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < SM_MAXE; ++e)
+                if (e < ne) { pv[e] = P[off + lane + 64 * e]; gv[e] = dP[off + lane + 64 * e]; dot += pv[e] * gv[e]; }
+            dot = wsum(dot);
+#pragma unroll
+            for (int e = 0; e < SM_MAXE; ++e)
+                if (e < ne) {
+                    const float gg = pv[e] * (gv[e] - dot);
+                    acc[e] += gg;
+                    dP[off + lane + 64 * e] = gg / temper;
+                }
+        }
+        if (G) {
+#pragma unroll
+            for (int e = 0; e < SM_MAXE; ++e)
+                if (e < ne) G[hr * S + lane + 64 * e] = acc[e];
+        }
+    }
+}
+
+// d bank[h][entry] = sum over (i, j) whose coordinate difference selects `entry`; one workgroup per
+// (h, bank, entry), fixed-order tree reduction.
+__global__ __launch_bounds__(256) void lvt_attn_bank_grad_kernel(const float *__restrict__ G, int H, int S,
+                                                                 BiasGeom g, float *__restrict__ ddt,
+                                                                 float *__restrict__ ddh, float *__restrict__ ddw) {
+    __shared__ float red[256];
+    const int nt = 2 * g.bt - 1, nh = 2 * g.bh - 1, nw = 2 * g.bw - 1;
+    const int per_h = nt + nh + nw;
+    const int h = blockIdx.x / per_h;
+    int e = blockIdx.x % per_h;
+    int which = 0;
+    if (e >= nt) { e -= nt; which = 1; if (e >= nh) { e -= nh; which = 2; } }
+    const float *Gh = G + (long long)h * S * S;
+    float s = 0.f;
+    for (int idx = threadIdx.x; idx < S * S; idx += 256) {
+        const int i = idx / S, j = idx % S;
+        int di;
+        if (which == 0) di = i / (g.bw * g.bh) - j / (g.bw * g.bh) + g.bt - 1;
+        else if (which == 1) di = (i / g.bw) % g.bh - (j / g.bw) % g.bh + g.bh - 1;
+        else di = i % g.bw - j % g.bw + g.bw - 1;
+        if (di == e) s += Gh[idx];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float *dst = which == 0 ? ddt + h * nt : (which == 1 ? ddh + h * nh : ddw + h * nw);
+        dst[e] = red[0];
+    }
+}
+
+extern "C" int lvt_attn_softmax_fwd(float *scores, int B, int H, int S, float temper, const float *dt,
+                                    const float *dh, const float *dw, int bt, int bh, int bw, int masked, float fill,
+                                    void *stream) {
+    LVT_REQUIRE(scores && dt && dh && dw && B > 0 && H > 0, "attn_softmax_fwd: bad args");
+    LVT_REQUIRE(S == bt * bh * bw && S % 64 == 0 && S <= 64 * SM_MAXE, "attn_softmax_fwd: S=%d unsupported", S);
+    BiasGeom g = {bt, bh, bw};
+    const long long rows = (long long)B * H * S;
+    const int blocks = (int)(lvt_cdiv(rows, 4) < 16384 ? lvt_cdiv(rows, 4) : 16384);
+    hipLaunchKernelGGL(lvt_attn_softmax_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scores, B, H, S,
+                       temper, dt, dh, dw, g, masked, fill);
+    LVT_CHECK_LAUNCH("lvt_attn_softmax_fwd_kernel");
+    return LVT_OK;
+}
+
+// dP is overwritten with dS; ddt/ddh/ddw receive the bias-bank gradients; G is an (H,S,S) scratch buffer.
+extern "C" int lvt_attn_softmax_bwd(const float *P, float *dP, int B, int H, int S, float temper, int bt, int bh,
+                                    int bw, float *G, float *ddt, float *ddh, float *ddw, void *stream) {
+    LVT_REQUIRE(P && dP && G && ddt && ddh && ddw && B > 0 && H > 0, "attn_softmax_bwd: bad args");
+    LVT_REQUIRE(S == bt * bh * bw && S % 64 == 0 && S <= 64 * SM_MAXE, "attn_softmax_bwd: S=%d unsupported", S);
+    hipStream_t s = (hipStream_t)stream;
+    const long long rows = (long long)H * S;
+    hipLaunchKernelGGL(lvt_attn_softmax_bwd_kernel, dim3((unsigned)lvt_cdiv(rows, 4)), dim3(256), 0, s, P, dP, B, H, S,
+                       temper, G);
+    LVT_CHECK_LAUNCH("lvt_attn_softmax_bwd_kernel");
+    BiasGeom g = {bt, bh, bw};
+    const int per_h = (2 * bt - 1) + (2 * bh - 1) + (2 * bw - 1);
+    hipLaunchKernelGGL(lvt_attn_bank_grad_kernel, dim3(H * per_h), dim3(256), 0, s, G, H, S, g, ddt, ddh, ddw);
+    LVT_CHECK_LAUNCH("lvt_attn_bank_grad_kernel");
+    return LVT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding bag: out[b*P+pos][:] = bias + btable[bindex[b]] + sum_slots table[tab_row[s] + idx(b,pos,s)][:]
+//   idx(b,pos,s) = idx[b*bstride + off[s] + pos];  negative indices (pad_value) contribute nothing.
+// ------------------------------------------------------------------------------------------------
+struct BagSlots { int n; int off[32]; int tab_row[32]; };
+
+__global__ void lvt_embbag_fwd_kernel(const long long *__restrict__ idx, long long bstride, int P, long long rows,
+                                      BagSlots sl, const float *__restrict__ table, int D,
+                                      const float *__restrict__ bias, const float *__restrict__ btable,
+                                      const long long *__restrict__ bindex, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int d4 = D / 4;
+    for (long long r = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < rows;
+         r += ((long long)gridDim.x * blockDim.x) >> 6) {
+        const long long b = r / P; const int pos = r % P;
+        const long long *ip = idx + b * bstride + pos;
+        for (int c = lane; c < d4; c += 64) {
+            float4 acc = bias ? reinterpret_cast<const float4 *>(bias)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < sl.n; ++s) {
+                const long long id = ip[sl.off[s]];
+                if (id >= 0) {
+                    const float4 v = reinterpret_cast<const float4 *>(table + (sl.tab_row[s] + id) * D)[c];
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+            }
+            if (btable) {
+                const float4 v = reinterpret_cast<const float4 *>(btable + bindex[b] * D)[c];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            reinterpret_cast<float4 *>(out + r * D)[c] = acc;
+        }
+    }
+}
+
+extern "C" int lvt_embbag_fwd(const long long *idx, long long bstride, int P, long long rows, int nslots,
+                              const int *slot_off, const int *tab_row, const float *table, int D, const float *bias,
+                              const float *btable, const long long *bindex, float *out, void *stream) {
+    LVT_REQUIRE(idx && slot_off && tab_row && table && out && nslots > 0 && nslots <= 32 && D % 4 == 0 && rows > 0 &&
+                    P > 0 && rows % P == 0, "embbag_fwd: bad args");
+    LVT_REQUIRE(!btable || bindex, "embbag_fwd: btable without bindex");
+    BagSlots sl; sl.n = nslots;
+    for (int i = 0; i < nslots; ++i) { sl.off[i] = slot_off[i]; sl.tab_row[i] = tab_row[i]; }
+    const int blocks = (int)(lvt_cdiv(rows, 4) < 16384 ? lvt_cdiv(rows, 4) : 16384);
+    hipLaunchKernelGGL(lvt_embbag_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, idx, bstride, P, rows,
+                       sl, table, D, bias, btable, bindex, out);
+    LVT_CHECK_LAUNCH("lvt_embbag_fwd_kernel");
+    return LVT_OK;
+}
+
+// out[d2][d1][d0] (contiguous) = in[i0*s0 + i1*s1 + i2*s2] : generic 3-D permute for weight re-layouts
+__global__ void lvt_permute3_kernel(const float *__restrict__ in, long long s0, long long s1, long long s2, int n0,
+                                    int n1, int n2, float *__restrict__ out) {
+    const long long total = (long long)n0 * n1 * n2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int i2 = i % n2; const long long t = i / n2;
+        const int i1 = t % n1; const int i0 = t / n1;
+        out[i] = in[i0 * s0 + i1 * s1 + i2 * s2];
+    }
+}
+// out is contiguous (n0, n1, n2); element (i0,i1,i2) is read from in with the given element strides.
+extern "C" int lvt_permute3(const float *in, long long s0, long long s1, long long s2, int n0, int n1, int n2,
+                            float *out, void *stream) {
+    LVT_REQUIRE(in && out && n0 > 0 && n1 > 0 && n2 > 0, "permute3: bad args");
+    const long long total = (long long)n0 * n1 * n2;
+    const int blocks = (int)(lvt_cdiv(total, 256) < 8192 ? lvt_cdiv(total, 256) : 8192);
+    hipLaunchKernelGGL(lvt_permute3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, s0, s1, s2, n0, n1,
+                       n2, out);
+    LVT_CHECK_LAUNCH("lvt_permute3_kernel");
+    return LVT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross entropy with ignore_index over rows of V logits (F.cross_entropy, vt.py:305-313)
+// ------------------------------------------------------------------------------------------------
+#define XE_MAXE 16   // V <= 4096
+__global__ void lvt_xent_fwd_kernel(const float *__restrict__ logits, const long long *__restrict__ target,
+                                    long long tstride_b, long long tstride_pos, int P, long long rows, int V,
+                                    long long ignore, float *__restrict__ row_loss, float *__restrict__ lse_out) {
+    const int lane = threadIdx.x & 63;
+    const int ne = V / 256;   // float4 per lane
+    for (long long r = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < rows;
+         r += ((long long)gridDim.x * blockDim.x) >> 6) {
+        const float4 *p = reinterpret_cast<const float4 *>(logits + r * V);
+        float4 v[XE_MAXE / 4 > 0 ? XE_MAXE : 1];
+        float m = -3.4e38f;
+#pragma unroll
+        for (int e = 0; e < XE_MAXE; ++e)
+            if (e < ne) { v[e] = p[lane + 64 * e]; m = fmaxf(m, fmaxf(fmaxf(v[e].x, v[e].y), fmaxf(v[e].z, v[e].w))); }
+        m = wmax(m);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < XE_MAXE; ++e)
+            if (e < ne) s += (expf(v[e].x - m) + expf(v[e].y - m)) + (expf(v[e].z - m) + expf(v[e].w - m));
+        s = wsum(s);
+        const float lse = m + logf(s);
+        if (lane == 0) {
+            const long long t = target[(r / P) * tstride_b + (r % P) * tstride_pos];
+            lse_out[r] = lse;
+            row_loss[r] = (t == ignore) ? 0.f : lse - logits[r * V + t];
+        }
+    }
+}
+// stage 1 of the loss reduction: partial sums + counts of non-ignored rows per workgroup
+__global__ __launch_bounds__(256) void lvt_xent_partial_kernel(const float *__restrict__ row_loss,
+                                                               const long long *__restrict__ target,
+                                                               long long tstride_b, long long tstride_pos, int P,
+                                                               long long rows, long long ignore,
+                                                               float *__restrict__ psum, float *__restrict__ pcnt) {
+    __shared__ float rs[256], rc[256];
+    float s = 0.f, c = 0.f;
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
+        const long long t = target[(r / P) * tstride_b + (r % P) * tstride_pos];
+        if (t != ignore) { s += row_loss[r]; c += 1.f; }
+    }
+    rs[threadIdx.x] = s; rc[threadIdx.x] = c;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) { rs[threadIdx.x] += rs[threadIdx.x + k]; rc[threadIdx.x] += rc[threadIdx.x + k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { psum[blockIdx.x] = rs[0]; pcnt[blockIdx.x] = rc[0]; }
+}
+__global__ void lvt_xent_finish_kernel(const float *__restrict__ psum, const float *__restrict__ pcnt, int n,
+                                       float scale, float *__restrict__ loss, float *__restrict__ count) {
+    __shared__ double rs[256], rc[256];
+    double s = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { s += psum[i]; c += pcnt[i]; }
+    rs[threadIdx.x] = s; rc[threadIdx.x] = c;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) { rs[threadIdx.x] += rs[threadIdx.x + k]; rc[threadIdx.x] += rc[threadIdx.x + k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { loss[0] = (float)(rs[0] / rc[0] * scale); count[0] = (float)rc[0]; }
+}
+// dlogits = gout * scale / count * (softmax - onehot), 0 for ignored rows
+__global__ void lvt_xent_bwd_kernel(const float *__restrict__ logits, const long long *__restrict__ target,
+                                    long long tstride_b, long long tstride_pos, int P, long long rows, int V,
+                                    long long ignore, const float *__restrict__ lse, const float *__restrict__ count,
+                                    const float *__restrict__ gout, float scale, float *__restrict__ dlogits) {
+    const int lane = threadIdx.x & 63;
+    const float c = (gout ? gout[0] : 1.f) * scale / count[0];
+    for (long long r = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < rows;
+         r += ((long long)gridDim.x * blockDim.x) >> 6) {
+        const long long t = target[(r / P) * tstride_b + (r % P) * tstride_pos];
+        const float l = lse[r];
+        for (int j = lane * 4; j < V; j += 256) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t != ignore) {
+                const float4 x = *reinterpret_cast<const float4 *>(logits + r * V + j);
+                o.x = c * (expf(x.x - l) - (t == j ? 1.f : 0.f));
+                o.y = c * (expf(x.y - l) - (t == j + 1 ? 1.f : 0.f));
+                o.z = c * (expf(x.z - l) - (t == j + 2 ? 1.f : 0.f));
+                o.w = c * (expf(x.w - l) - (t == j + 3 ? 1.f : 0.f));
+            }
+            *reinterpret_cast<float4 *>(dlogits + r * V + j) = o;
+        }
+    }
+}
+
+#define XE_BLOCKS 512
+extern "C" size_t lvt_xent_workspace_bytes(void) { return (size_t)2 * XE_BLOCKS * sizeof(float); }
+// loss[0] = scale * mean over non-ignored rows of (lse - logit[target]); count[0] = #non-ignored rows.
+// target(b,pos) = target[b*tstride_b + pos*tstride_pos] with rows = B*P.
+extern "C" int lvt_xent_fwd(const float *logits, const long long *target, long long tstride_b, long long tstride_pos,
+                            int P, long long rows, int V, long long ignore, float scale, float *row_loss, float *lse,
+                            float *loss, float *count, void *workspace, size_t workspace_bytes, void *stream) {
+    LVT_REQUIRE(logits && target && row_loss && lse && loss && count && rows > 0 && P > 0 && rows % P == 0,
+                "xent_fwd: bad args");
+    LVT_REQUIRE(V % 256 == 0 && V <= 256 * XE_MAXE, "xent_fwd: V=%d unsupported", V);
+    LVT_REQUIRE(workspace && workspace_bytes >= lvt_xent_workspace_bytes(), "xent_fwd: workspace");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (int)(lvt_cdiv(rows, 4) < 16384 ? lvt_cdiv(rows, 4) : 16384);
+    hipLaunchKernelGGL(lvt_xent_fwd_kernel, dim3(blocks), dim3(256), 0, s, logits, target, tstride_b, tstride_pos, P,
+                       rows, V, ignore, row_loss, lse);
+    LVT_CHECK_LAUNCH("lvt_xent_fwd_kernel");
+    const int pb = (int)(lvt_cdiv(rows, 256) < XE_BLOCKS ? lvt_cdiv(rows, 256) : XE_BLOCKS);
+    float *psum = (float *)workspace, *pcnt = psum + XE_BLOCKS;
+    hipLaunchKernelGGL(lvt_xent_partial_kernel, dim3(pb), dim3(256), 0, s, row_loss, target, tstride_b, tstride_pos, P,
+                       rows, ignore, psum, pcnt);
+    hipLaunchKernelGGL(lvt_xent_finish_kernel, dim3(1), dim3(256), 0, s, psum, pcnt, pb, scale, loss, count);
+    LVT_CHECK_LAUNCH("lvt_xent_finish_kernel");
+    return LVT_OK;
+}
+extern "C" int lvt_xent_bwd(const float *logits, const long long *target, long long tstride_b, long long tstride_pos,
+                            int P, long long rows, int V, long long ignore, const float *lse, const float *count,
+                            const float *gout, float scale, float *dlogits, void *stream) {
+    LVT_REQUIRE(logits && target && lse && count && dlogits && rows > 0 && V % 4 == 0, "xent_bwd: bad args");
+    const int blocks = (int)(lvt_cdiv(rows, 4) < 16384 ? lvt_cdiv(rows, 4) : 16384);
+    hipLaunchKernelGGL(lvt_xent_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, target, tstride_b,
+                       tstride_pos, P, rows, V, ignore, lse, count, gout, scale, dlogits);
+    LVT_CHECK_LAUNCH("lvt_xent_bwd_kernel");
+    return LVT_OK;
+}

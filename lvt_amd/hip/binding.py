@@ -77,6 +77,15 @@ def _declare(lib):
         "lvt_layernorm_fwd": (ci, [vp, cll, ci, cf, vp, vp, vp, vp, vp, vp]),
         "lvt_layernorm_bwd_workspace_bytes": (sz, [ci]),
         "lvt_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, cll, ci, vp, vp, vp, vp, vp, sz, vp]),
+        "lvt_attn_softmax_fwd": (ci, [vp, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp]),
+        "lvt_attn_softmax_bwd": (ci, [vp, vp, ci, ci, ci, cf, ci, ci, ci, vp, vp, vp, vp, vp]),
+        "lvt_embbag_fwd": (ci, [vp, cll, ci, cll, ci, P(ci), P(ci), vp, ci, vp, vp, vp, vp, vp]),
+        "lvt_onehot_tn_workspace_bytes": (sz, [ci, ci, ci, cll]),
+        "lvt_onehot_tn_gemm": (ci, [vp, ci, ci, P(ci), cll, cll, ci, cll, vp, cll, ci, vp, vp, sz, vp]),
+        "lvt_permute3": (ci, [vp, cll, cll, cll, ci, ci, ci, vp, vp]),
+        "lvt_xent_workspace_bytes": (sz, []),
+        "lvt_xent_fwd": (ci, [vp, vp, cll, cll, ci, cll, ci, cll, cf, vp, vp, vp, vp, vp, sz, vp]),
+        "lvt_xent_bwd": (ci, [vp, vp, cll, cll, ci, cll, ci, cll, vp, vp, vp, cf, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -129,6 +138,38 @@ def stream_ptr():
 
 def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class KernelTimer:
+    """Optional per-launch timing of engine calls with HIP events recorded on the launch stream
+    (used by bench.py for the roofline block).  Disabled (None) by default: zero overhead."""
+
+    def __init__(self):
+        self.records = []          # (key, flops, start_event, end_event)
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, key, flops, start):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.records.append((key, flops, start, ev))
+
+    def summary(self):
+        """-> {key: dict(launches, ms, flops)} after synchronising."""
+        torch.cuda.synchronize()
+        out = {}
+        for key, flops, a, b in self.records:
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["ms"] += a.elapsed_time(b)
+            d["flops"] += flops
+        return out
+
+
+TIMER = None     # set to a KernelTimer() to time every engine launch
 
 
 _ws = {}

@@ -32,7 +32,10 @@ def gemm(A, B, C_out, M, N, K, ta=0, tb=0, lda=None, ldb=None, ldc=None, a_kb=0,
     if splits > 1:
         nws = lib.lvt_gemm_workspace_bytes(C.byref(d))
         ws = L.workspace(nws, A.device, "gemm")
+    t0 = L.TIMER.begin() if L.TIMER is not None else None
     L.check(lib.lvt_gemm_f32(C.byref(d), L.ptr(ws), nws, L.stream_ptr()), "lvt_gemm_f32")
+    if t0 is not None:
+        L.TIMER.end("gemm_%s%s" % ("nt"[ta], "tn"[tb]), 2.0 * M * N * K * batch_outer * batch_inner, t0)
     return C_out
 
 
@@ -48,6 +51,12 @@ def conv_geom(N, Ti, Hi, Wi, Ci, Co, kernel, stride, pad, out=None):
         out = tuple((i + 2 * p - k) // s + 1 for i, p, k, s in zip((Ti, Hi, Wi), pad, kernel, stride))
     g.To, g.Ho, g.Wo = out
     return g
+
+
+def conv_flops(g):
+    """Algorithmic FLOPs of one pass (fwd == bwd-data == bwd-weight): 2 * outputs * Ci * taps, counted
+    over the device channel counts (the 3-channel image ends are carried as 4)."""
+    return 2.0 * g.N * g.To * g.Ho * g.Wo * g.Co * g.Ci * g.Kt * g.Kh * g.Kw
 
 
 def pack_weight(g, w, Ci_real, Co_real):
@@ -67,8 +76,11 @@ def conv_fwd(g, x, wp, bias=None, res=None, mask=None, flags=0):
         flags |= L.EPI_RESIDUAL
     if mask is not None:
         flags |= L.EPI_MASK
+    t0 = L.TIMER.begin() if L.TIMER is not None else None
     L.check(L.lib().lvt_conv3d_fwd(C.byref(g), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(mask), L.ptr(y),
                                    flags, L.stream_ptr()), "lvt_conv3d_fwd")
+    if t0 is not None:
+        L.TIMER.end("conv_fwd", conv_flops(g), t0)
     return y
 
 
@@ -81,8 +93,11 @@ def conv_bwd_data(g, dy, wp, bias=None, res=None, mask=None, flags=0):
         flags |= L.EPI_RESIDUAL
     if mask is not None:
         flags |= L.EPI_MASK
+    t0 = L.TIMER.begin() if L.TIMER is not None else None
     L.check(L.lib().lvt_conv3d_bwd_data(C.byref(g), L.ptr(dy), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(mask),
                                         L.ptr(dx), flags, L.stream_ptr()), "lvt_conv3d_bwd_data")
+    if t0 is not None:
+        L.TIMER.end("conv_bwd_data", conv_flops(g), t0)
     return dx
 
 
@@ -92,8 +107,11 @@ def conv_bwd_weight(g, x, dy, Ci_real, Co_real):
     dw = torch.empty(Co_real, Ci_real, g.Kt, g.Kh, g.Kw, dtype=torch.float32, device=x.device)
     nws = lib.lvt_conv3d_bwd_weight_workspace_bytes(C.byref(g))
     ws = L.workspace(nws, x.device, "wgrad")
+    t0 = L.TIMER.begin() if L.TIMER is not None else None
     L.check(lib.lvt_conv3d_bwd_weight(C.byref(g), L.ptr(x), L.ptr(dy), L.ptr(dw), Ci_real, Co_real, L.ptr(ws),
                                       nws, L.stream_ptr()), "lvt_conv3d_bwd_weight")
+    if t0 is not None:
+        L.TIMER.end("conv_bwd_weight", conv_flops(g), t0)
     return dw
 
 

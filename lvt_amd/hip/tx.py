@@ -1,0 +1,95 @@
+"""Typed wrappers over the transformer-specific kernels (csrc/transformer.hip + the one-hot GEMM)."""
+import ctypes as C
+
+import torch
+
+from . import binding as L
+
+
+def _iarr(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def attn_softmax_fwd_(scores, temper, dt, dh, dw, block, masked, fill=-1e4):
+    L.require(scores, dt, dh, dw)
+    B, H, S, _ = scores.shape
+    L.check(L.lib().lvt_attn_softmax_fwd(L.ptr(scores), B, H, S, temper, L.ptr(dt), L.ptr(dh), L.ptr(dw),
+                                         block[0], block[1], block[2], 1 if masked else 0, fill, L.stream_ptr()),
+            "lvt_attn_softmax_fwd")
+    return scores
+
+
+def attn_softmax_bwd_(P, dP, temper, block):
+    """dP is overwritten with dS.  Returns (ddt, ddh, ddw)."""
+    L.require(P, dP)
+    B, H, S, _ = P.shape
+    G = torch.empty(H, S, S, dtype=torch.float32, device=P.device)
+    ddt = torch.empty(H, 2 * block[0] - 1, dtype=torch.float32, device=P.device)
+    ddh = torch.empty(H, 2 * block[1] - 1, dtype=torch.float32, device=P.device)
+    ddw = torch.empty(H, 2 * block[2] - 1, dtype=torch.float32, device=P.device)
+    L.check(L.lib().lvt_attn_softmax_bwd(L.ptr(P), L.ptr(dP), B, H, S, temper, block[0], block[1], block[2], L.ptr(G),
+                                         L.ptr(ddt), L.ptr(ddh), L.ptr(ddw), L.stream_ptr()), "lvt_attn_softmax_bwd")
+    return ddt, ddh, ddw
+
+
+def embbag_fwd(idx, bstride, P, rows, slot_off, tab_row, table, D, bias=None, btable=None, bindex=None):
+    L.require(idx, table, bias, btable, bindex)
+    out = torch.empty(rows, D, dtype=torch.float32, device=idx.device)
+    L.check(L.lib().lvt_embbag_fwd(L.ptr(idx), bstride, P, rows, len(slot_off), _iarr(slot_off), _iarr(tab_row),
+                                   L.ptr(table), D, L.ptr(bias), L.ptr(btable), L.ptr(bindex), L.ptr(out),
+                                   L.stream_ptr()), "lvt_embbag_fwd")
+    return out
+
+
+def onehot_tn_gemm(idx, V, slot_off, bstride, pstride, P, rows, dout, N, ldb=None):
+    """-> (nslots*V, N) gradient of the gathered table."""
+    L.require(idx, dout)
+    lib = L.lib()
+    ns = len(slot_off)
+    out = torch.empty(ns * V, N, dtype=torch.float32, device=dout.device)
+    nws = lib.lvt_onehot_tn_workspace_bytes(ns, V, N, rows)
+    ws = L.workspace(nws, dout.device, "onehot")
+    t0 = L.TIMER.begin() if L.TIMER is not None else None
+    L.check(lib.lvt_onehot_tn_gemm(L.ptr(idx), ns, V, _iarr(slot_off), bstride, pstride, P, rows, L.ptr(dout),
+                                   ldb if ldb is not None else N, N, L.ptr(out), L.ptr(ws), nws, L.stream_ptr()),
+            "lvt_onehot_tn_gemm")
+    if t0 is not None:
+        L.TIMER.end("gemm_onehot_tn", 2.0 * ns * V * N * rows, t0)
+    return out
+
+
+def permute3(x, strides, shape):
+    """contiguous `shape` tensor whose element (i0,i1,i2) is x.flatten()[i0*s0+i1*s1+i2*s2]."""
+    L.require(x)
+    out = torch.empty(*shape, dtype=torch.float32, device=x.device)
+    L.check(L.lib().lvt_permute3(L.ptr(x), strides[0], strides[1], strides[2], shape[0], shape[1], shape[2],
+                                 L.ptr(out), L.stream_ptr()), "lvt_permute3")
+    return out
+
+
+def xent_fwd(logits, target, tstride_b, tstride_pos, P, ignore, scale):
+    """logits (rows, V); target is a view INTO an int64 tensor (its data_ptr is the (b=0,pos=0) element)."""
+    L.require(logits)
+    rows, V = logits.shape
+    dev = logits.device
+    row_loss = torch.empty(rows, dtype=torch.float32, device=dev)
+    lse = torch.empty(rows, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    count = torch.empty(1, dtype=torch.float32, device=dev)
+    lib = L.lib()
+    nws = lib.lvt_xent_workspace_bytes()
+    ws = L.workspace(nws, dev, "xent")
+    L.check(lib.lvt_xent_fwd(L.ptr(logits), C.c_void_p(target.data_ptr()), tstride_b, tstride_pos, P, rows, V, ignore,
+                             scale, L.ptr(row_loss), L.ptr(lse), L.ptr(loss), L.ptr(count), L.ptr(ws), nws,
+                             L.stream_ptr()), "lvt_xent_fwd")
+    return loss.view(()), lse, count
+
+
+def xent_bwd(logits, target, tstride_b, tstride_pos, P, ignore, lse, count, gout, scale):
+    L.require(logits, lse, count, gout)
+    rows, V = logits.shape
+    dl = torch.empty_like(logits)
+    L.check(L.lib().lvt_xent_bwd(L.ptr(logits), C.c_void_p(target.data_ptr()), tstride_b, tstride_pos, P, rows, V,
+                                 ignore, L.ptr(lse), L.ptr(count), L.ptr(gout), scale, L.ptr(dl), L.stream_ptr()),
+            "lvt_xent_bwd")
+    return dl

@@ -1,0 +1,370 @@
+"""Latent video transformer (reference: vidgen/modeling/autoregressive/videotransformer.py:11-248).
+
+VTEncoder / VTDecoder / ChannelPredictor / VideoTransformer keep the reference's constructor
+arguments, parameter names and `forward(context, slice, slice_idx, mode=...)` contract.  Internally
+everything runs token-major on the HIP engine:
+
+  * the encoder's one-hot + Conv3d(nc*nv -> de, (kt,1,1)) is an embedding-bag gather over the packed
+    weight (the one-hot tensor is never materialised), and so are the decoder's channel embeddings and
+    the one-hot inputs of the channel predictor's U_k; their weight gradients are transposed one-hot
+    GEMMs on the matrix cores (deterministic, no float atomics);
+  * the causal MaskedConv3d runs on the implicit-GEMM conv engine;
+  * every 1x1x1 Conv3d / Linear is a fused GEMM (+bias/ReLU/residual epilogue).
+"""
+import torch
+from torch import nn
+
+from ...hip import binding as L
+from ...hip import ew, tx
+from ...hip import gemm as G
+from .. import convstack
+from .autoregressive import Autoregressive
+from .build import AUTOREGRESSIVE_REGISTRY
+from .vt_attention import BlockLocalAttention, PositionalEncoding, linear_wgrad
+
+
+class MaskedConv3d(nn.Module):
+    """Causal 3-D conv parameter container (vt_utils.py:183-200): front pads (kt-1, kh-1, kw//2), taps
+    [:, :, -1, -1, kw//2:] re-zeroed in `weight.data` on every forward, like the reference."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True):
+        super().__init__()
+        for k in kernel_size:
+            assert k % 2 == 1
+        self.kernel_size = tuple(kernel_size)
+        kt, kh, kw = kernel_size
+        self.pad = [kw // 2, kw // 2, kh - 1, 0, kt - 1, 0]
+        self.causal = kw // 2
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, padding=0, bias=bias)
+        self.conv.weight.data = torch.ones(out_channels, in_channels, kt, kh, kw)
+
+    def rezero_(self):
+        if self.causal > 0:
+            self.conv.weight.data[:, :, -1, -1, self.causal:].zero_()
+
+
+# ------------------------------------------------------------------------------------------------
+# encoder front end: one-hot Conv3d (as a gather) + slice embedding + 1x1x1 projector
+# ------------------------------------------------------------------------------------------------
+class _EncoderFrontFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, context, slice_idx, conv_w, conv_b, slice_emb, proj_w, nv):
+        L.require(context, slice_idx)
+        b, nc, kt, H, W = context.shape
+        de = conv_w.shape[0]
+        d = proj_w.shape[0]
+        P = H * W
+        rows = b * P
+        # conv weight (de, nc*nv, kt,1,1) -> packed (kt, nc*nv, de): row (tau*nc + c)*nv + code
+        wt = tx.permute3(conv_w, (1, kt, nc * nv * kt), (kt, nc * nv, de))
+        slots = [(tau, c) for tau in range(kt) for c in range(nc)]
+        off = [(c * kt + tau) * P for tau, c in slots]
+        tab = [(tau * nc + c) * nv for tau, c in slots]
+        e = tx.embbag_fwd(context, nc * kt * P, P, rows, off, tab, wt, de, bias=conv_b, btable=slice_emb,
+                          bindex=slice_idx)
+        z = torch.empty(rows, d, dtype=torch.float32, device=e.device)
+        G.gemm(e, proj_w, z, rows, d, de)
+        ctx.save_for_backward(context, slice_idx, e, proj_w)
+        ctx.geo = (b, nc, kt, P, de, d, nv, off, slice_emb.shape[0])
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        context, slice_idx, e, proj_w = ctx.saved_tensors
+        b, nc, kt, P, de, d, nv, off, n_slices = ctx.geo
+        rows = b * P
+        dz = dz.contiguous()
+        de_ = torch.empty(rows, de, dtype=torch.float32, device=dz.device)
+        G.gemm(dz, proj_w, de_, rows, de, d, ta=0, tb=1, ldb=de)
+        dproj = linear_wgrad(dz, e, d, de, rows).view(d, de, 1, 1, 1)
+        dbias = G.colsum(de_, rows, de)
+        # slice embedding: one index per sample (position stride 0)
+        dslice = tx.onehot_tn_gemm(slice_idx, (n_slices + 3) // 4 * 4, [0], 1, 0, P, rows, de_, de)[:n_slices]
+        dwt = tx.onehot_tn_gemm(context, nv, off, nc * kt * P, 1, P, rows, de_, de)      # (kt*nc*nv, de)
+        dconv = tx.permute3(dwt, (1, de, nc * nv * de), (de, nc * nv, kt)).view(de, nc * nv, kt, 1, 1)
+        return None, None, dconv, dbias, dslice.contiguous(), dproj, None
+
+
+class VTEncoder(nn.Module):
+    def __init__(self, nc, nv, da, de, d, blocks, n_heads, kernel_size, stride, pad_value=-1, class_num=0):
+        super().__init__()
+        if class_num > 0:
+            raise NotImplementedError("class-conditional encoder (CLASS_NUM > 0) is not used by the BAIR configs")
+        self.nc, self.nv, self.stride, self.pad_value, self.class_num = nc, nv, tuple(stride), pad_value, class_num
+        self.kernel_size = tuple(kernel_size)
+        self.conv = nn.Conv3d(nc * nv, de, kernel_size, stride, bias=True)
+        self.positional_encoder = PositionalEncoding(de)      # constructed but never applied (reference quirk)
+        self.block_local_attention = nn.Sequential(*[BlockLocalAttention(blk, da, d, nh, masked=False)
+                                                     for blk, nh in zip(blocks, n_heads)])
+        st, sh, sw = stride
+        self.slice_embedding = nn.Embedding(st * sh * sw, de)
+        self.linear_projector = nn.Conv3d(de, d, 1, bias=False)
+
+    def forward_tokens(self, context, slice_idx):
+        """context (b, nc, kt, H, W) int64 -> token-major (b*H*W, d)."""
+        b, nc, T, H, W = context.shape
+        kt, kh, kw = self.kernel_size
+        if not (kh == 1 and kw == 1 and T == kt):
+            raise NotImplementedError("only (kt,1,1) context kernels with a single output frame (DSFVT/KDSFVT) are built")
+        z = _EncoderFrontFn.apply(context.contiguous(), slice_idx.contiguous(), self.conv.weight, self.conv.bias,
+                                  self.slice_embedding.weight, self.linear_projector.weight, self.nv)
+        for layer in self.block_local_attention:
+            z = layer.forward_tokens(z)
+        return z
+
+    def forward(self, x, slice_idx, class_idx=None):
+        b, nc, T, H, W = x.shape
+        z = self.forward_tokens(x, slice_idx)
+        return convstack._TokensOut.apply(z, b, z.shape[-1], 1, H, W)
+
+
+# ------------------------------------------------------------------------------------------------
+# decoder front end: channel-embedding sum + causal conv + positions + projection of z_l
+# ------------------------------------------------------------------------------------------------
+class _DecoderFrontFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sl, zl, tables, conv_w, conv_b, proj_w, pos_table, thw):
+        L.require(sl, zl)
+        b, nc, t, h, w = sl.shape
+        nv, de = tables.shape[0] // nc, tables.shape[1]
+        d = conv_w.shape[0]
+        P = t * h * w
+        rows = b * P
+        off = [k * P for k in range(nc)]
+        emb = tx.embbag_fwd(sl, nc * P, P, rows, off, [k * nv for k in range(nc)], tables, de)
+        kt, kh, kw = conv_w.shape[2:]
+        g = G.conv_geom(b, t, h, w, de, d, (kt, kh, kw), (1, 1, 1), (kt - 1, kh - 1, kw // 2), out=(t, h, w))
+        wp = G.pack_weight(g, conv_w, de, d)
+        x = G.conv_fwd(g, emb.view(b, t, h, w, de), wp, bias=conv_b).view(rows, d)
+        ew.add_periodic_(x, pos_table, P)
+        y = torch.empty(rows, d, dtype=torch.float32, device=x.device)
+        G.gemm(zl, proj_w, y, rows, d, d, flags=L.EPI_RESIDUAL, res=x)
+        ctx.save_for_backward(sl, zl, emb, wp, proj_w)
+        ctx.g, ctx.geo = g, (b, nc, P, nv, de, d, off)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        sl, zl, emb, wp, proj_w = ctx.saved_tensors
+        g = ctx.g
+        b, nc, P, nv, de, d, off = ctx.geo
+        rows = b * P
+        dy = dy.contiguous()
+        dzl = torch.empty(rows, d, dtype=torch.float32, device=dy.device)
+        G.gemm(dy, proj_w, dzl, rows, d, d, ta=0, tb=1, ldb=d)
+        dproj = linear_wgrad(dy, zl, d, d, rows).view(d, d, 1, 1, 1)
+        dy5 = dy.view(g.N, g.To, g.Ho, g.Wo, d)
+        demb = G.conv_bwd_data(g, dy5, wp).view(rows, de)
+        dconv = G.conv_bwd_weight(g, emb.view(g.N, g.Ti, g.Hi, g.Wi, de), dy5, de, d)
+        dbias = G.colsum(dy, rows, d)
+        dtab = tx.onehot_tn_gemm(sl, nv, off, nc * P, 1, P, rows, demb, de)
+        return None, dzl, dtab, dconv, dbias, dproj, None, None
+
+
+class VTDecoder(nn.Module):
+    def __init__(self, nc, nv, da, de, d, blocks, n_heads):
+        super().__init__()
+        self.ch_embedder = nn.ModuleList([nn.Embedding(nv, de) for _ in range(nc)])
+        self.de, self.nc, self.nv = de, nc, nv
+        self.conv = MaskedConv3d(de, d, (3, 3, 3))
+        self.positional_encoder = PositionalEncoding(d)
+        self.linear_projector = nn.Conv3d(d, d, 1, bias=False)
+        self.block_local_attention = nn.Sequential(*[BlockLocalAttention(blk, da, d, nh, masked=True)
+                                                     for blk, nh in zip(blocks, n_heads)])
+
+    def forward_tokens(self, sl, zl_tok):
+        b, nc, t, h, w = sl.shape
+        self.conv.rezero_()
+        tables = torch.cat([e.weight for e in self.ch_embedder], dim=0)          # (nc*nv, de)
+        pos = self.positional_encoder.table(t, h, w, zl_tok.device)
+        y = _DecoderFrontFn.apply(sl.contiguous(), zl_tok, tables, self.conv.conv.weight, self.conv.conv.bias,
+                                  self.linear_projector.weight, pos, (t, h, w))
+        for layer in self.block_local_attention:
+            y = layer.forward_tokens(y)
+        return y
+
+    def forward(self, slice, zl):
+        b, nc, t, h, w = slice.shape
+        y = self.forward_tokens(slice, convstack._TokensIn.apply(zl))
+        return convstack._TokensOut.apply(y, b, y.shape[-1], t, h, w)
+
+
+# ------------------------------------------------------------------------------------------------
+# channel predictor
+# ------------------------------------------------------------------------------------------------
+class _ChannelPredictorFn(torch.autograd.Function):
+    """logits_k = P_k(relu(U_k([LN(y), onehot(slice[:, :k])]))) for k < nc, token-major (rows, nv)."""
+
+    @staticmethod
+    def forward(ctx, yl, sl, ln_w, ln_b, nv, *UP):
+        L.require(yl, sl)
+        rows, d = yl.shape
+        b, nc = sl.shape[:2]
+        P = rows // b
+        y, mean, rstd = ew.layernorm_fwd(yl, ln_w, ln_b)
+        us, outs = [], []
+        for k in range(nc):
+            uw, ub, pw, pb = UP[4 * k:4 * k + 4]
+            fin = uw.shape[1]
+            res = None
+            if k > 0:
+                # transposed one-hot part of U_k: (k*nv, d) so that a code selects a contiguous row
+                ut = _permute_cols(uw, d, k * nv)
+                res = tx.embbag_fwd(sl, nc * P, P, rows, [c * P for c in range(k)], [c * nv for c in range(k)], ut, d)
+            u = torch.empty(rows, d, dtype=torch.float32, device=yl.device)
+            G.gemm(y, uw, u, rows, d, d, ldb=fin, flags=L.EPI_BIAS | L.EPI_RELU | (L.EPI_RESIDUAL if k else 0),
+                   bias=ub, res=res)
+            o = torch.empty(rows, pw.shape[0], dtype=torch.float32, device=yl.device)
+            G.gemm(u, pw, o, rows, pw.shape[0], d, flags=L.EPI_BIAS, bias=pb)
+            us.append(u)
+            outs.append(o)
+        ctx.save_for_backward(yl, sl, mean, rstd, y, ln_w, *us, *UP)
+        ctx.geo = (rows, d, b, nc, P, nv)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        rows, d, b, nc, P, nv = ctx.geo
+        saved = ctx.saved_tensors
+        yl, sl, mean, rstd, y, ln_w = saved[:6]
+        us = saved[6:6 + nc]
+        UP = saved[6 + nc:]
+        dev = yl.device
+        dy = torch.empty(rows, d, dtype=torch.float32, device=dev)
+        grads = []
+        for k in range(nc):
+            uw, ub, pw, pb = UP[4 * k:4 * k + 4]
+            do = douts[k].contiguous()
+            nvk = pw.shape[0]
+            fin = uw.shape[1]
+            du = torch.empty(rows, d, dtype=torch.float32, device=dev)
+            G.gemm(do, pw, du, rows, d, nvk, ta=0, tb=1, ldb=d, flags=L.EPI_MASK, mask=us[k])
+            dpw = linear_wgrad(do, us[k], nvk, d, rows)
+            dpb = G.colsum(do, rows, nvk)
+            G.gemm(du, uw, dy, rows, d, d, ta=0, tb=1, ldb=fin, flags=L.EPI_ACCUM if k else 0)
+            duw = torch.empty(d, fin, dtype=torch.float32, device=dev)
+            duw[:, :d] = linear_wgrad(du, y, d, d, rows)
+            if k > 0:
+                dut = tx.onehot_tn_gemm(sl, nv, [c * P for c in range(k)], nc * P, 1, P, rows, du, d)   # (k*nv, d)
+                duw[:, d:] = dut.t()
+            dub = G.colsum(du, rows, d)
+            grads += [duw, dub, dpw, dpb]
+        dyl, dlnw, dlnb = ew.layernorm_bwd(dy, yl, mean, rstd, ln_w)
+        return (dyl, None, dlnw, dlnb, None) + tuple(grads)
+
+
+def _permute_cols(uw, d, ncols):
+    """U.weight[:, d:d+ncols] (out, ncols) -> contiguous (ncols, out)."""
+    import ctypes as C
+    out = torch.empty(ncols, uw.shape[0], dtype=torch.float32, device=uw.device)
+    fin = uw.shape[1]
+    L.check(L.lib().lvt_permute3(C.c_void_p(uw.data_ptr() + 4 * d), 1, fin, 0, ncols, uw.shape[0], 1, L.ptr(out),
+                                 L.stream_ptr()), "lvt_permute3")
+    return out
+
+
+class ChannelPredictor(nn.Module):
+    def __init__(self, d, nc, nv, de, share_p=True, share_embeddings=False):
+        super().__init__()
+        if share_p or share_embeddings:
+            raise NotImplementedError("SHARE_P / SHARE_EMBEDDINGS variants are not used by the shipped configs")
+        self.nc, self.nv, self.share_p, self.share_embeddings = nc, nv, share_p, share_embeddings
+        self.layer_norm = nn.LayerNorm(d)
+        self.U = nn.ModuleList([nn.Linear(d + k * nv, d, bias=True) for k in range(nc)])
+        self.relu = nn.ReLU(inplace=True)
+        self.P = nn.ModuleList([nn.Linear(d, nv, bias=True) for _ in range(nc)])
+
+    def _flat_params(self):
+        flat = []
+        for k in range(self.nc):
+            flat += [self.U[k].weight, self.U[k].bias, self.P[k].weight, self.P[k].bias]
+        return flat
+
+    def logits_tokens(self, sl, yl_tok):
+        """-> tuple of nc (rows, nv) token-major logits."""
+        return _ChannelPredictorFn.apply(yl_tok, sl.contiguous(), self.layer_norm.weight, self.layer_norm.bias,
+                                         self.nv, *self._flat_params())
+
+    def sample_pixel_tokens(self, yl_tok, b, P, pos, temp=1.0, forced_codes=None, return_probs=False):
+        """One pixel of every sample: sequentially draw the nc channels (videotransformer.py:161-185).
+        yl_tok (b*P, d); pos = flat position inside the slice.  Returns codes (b, nc) int64.
+        `forced_codes` (b, nc) replaces the draws (teacher forcing, used to check the per-channel
+        probabilities against the reference since torch.multinomial streams are device specific)."""
+        d = yl_tok.shape[-1]
+        rows = yl_tok.view(b, P, d)[:, pos].contiguous()                      # (b, d)
+        y, _, _ = ew.layernorm_fwd(rows, self.layer_norm.weight, self.layer_norm.bias, save_stats=False)
+        codes = torch.zeros(b, self.nc, 1, dtype=torch.int64, device=yl_tok.device)
+        probs = []
+        for k in range(self.nc):
+            uw, pw = self.U[k].weight, self.P[k].weight
+            res = None
+            if k > 0:
+                ut = _permute_cols(uw, d, k * self.nv)
+                res = tx.embbag_fwd(codes, self.nc, 1, b, list(range(k)), [c * self.nv for c in range(k)], ut, d)
+            u = torch.empty(b, d, dtype=torch.float32, device=y.device)
+            G.gemm(y, uw, u, b, d, d, ldb=uw.shape[1], flags=L.EPI_BIAS | L.EPI_RELU | (L.EPI_RESIDUAL if k else 0),
+                   bias=self.U[k].bias, res=res)
+            o = torch.empty(b, self.nv, dtype=torch.float32, device=y.device)
+            G.gemm(u, pw, o, b, self.nv, d, flags=L.EPI_BIAS, bias=self.P[k].bias)
+            prob = torch.softmax(o / temp, 1)
+            probs.append(prob)
+            codes[:, k, 0] = (torch.multinomial(prob, 1).squeeze(-1) if forced_codes is None
+                              else forced_codes[:, k].to(codes.device))
+        if return_probs:
+            return codes[:, :, 0], torch.stack(probs, 1)
+        return codes[:, :, 0]
+
+    def forward(self, slice, yl, mode="logits", pixel=None, temp=1.0, ch_embedder=None, target=None):
+        b, d, t, h, w = yl.shape
+        tok = convstack._TokensIn.apply(yl)
+        if mode == "logits":
+            outs = self.logits_tokens(slice, tok)
+            return [convstack._TokensOut.apply(o, b, self.nv, t, h, w) for o in outs]
+        if mode == "sample_pixel":
+            ti, hi, wi = pixel
+            return self.sample_pixel_tokens(tok, b, t * h * w, (ti * h + hi) * w + wi, temp)
+        raise ValueError
+
+
+@AUTOREGRESSIVE_REGISTRY.register()
+class VideoTransformer(Autoregressive):
+    @classmethod
+    def from_config(cls, cfg, **kwargs):
+        v = cfg.MODEL.AUTOREGRESSIVE.VT
+        return cls(nc=v.NC, nv=v.NV, kernel_size=v.KERNEL, stride=v.STRIDE, d=v.D, da=v.DA, de=v.DE,
+                   blocks_e=v.BLOCKS_E, n_head_e=v.N_HEAD_E, blocks_d=v.BLOCKS_D, n_head_d=v.N_HEAD_D,
+                   pad_value=v.PAD_VALUE, share_p=v.SHARE_P, share_embeddings=v.SHARE_EMBEDDINGS,
+                   class_num=v.CLASS_NUM)
+
+    def __init__(self, nc, nv, da, de, d, blocks_e, n_head_e, kernel_size, stride, blocks_d, n_head_d, pad_value,
+                 share_p, share_embeddings, class_num):
+        super().__init__()
+        self.nv, self.nc = nv, nc
+        self.encoder = VTEncoder(nc, nv, da, de, d, blocks_e, n_head_e, kernel_size, stride, pad_value, class_num)
+        self.decoder = VTDecoder(nc, nv, da, de, d, blocks_d, n_head_d)
+        self.ch_predictor = ChannelPredictor(d, nc, nv, de, share_p=share_p, share_embeddings=share_embeddings)
+
+    # token-major fast path used by VideoTransformerModel -----------------------------------------------
+    def logits_tokens(self, context, slice, slice_idx):
+        zl = self.encoder.forward_tokens(context, slice_idx)
+        yl = self.decoder.forward_tokens(slice, zl)
+        return self.ch_predictor.logits_tokens(slice, yl)
+
+    def forward(self, context, slice, slice_idx, mode="logits", pixel=None, zl=None, temp=1.0, drop_mask=None,
+                class_idx=None):
+        """Reference contract: logits as a list of nc (b, nv, t, h, w) tensors; `sample_pixel` returns
+        ((b, nc) codes, zl) with zl in the reference's (b, d, t, h, w) layout."""
+        b, nc, t, h, w = slice.shape
+        if mode == "logits":
+            outs = self.logits_tokens(context, slice, slice_idx)
+            return [convstack._TokensOut.apply(o, b, self.nv, t, h, w) for o in outs]
+        if mode == "sample_pixel":
+            zl_tok = (self.encoder.forward_tokens(context, slice_idx) if zl is None
+                      else convstack._TokensIn.apply(zl))
+            yl = self.decoder.forward_tokens(slice, zl_tok)
+            ti, hi, wi = pixel
+            pred = self.ch_predictor.sample_pixel_tokens(yl, b, t * h * w, (ti * h + hi) * w + wi, temp)
+            if zl is None:
+                zl = convstack._TokensOut.apply(zl_tok, b, zl_tok.shape[-1], t, h, w)
+            return pred, zl
+        raise ValueError

@@ -1,0 +1,236 @@
+"""Attention building blocks of the latent video transformer
+(reference: vidgen/modeling/autoregressive/vt_attention.py:10-202).
+
+Modules keep the reference's parameter / buffer names; BlockLocalAttention executes one whole layer
+(LN -> per-head QKV -> QK^T/sqrt(da) + relative-position bias [+ causal fill -1e4] -> softmax -> PV ->
+proj + residual -> LN -> Linear -> ReLU -> Linear + residual) as a single autograd node made of
+fp32-MFMA GEMM launches and fused HBM-bound kernels on token-major (b*S, d) activations.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import init
+
+from ...hip import binding as L
+from ...hip import ew, tx
+from ...hip import gemm as G
+
+
+class PositionalEncoding(nn.Module):
+    """3-D sinusoidal position signal (vt_attention.py:10-50).  The signal depends only on the grid
+    extents, so it is built once per (T,H,W) on the host with the reference's formula and cached on
+    the device as a (T*H*W, d_model) table that one kernel adds to token-major activations."""
+
+    def __init__(self, d_model, num_dims=3, min_timescale=1.0, max_timescale=1.0e4):
+        super().__init__()
+        assert d_model >= num_dims * 2, "d_model should be >= then 2*num_dims"
+        self.d_model, self.num_dims = d_model, num_dims
+        self.num_timescales = d_model // (num_dims * 2)
+        inc = np.log(max_timescale / min_timescale) / self.num_timescales
+        self.register_buffer("inv_timescales",
+                             min_timescale * torch.exp(torch.arange(self.num_timescales).float() * -inc))
+        self._tables = {}
+
+    def table(self, T, H, W, device):
+        key = (T, H, W, str(device))
+        if key not in self._tables:
+            inv = self.inv_timescales.detach().float().cpu()
+            nts = self.num_timescales
+            tab = torch.zeros(T, H, W, self.d_model)
+            for dim, length in enumerate((T, H, W)):
+                scaled = torch.arange(length, dtype=torch.float).view(-1, 1) * inv.view(1, -1)
+                sig = torch.cat([torch.sin(scaled), torch.cos(scaled)], 1)       # (length, 2*nts)
+                shape = [1, 1, 1, 2 * nts]
+                shape[dim] = length
+                tab[..., dim * 2 * nts:(dim + 1) * 2 * nts] += sig.view(shape)
+            self._tables[key] = tab.view(T * H * W, self.d_model).contiguous().to(device)
+        return self._tables[key]
+
+    def add_tokens_(self, x_tok, T, H, W):
+        """x_tok (b*T*H*W, d) += signal, in place."""
+        return ew.add_periodic_(x_tok, self.table(T, H, W, x_tok.device), T * H * W)
+
+    def forward(self, x):
+        """Reference contract: (b, d, T, H, W), in-place add."""
+        b, d, T, H, W = x.shape
+        tab = self.table(T, H, W, x.device).t().reshape(1, d, T, H, W)
+        x += tab
+        return x
+
+
+class MultiHeadAttention(nn.Module):
+    """Parameter container (vt_attention.py:84-112): layer_norm, w_q/w_k/w_v (na, d, da), proj."""
+
+    def __init__(self, na, d, da):
+        super().__init__()
+        self.na, self.da = na, da
+        self.layer_norm = nn.LayerNorm(d)
+        self.w_q = nn.Parameter(torch.empty(na, d, da))
+        self.w_k = nn.Parameter(torch.empty(na, d, da))
+        self.w_v = nn.Parameter(torch.empty(na, d, da))
+        self.proj = nn.Linear(na * da, d, bias=False)
+        self.init_weights()
+
+    def init_weights(self, *args, **kwargs):
+        init.xavier_normal_(self.w_q)
+        init.xavier_normal_(self.w_k)
+        init.xavier_normal_(self.w_v)
+        init.xavier_normal_(self.proj.weight)
+
+
+def _splits(tiles, k):
+    s = max(1, -(-768 // max(1, tiles)))
+    return max(1, min(s, k // 512 if k >= 1024 else 1))
+
+
+def linear_wgrad(dy, x, n_out, k_in, rows):
+    """dW (n_out, k_in) = dy^T x with deterministic split-K."""
+    dw = torch.empty(n_out, k_in, dtype=torch.float32, device=dy.device)
+    tiles = -(-n_out // 128) * -(-k_in // 128)
+    G.gemm(dy, x, dw, n_out, k_in, rows, ta=1, tb=1, lda=dy.shape[-1], ldb=x.shape[-1], splits=_splits(tiles, rows))
+    return dw
+
+
+class _BlockLocalAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, block, masked, dt, dh, dw, ln_w, ln_b, w_q, w_k, w_v, proj_w, f0w, f0b, f1w, f1b, f3w, f3b):
+        L.require(x)
+        M, d = x.shape
+        S = block[0] * block[1] * block[2]
+        b = M // S
+        na, _, da = w_q.shape
+        hd = na * da
+        temper = math.sqrt(da)
+        dev = x.device
+        xn, mean1, rstd1 = ew.layernorm_fwd(x, ln_w, ln_b)
+        qkv = []
+        for w in (w_q, w_k, w_v):
+            out = torch.empty(M, hd, dtype=torch.float32, device=dev)
+            G.gemm(xn, w, out, M, da, d, ta=0, tb=1, lda=d, ldb=da, ldc=hd, batch_inner=na, sB=(0, d * da), sC=(0, da))
+            qkv.append(out)
+        q, k, v = qkv
+        P = torch.empty(b, na, S, S, dtype=torch.float32, device=dev)
+        G.gemm(q, k, P, S, S, da, ta=0, tb=0, lda=hd, ldb=hd, ldc=S, batch_outer=b, batch_inner=na,
+               sA=(S * hd, da), sB=(S * hd, da), sC=(na * S * S, S * S))
+        tx.attn_softmax_fwd_(P, temper, dt, dh, dw, block, masked)
+        o = torch.empty(M, hd, dtype=torch.float32, device=dev)
+        G.gemm(P, v, o, S, da, S, ta=0, tb=1, lda=S, ldb=hd, ldc=hd, batch_outer=b, batch_inner=na,
+               sA=(na * S * S, S * S), sB=(S * hd, da), sC=(S * hd, da))
+        y1 = torch.empty(M, d, dtype=torch.float32, device=dev)
+        G.gemm(o, proj_w, y1, M, d, hd, flags=L.EPI_RESIDUAL, res=x)
+        fn, mean2, rstd2 = ew.layernorm_fwd(y1, f0w, f0b)
+        h1 = torch.empty(M, f1w.shape[0], dtype=torch.float32, device=dev)
+        G.gemm(fn, f1w, h1, M, f1w.shape[0], d, flags=L.EPI_BIAS | L.EPI_RELU, bias=f1b)
+        y2 = torch.empty(M, d, dtype=torch.float32, device=dev)
+        G.gemm(h1, f3w, y2, M, d, f3w.shape[1], flags=L.EPI_BIAS | L.EPI_RESIDUAL, bias=f3b, res=y1)
+        ctx.save_for_backward(x, mean1, rstd1, xn, q, k, v, P, o, y1, mean2, rstd2, fn, h1,
+                              ln_w, w_q, w_k, w_v, proj_w, f0w, f1w, f3w)
+        ctx.block, ctx.dims = block, (M, d, S, b, na, da)
+        return y2
+
+    @staticmethod
+    def backward(ctx, dy2):
+        (x, mean1, rstd1, xn, q, k, v, P, o, y1, mean2, rstd2, fn, h1,
+         ln_w, w_q, w_k, w_v, proj_w, f0w, f1w, f3w) = ctx.saved_tensors
+        M, d, S, b, na, da = ctx.dims
+        hd = na * da
+        temper = math.sqrt(da)
+        dev = x.device
+        dy2 = dy2.contiguous()
+        dff = f1w.shape[0]
+        # FFN: y2 = h1 W3^T + b3 + y1 ; h1 = relu(fn W1^T + b1)
+        dh1 = torch.empty(M, dff, dtype=torch.float32, device=dev)
+        G.gemm(dy2, f3w, dh1, M, dff, d, ta=0, tb=1, ldb=dff, flags=L.EPI_MASK, mask=h1)
+        df3w = linear_wgrad(dy2, h1, d, dff, M)
+        df3b = G.colsum(dy2, M, d)
+        dfn = torch.empty(M, d, dtype=torch.float32, device=dev)
+        G.gemm(dh1, f1w, dfn, M, d, dff, ta=0, tb=1, ldb=d)
+        df1w = linear_wgrad(dh1, fn, dff, d, M)
+        df1b = G.colsum(dh1, M, dff)
+        dy1, df0w, df0b = ew.layernorm_bwd(dfn, y1, mean2, rstd2, f0w, add=dy2)
+        # proj: y1 = o proj^T + x
+        do = torch.empty(M, hd, dtype=torch.float32, device=dev)
+        G.gemm(dy1, proj_w, do, M, hd, d, ta=0, tb=1, ldb=hd)
+        dproj = linear_wgrad(dy1, o, d, hd, M)
+        # attention core
+        bh = dict(batch_outer=b, batch_inner=na)
+        dv = torch.empty(M, hd, dtype=torch.float32, device=dev)
+        G.gemm(P, do, dv, S, da, S, ta=1, tb=1, lda=S, ldb=hd, ldc=hd, sA=(na * S * S, S * S), sB=(S * hd, da),
+               sC=(S * hd, da), **bh)
+        dP = torch.empty(b, na, S, S, dtype=torch.float32, device=dev)
+        G.gemm(do, v, dP, S, S, da, ta=0, tb=0, lda=hd, ldb=hd, ldc=S, sA=(S * hd, da), sB=(S * hd, da),
+               sC=(na * S * S, S * S), **bh)
+        ddt, ddh, ddw = tx.attn_softmax_bwd_(P, dP, temper, ctx.block)       # dP now holds dS
+        dq = torch.empty(M, hd, dtype=torch.float32, device=dev)
+        G.gemm(dP, k, dq, S, da, S, ta=0, tb=1, lda=S, ldb=hd, ldc=hd, sA=(na * S * S, S * S), sB=(S * hd, da),
+               sC=(S * hd, da), **bh)
+        dk = torch.empty(M, hd, dtype=torch.float32, device=dev)
+        G.gemm(dP, q, dk, S, da, S, ta=1, tb=1, lda=S, ldb=hd, ldc=hd, sA=(na * S * S, S * S), sB=(S * hd, da),
+               sC=(S * hd, da), **bh)
+        del dP
+        # per-head projections: q = xn w_q[h]
+        dxn = torch.empty(M, d, dtype=torch.float32, device=dev)
+        dws = []
+        for i, (g_, w) in enumerate(((dq, w_q), (dk, w_k), (dv, w_v))):
+            G.gemm(g_, w, dxn, M, d, hd, ta=0, tb=0, lda=hd, ldb=da, b_kb=da, b_skb=d * da,
+                   flags=L.EPI_ACCUM if i else 0)
+            dwh = torch.empty(na, d, da, dtype=torch.float32, device=dev)
+            G.gemm(xn, g_, dwh, d, da, M, ta=1, tb=1, lda=d, ldb=hd, ldc=da, batch_inner=na, sB=(0, da),
+                   sC=(0, d * da), splits=_splits(na * -(-d // 128), M))
+            dws.append(dwh)
+        dx, dlnw, dlnb = ew.layernorm_bwd(dxn, x, mean1, rstd1, ln_w, add=dy1)
+        return (dx, None, None, ddt, ddh, ddw, dlnw, dlnb, dws[0], dws[1], dws[2], dproj, df0w, df0b,
+                df1w, df1b, df3w, df3b)
+
+
+class BlockLocalAttention(nn.Module):
+    def __init__(self, block_size, da, d, n_head, masked=False):
+        super().__init__()
+        self.block_size = tuple(block_size)
+        self.n_head, self.masked = n_head, masked
+        self.mha = MultiHeadAttention(n_head, d, da)
+        self.ffn = nn.Sequential(nn.LayerNorm(d), nn.Linear(d, d), nn.ReLU(True), nn.Linear(d, d))
+        t, h, w = self.block_size
+        self.dt_bank = nn.Parameter(torch.zeros(n_head, 2 * t - 1))
+        self.dh_bank = nn.Parameter(torch.zeros(n_head, 2 * h - 1))
+        self.dw_bank = nn.Parameter(torch.zeros(n_head, 2 * w - 1))
+        # index / mask buffers are part of the reference's state_dict (vt_attention.py:146-167); the
+        # kernels derive the same indices arithmetically and never read them.
+        it = torch.arange(t).view(t, 1, 1).expand(t, h, w).reshape(-1, 1)
+        ih = torch.arange(h).view(1, h, 1).expand(t, h, w).reshape(-1, 1)
+        iw = torch.arange(w).view(1, 1, w).expand(t, h, w).reshape(-1, 1)
+        for name, ix, n in (("dt", it, t), ("dh", ih, h), ("dw", iw, w)):
+            self.register_buffer(name, (ix - ix.t() + (n - 1)).reshape(-1))
+        if masked:
+            s = t * h * w
+            self.register_buffer("mask", torch.triu(torch.ones(1, 1, s, s), diagonal=1))
+        else:
+            self.register_buffer("mask", None)
+
+    def get_B(self):
+        """(n_head, 1, S, S) relative-position bias (vt_attention.py:169-174); diagnostic only."""
+        t, h, w = self.block_size
+        s = t * h * w
+        return (self.dt_bank.index_select(1, self.dt) + self.dh_bank.index_select(1, self.dh)
+                + self.dw_bank.index_select(1, self.dw)).view(self.n_head, 1, s, s)
+
+    def forward_tokens(self, x_tok):
+        """(b*S, d) token-major -> same."""
+        m, f = self.mha, self.ffn
+        return _BlockLocalAttentionFn.apply(
+            x_tok, self.block_size, self.masked, self.dt_bank, self.dh_bank, self.dw_bank,
+            m.layer_norm.weight, m.layer_norm.bias, m.w_q, m.w_k, m.w_v, m.proj.weight,
+            f[0].weight, f[0].bias, f[1].weight, f[1].bias, f[3].weight, f[3].bias)
+
+    def forward(self, x):
+        """Reference contract: (B, C, T, H, W) -> same shape."""
+        from .. import convstack
+        B, C, T, H, W = x.shape
+        if (T, H, W) != self.block_size:
+            raise NotImplementedError("block-split attention (vt_attention.py:189-200) is only needed by the "
+                                      "DSSVT/DSTSVT evaluation configs and is not built yet")
+        tok = convstack._TokensIn.apply(x)
+        tok = self.forward_tokens(tok)
+        return convstack._TokensOut.apply(tok, B, C, T, H, W)

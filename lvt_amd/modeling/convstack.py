@@ -90,3 +90,34 @@ class ResBlock(nn.Module):
         super().__init__()
         self.block = nn.Sequential(nn.ReLU(True), nn.Conv2d(dim, dim_res, 3, 1, 1), nn.ReLU(True),
                                    nn.Conv2d(dim_res, dim, 1))
+
+
+class _TokensIn(torch.autograd.Function):
+    """(B, C, T, H, W) -> token-major (B*T*H*W, C)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        B, C = x.shape[:2]
+        R = x[0, 0].numel()
+        return ew.to_channels_last(x.contiguous().view(B, C, R), C).view(B * R, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C = ctx.shape[:2]
+        R = g.shape[0] // B
+        return ew.to_channels_first(g.contiguous().view(B, R, C), C).view(ctx.shape)
+
+
+class _TokensOut(torch.autograd.Function):
+    """token-major (B*R, C) -> (B, C, T, H, W)."""
+
+    @staticmethod
+    def forward(ctx, tok, B, C, T, H, W):
+        return ew.to_channels_first(tok.contiguous().view(B, T * H * W, tok.shape[-1]), C).view(B, C, T, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C = g.shape[:2]
+        R = g[0, 0].numel()
+        return ew.to_channels_last(g.contiguous().view(B, C, R), C).view(B * R, C), None, None, None, None, None

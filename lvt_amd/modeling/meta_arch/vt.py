@@ -1,9 +1,208 @@
+"""Latent video transformer meta-architecture (reference: vidgen/modeling/meta_arch/vt.py:22-328).
+
+supervised: one random subscale slice per sample -> mean_k CE(logits_k, slice_k | ignore first N_PRIME frames).
+inference : logits for an entire video (BitsEvaluator) and / or autoregressive sampling (VTSampler).
+"""
+import os
+
+import torch
 from torch import nn
 
+from ...engine.grad_reducer import BucketedGradReducer
+from ...hip import binding as L
+from ...hip import tx
+from ...solver import build_lr_scheduler, build_optimizer
+from ...utils.checkpoint import Checkpointer
+from ...utils.events import get_event_storage
+from ..autoregressive import build_autoregressive
+from ..autoregressive.vt_utils import slice_and_context, subscale_order
 from .build import META_ARCH_REGISTRY
+from .common import init_weights, stack_to_device
+
+
+class _XentFn(torch.autograd.Function):
+    """scale * mean over non-ignored positions of CE(logits_tok (rows, nv), target[:, k])."""
+
+    @staticmethod
+    def forward(ctx, logits, target, k, ignore, scale):
+        b, nc, P = target.shape
+        loss, lse, count = tx.xent_fwd(logits, target[0, k], nc * P, 1, P, ignore, scale)
+        ctx.save_for_backward(logits, target, lse, count)
+        ctx.args = (k, ignore, scale)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, lse, count = ctx.saved_tensors
+        k, ignore, scale = ctx.args
+        b, nc, P = target.shape
+        return tx.xent_bwd(logits, target[0, k], nc * P, 1, P, ignore, lse, count, g.contiguous().view(1), scale), \
+            None, None, None, None
 
 
 @META_ARCH_REGISTRY.register()
-class VideoTransformerModel(nn.Module):   # placeholder until the transformer path lands
+class VideoTransformerModel(nn.Module):
     def __init__(self, cfg):
-        raise NotImplementedError
+        super().__init__()
+        self.cfg = cfg
+        self.device = torch.device(cfg.MODEL.DEVICE)
+        self.model = build_autoregressive(cfg)
+        self.init_weights(self.model, cfg.MODEL.INIT_TYPE)
+        self.vis_period = cfg.VIS_PERIOD
+        self._reducers = []
+        self.to(self.device)
+
+    init_weights = staticmethod(init_weights)
+
+    def train(self, mode=True):
+        self.training = mode
+        self.model.train(mode)
+        return self
+
+    def wrap_parallel(self, device_ids, broadcast_buffers):
+        """Bucketed RCCL gradient averaging overlapped with backward (reference: torch DDP, vt.py:61-63)."""
+        self._reducers = [BucketedGradReducer(self.model.parameters())]
+
+    def finish_gradient_sync(self):
+        for r in self._reducers:
+            r.wait()
+
+    def _require_gpu(self):
+        if self.device.type != "cuda":
+            raise L.LvtError("lvt_amd models compute only on a MI355X (MODEL.DEVICE=%s); there is no CPU path"
+                             % self.device)
+
+    @property
+    def _vt(self):
+        return self.cfg.MODEL.AUTOREGRESSIVE.VT
+
+    # ---- supervised ------------------------------------------------------------------------------------
+    def preprocess_data(self, data):
+        """list[dict] -> (context, slice, slice_idx, ignore_mask, class_idx) on the device (vt.py:284-299)."""
+        self._require_gpu()
+        ctx = stack_to_device([x["context"] for x in data], self.device)
+        sl = stack_to_device([x["slice"] for x in data], self.device)
+        sidx = stack_to_device([x["slice_idx"] for x in data], self.device)
+        ign = stack_to_device([x["ignore_mask"] for x in data], self.device)
+        if "class" in data[0]:
+            raise NotImplementedError("class-conditional training (CLASS_NUM > 0) is not built")
+        return ctx, sl, sidx, ign, None
+
+    def compute_supervised_loss(self, context, slice, slice_idx, ignore_mask, iter=0, class_idx=None):
+        ignore = self.cfg.MODEL.IGNORE_INDEX
+        b, nc = slice.shape[:2]
+        target = torch.masked_fill(slice, ignore_mask, ignore).reshape(b, nc, -1).contiguous()
+        logits = self.model.logits_tokens(context.contiguous(), slice.contiguous(), slice_idx.contiguous())
+        loss = 0
+        for k in range(nc):
+            loss = loss + _XentFn.apply(logits[k], target, k, ignore, 1.0 / nc)
+        return {"loss_cross_entropy": loss}
+
+    def forward(self, data, mode="inference"):
+        if mode == "supervised":
+            context, slice, slice_idx, ignore_mask, class_idx = self.preprocess_data(data)
+            it = get_event_storage().iter
+            return self.compute_supervised_loss(context, slice, slice_idx, ignore_mask, it, class_idx)
+        if mode == "inference":
+            self._require_gpu()
+            output = [{} for _ in range(len(data))]
+            if "BitsEvaluator" in self.cfg.TEST.EVALUATORS:
+                output = self.calculate_logits_for_entire_video(data, output)
+            if "VTSampler" in self.cfg.TEST.EVALUATORS:
+                output = self.sample_videos(data, output, n_prime=self.cfg.TEST.VT_SAMPLER.N_PRIME,
+                                            num_samples=self.cfg.TEST.VT_SAMPLER.NUM_SAMPLES)
+            assert len(output[0]) > 0
+            return output
+        raise ValueError("|mode| is invalid")
+
+    # ---- likelihood of a whole video (vt.py:230-282) ------------------------------------------------------
+    @torch.no_grad()
+    def calculate_logits_for_entire_video(self, data, output):
+        v = self._vt
+        video = stack_to_device([torch.as_tensor(x["image_sequence"]) for x in data], self.device)
+        B, T, nc, H, W = video.shape
+        video = video.transpose(1, 2).contiguous()                   # B, nc, T, H, W
+        st, sh, sw = v.STRIDE
+        idx2abc, _ = subscale_order(st, sh, sw)
+        t, h, w = T // st, H // sh, W // sw
+        logits = torch.zeros(B, nc, v.NV, T, H, W, device=video.device)
+        for si, (a, b_, c) in enumerate(idx2abc):
+            sl, ctx = slice_and_context(video, a, b_, c, v.STRIDE, v.KERNEL, v.PAD_VALUE)
+            sidx = torch.full((B,), si, dtype=torch.long, device=video.device)
+            pred = self.model.logits_tokens(ctx.contiguous(), sl, sidx)          # nc x (B*t*h*w, nv)
+            for k in range(nc):
+                logits[:, k, :, a::st, b_::sh, c::sw] = pred[k].view(B, t, h, w, v.NV).permute(0, 4, 1, 2, 3)
+        ignore_mask = torch.zeros(1, T, H, W, dtype=torch.bool, device=video.device)
+        if v.N_PRIME > 0:
+            ignore_mask[:, :v.N_PRIME] = True
+        for i in range(B):
+            output[i]["ignore_mask"] = ignore_mask
+            output[i]["logits"] = logits[i]
+        return output
+
+    # ---- sampling (vt.py:82-136, 210-228) -----------------------------------------------------------------
+    @torch.no_grad()
+    def sample_video(self, video, temp=1.0, n_prime=1, class_idx=None):
+        """video (B, nc, T, H, W) int64 with the first n_prime frames given; returns the completed grid.
+        Same schedule as the reference (encoder once per slice, full decoder pass per generated pixel)."""
+        self._require_gpu()
+        v = self._vt
+        video = video.to(self.device).clone()
+        st, sh, sw = v.STRIDE
+        idx2abc, _ = subscale_order(st, sh, sw)
+        B, nc, T, H, W = video.shape
+        t, h, w = T // st, H // sh, W // sw
+        prime = torch.zeros(T, H, W, dtype=torch.bool)
+        if n_prime > 0:
+            prime[:n_prime] = True
+        for si, (a, b_, c) in enumerate(idx2abc):
+            sl, ctx = slice_and_context(video, a, b_, c, v.STRIDE, v.KERNEL, v.PAD_VALUE)
+            prime_sl = prime[a::st, b_::sh, c::sw]
+            if bool(prime_sl.all()):
+                continue
+            sidx = torch.full((B,), si, dtype=torch.long, device=video.device)
+            zl = self.model.encoder.forward_tokens(ctx.contiguous(), sidx)     # context is fixed per slice
+            for ti in range(t):
+                for hi in range(h):
+                    for wi in range(w):
+                        if prime_sl[ti, hi, wi]:
+                            continue
+                        yl = self.model.decoder.forward_tokens(sl, zl)
+                        sl[:, :, ti, hi, wi] = self.model.ch_predictor.sample_pixel_tokens(
+                            yl, B, t * h * w, (ti * h + hi) * w + wi, temp)
+            video[:, :, a::st, b_::sh, c::sw] = sl
+        return video
+
+    @torch.no_grad()
+    def sample_slice(self, context, slice_idx, slice_size, temp=0.9, class_idx=None):
+        sl = torch.zeros(size=slice_size, device=context.device, dtype=torch.long)
+        B, _, t, h, w = sl.shape
+        zl = self.model.encoder.forward_tokens(context.contiguous(), slice_idx.contiguous())
+        for ti in range(t):
+            for hi in range(h):
+                for wi in range(w):
+                    yl = self.model.decoder.forward_tokens(sl, zl)
+                    sl[:, :, ti, hi, wi] = self.model.ch_predictor.sample_pixel_tokens(
+                        yl, B, t * h * w, (ti * h + hi) * w + wi, temp)
+        return sl
+
+    def sample_videos(self, data, output, n_prime=5, num_samples=1):
+        video = stack_to_device([torch.as_tensor(x["image_sequence"]) for x in data], self.device)
+        video = video.transpose(1, 2).contiguous()                   # B, nc, T, H, W
+        video[:, :, n_prime:] = 0
+        if "class" in data[0]:
+            raise NotImplementedError("class-conditional sampling is not built")
+        samples = [self.sample_video(video.clone(), n_prime=n_prime) for _ in range(num_samples)]
+        assert video.size(0) == len(output)
+        for i in range(video.size(0)):
+            output[i]["samples"] = [s[i] for s in samples]
+        return output
+
+    # ---- optimizers / checkpointers (vt.py:316-328) -----------------------------------------------------
+    def configure_optimizers_and_checkpointers(self):
+        opt = build_optimizer(self.model, self.cfg, suffix="_G")
+        os.makedirs(os.path.join(self.cfg.OUTPUT_DIR, "netG"), exist_ok=True)
+        c = [{"checkpointer": Checkpointer(self.model, os.path.join(self.cfg.OUTPUT_DIR, "netG")),
+              "pretrained": self.cfg.MODEL.GENERATOR.WEIGHTS}]
+        o = [{"optimizer": opt, "scheduler": build_lr_scheduler(self.cfg, opt), "type": "generator"}]
+        return o, c

@@ -408,7 +408,7 @@ def multi_head_attention(p, pre, x, B, masked):
     attn = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(da)
     attn = attn + B
     if masked:
-        m = torch.triu(torch.ones(1, 1, s, s), diagonal=1).bool()
+        m = torch.triu(torch.ones(1, 1, s, s), diagonal=1).bool()   # reference: float buffer .bool()
         attn = attn.masked_fill(m, -1e4)
     attn = torch.softmax(attn, dim=3)
     out = torch.matmul(attn, v)  # na, b, s, da
@@ -468,8 +468,8 @@ def vt_encoder(p, context, slice_idx, blocks, stride, nv=512, pad_value=-1):
     oh = oh.masked_fill(mask.unsqueeze(-1), 0)
     oh = oh.permute(0, 1, 5, 2, 3, 4).contiguous()
     b, nc, _, T, H, W = oh.shape
-    x = F.conv3d(oh.view(b, nc * nv, T, H, W).float(), p[pre + "conv.weight"], p[pre + "conv.bias"],
-                 stride=stride)
+    w = p[pre + "conv.weight"]
+    x = F.conv3d(oh.view(b, nc * nv, T, H, W).to(w.dtype), w, p[pre + "conv.bias"], stride=stride)
     x = x + F.embedding(slice_idx, p[pre + "slice_embedding.weight"])[:, :, None, None, None]
     x = F.conv3d(x, p[pre + "linear_projector.weight"])
     for i, blk in enumerate(blocks):
@@ -486,7 +486,7 @@ def vt_decoder(p, sl, zl, blocks):
         emb = emb + F.embedding(sl[:, k], p[pre + "ch_embedder.%d.weight" % k])   # b,t,h,w,de
     x = emb.permute(0, 4, 1, 2, 3)
     x, _ = masked_conv3d(p[pre + "conv.conv.weight"], p[pre + "conv.conv.bias"], x)
-    x = x + positional_encoding_table(x.size(1), t, h, w)[None]
+    x = x + positional_encoding_table(x.size(1), t, h, w)[None].to(x.dtype)
     x = x + F.conv3d(zl, p[pre + "linear_projector.weight"])
     for i, blk in enumerate(blocks):
         x = block_local_attention(p, pre + "block_local_attention.%d." % i, x, blk, masked=True)
@@ -501,7 +501,7 @@ def channel_predictor_logits(p, sl, yl, nv=512):
     nc = sl.size(1)
     y = layer_norm(yl.view(b, d, -1).transpose(1, 2), p[pre + "layer_norm.weight"],
                    p[pre + "layer_norm.bias"])
-    oh = F.one_hot(sl.view(b, nc, -1).transpose(1, 2), nv).view(b, t * h * w, nc * nv).float()
+    oh = F.one_hot(sl.view(b, nc, -1).transpose(1, 2), nv).view(b, t * h * w, nc * nv).to(y.dtype)
     out = []
     for k in range(nc):
         inp = y if k == 0 else torch.cat((y, oh[:, :, :k * nv]), dim=2)
