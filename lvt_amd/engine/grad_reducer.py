@@ -15,10 +15,15 @@ import torch.distributed as dist
 
 
 class BucketedGradReducer:
-    def __init__(self, params, bucket_bytes=16 << 20, group=None):
+    def __init__(self, params, bucket_bytes=16 << 20, group=None, broadcast_params=True):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if broadcast_params and self.world > 1:
+            # like torch DDP at construction: every replica starts from rank 0's weights
+            with torch.no_grad():
+                for p in self.params:
+                    dist.broadcast(p.data, 0, group=group)
         self.buckets = []          # list of dict(flat, params, offsets, pending, work)
         self._slot = {}
         cur, cur_bytes = [], 0

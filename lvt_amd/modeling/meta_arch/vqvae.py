@@ -36,6 +36,22 @@ class VQVAEModel(AutoEncoderModel):
         self.codebook.train(mode)
         return self
 
+    def wrap_parallel(self, device_ids, broadcast_buffers):
+        """Encoder / generator gradients are averaged by the bucketed reducer (see AutoEncoderModel).  The
+        EMA codebook takes no gradient; its statistics are summed across ranks inside the quantiser.  The
+        reference neither wraps nor synchronises the codebook, so with per-rank seeds (SEED + rank) the
+        replicas start from different codebooks and only converge geometrically; here rank 0's codebook
+        and EMA buffers are broadcast once so that all replicas stay bit-identical (documented deviation,
+        single-GPU behaviour unaffected)."""
+        import torch
+        import torch.distributed as dist
+        from ...utils import comm
+        super().wrap_parallel(device_ids, broadcast_buffers)
+        if comm.get_world_size() > 1:
+            with torch.no_grad():
+                for t in self.codebook._flat():
+                    dist.broadcast(t, 0)
+
     def _generator_parameters(self):
         params = super()._generator_parameters()
         if not self.use_codebook_ema:
