@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-clips", type=int, default=32, help="clips per GPU per step (BASELINE: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dsfvt", action="store_true", help="skip the secondary DSFVT train-step figure")
+    ap.add_argument("--dsfvt-batch", type=int, default=64)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
@@ -68,6 +70,69 @@ def vqvae_step(model, optimizers, data, storage_iter):
     for o in optimizers:
         o["optimizer"].zero_grad()
     return losses
+
+
+def bench_dsfvt(device, world, rank, steps, warmup, batch):
+    """Secondary figure: DSFVT train step (fwd + bwd + RMSprop) on synthetic code clips, one random
+    subscale slice per clip (BASELINE.json configs[2]); reported under `extra.dsfvt`."""
+    from lvt_amd.config import get_cfg
+    from lvt_amd.data.dataset_mapper import prepare_slices_batch
+    from lvt_amd.hip import binding as L
+    from lvt_amd.modeling import build_model
+    from lvt_amd.utils.events import EventStorage
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs/vt/DSFVT.yaml"))
+    cfg.MODEL.DEVICE = device
+    cfg.OUTPUT_DIR = "/tmp/lvt_bench_out"
+    torch.manual_seed(29871897 + rank)
+    model = build_model(cfg)
+    model.train()
+    optimizers, _ = model.configure_optimizers_and_checkpointers()
+    if world > 1:
+        model.wrap_parallel(device_ids=[0], broadcast_buffers=False)
+    v = cfg.MODEL.AUTOREGRESSIVE.VT
+    g = torch.Generator(device="cpu").manual_seed(4321 + rank)
+    codes = torch.randint(0, v.NV, (batch, 16, v.NC, 16, 16), generator=g).to(device)
+    abcs = [(int(a), 0, 0) for a in torch.randint(v.N_PRIME, 16, (batch,), generator=g)]
+    ctx, sl, sidx, ign = prepare_slices_batch(codes, abcs, v.STRIDE, v.KERNEL, v.N_PRIME, v.PAD_VALUE)
+
+    def step(i):
+        with EventStorage(i):
+            loss = model.compute_supervised_loss(ctx, sl, sidx, ign)["loss_cross_entropy"]
+        loss.backward()
+        model.finish_gradient_sync()
+        for o in optimizers:
+            o["optimizer"].step()
+        for o in optimizers:
+            o["optimizer"].zero_grad()
+        return loss
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    L.TIMER = L.KernelTimer()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    timer, L.TIMER = L.TIMER, None
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    summ = timer.summary()
+    eng_ms = sum(v_["ms"] for v_ in summ.values())
+    eng_fl = sum(v_["flops"] for v_ in summ.values())
+    return {"samples_per_s": round(batch * world * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 2),
+            "batch_per_gpu": batch, "loss": round(float(loss.detach()), 5),
+            "engine_tflops": round(eng_fl / (eng_ms * 1e-3) / 1e12, 2) if eng_ms else None,
+            "engine_ms_per_step": round(eng_ms / steps, 2),
+            "note": "one subscale slice (256 tokens x 4 code channels) of one 16-frame clip per sample; "
+                    "fp32; 49.87M parameters; engine_tflops counts executed GEMM FLOPs of the fp32-MFMA engine"}
 
 
 def cpu_baseline(batch_clips, budget_s):
@@ -161,6 +226,12 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
+    extra = {}
+    if not args.no_dsfvt:
+        del model, optimizers, clips, data
+        torch.cuda.empty_cache()
+        extra["dsfvt"] = bench_dsfvt(device, world, rank, max(3, args.steps // 4), 2, args.dsfvt_batch)
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = args.batch_clips * world * args.steps / elapsed
@@ -188,6 +259,7 @@ def main():
                                    % (launches // args.steps, tot_ms / args.steps, ms),
                          "per_kind": per_kind},
         }
+        out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch_clips, args.cpu_seconds)
         print(json.dumps(out))

@@ -111,10 +111,13 @@ int lvt_vq_nearest(const float *z, long long rows, int ldz, int num, int D, int 
 /* out[row][g*D+d] = codebooks[g][idx][d]   (index_select / embedding: z_q_st, z_q_bar, mode "emb")   */
 int lvt_vq_gather(const long long *idx, const float *codebooks, long long rows, int num, int D, int KC,
                   int P, float *out, int ldo, void *stream);
-/* stats[num][KC][D+1]: per-code sum of assigned rows and (last column) their count; zeroed inside.
+/* stats[num][KC][D+1]: per-code sum of assigned rows and (last column) their count.  LDS-private
+ * accumulation per (group, row chunk) + fixed-order chunk reduction: no atomics, bit-reproducible.
  * Kept separate from finalize so that a data-parallel all-reduce of `stats` can sit in between.      */
+size_t lvt_vq_ema_workspace_bytes(long long rows, int num, int D, int KC);
 int lvt_vq_ema_accumulate(const long long *idx, const float *z, long long rows, int ldz, int num, int D,
-                          int KC, int P, float *stats, void *stream);
+                          int KC, int P, float *stats, void *workspace, size_t workspace_bytes,
+                          void *stream);
 /* running_size[num][KC], running_sum/weight[num][KC][D] updated in place (vq_embedding.py:48-59).    */
 int lvt_vq_ema_finalize(const float *stats, int num, int D, int KC, float decay, float eps,
                         float *running_size, float *running_sum, float *weight, void *stream);
@@ -190,6 +193,20 @@ int lvt_xent_fwd(const float *logits, const long long *target, long long tstride
 int lvt_xent_bwd(const float *logits, const long long *target, long long tstride_b, long long tstride_pos,
                  int P, long long rows, int V, long long ignore, const float *lse, const float *count,
                  const float *gout, float scale, float *dlogits, void *stream);
+
+/* ---- fused multi-tensor optimizer steps (torch.optim.Adam / RMSprop as configured by
+ * vidgen/solver/build.py:46-74; the reference's one-param-group-per-parameter layout costs hundreds of
+ * launches per step).  `entries` is a HOST array; up to 64 tensors travel by value per launch.          */
+typedef struct {
+    float *p; const float *g; float *s0; float *s1;   /* param, grad, state 0, state 1 (device pointers) */
+    long long n; float lr; float wd;
+} lvt_opt_entry;
+/* s0 = exp_avg, s1 = exp_avg_sq; step = 1-based step count (bias correction).                           */
+int lvt_adam_step(const lvt_opt_entry *entries, int n, float beta1, float beta2, float eps, int step,
+                  void *stream);
+/* s0 = square_avg, s1 = momentum_buffer.                                                                */
+int lvt_rmsprop_step(const lvt_opt_entry *entries, int n, float alpha, float eps, float momentum,
+                     void *stream);
 
 #ifdef __cplusplus
 }

@@ -279,7 +279,7 @@ extern "C" int lvt_layernorm_fwd(const float *x, long long rows, int d, float ep
 }
 
 // dx = rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat)) (+ add);  partial dw/db per workgroup
-#define LN_BWD_BLOCKS 512
+#define LN_BWD_BLOCKS 256
 __global__ __launch_bounds__(256) void lvt_layernorm_bwd_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ mean,
     const float *__restrict__ rstd, const float *__restrict__ w, long long rows, int d, const float *__restrict__ add,
@@ -344,13 +344,23 @@ __global__ __launch_bounds__(256) void lvt_layernorm_bwd_kernel(
         pdb[(long long)blockIdx.x * d + c] = ((sdb[0][c] + sdb[1][c]) + sdb[2][c]) + sdb[3][c];
     }
 }
-__global__ void lvt_rowsum_partials_kernel(const float *__restrict__ partial, int nblk, int n,
-                                           float *__restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
+// out[c] = sum_b partial[b][c] with the partial rows split over RL row-lanes per column group
+// (fixed order: lane-local sequential sums, then lanes combined in lane order).
+__global__ __launch_bounds__(256) void lvt_rowsum_partials_kernel(const float *__restrict__ partial, int nblk, int n,
+                                                                  float *__restrict__ out) {
+    __shared__ float red[256];
+    const int cols = 32;                       // columns per workgroup
+    const int c = blockIdx.x * cols + (threadIdx.x % cols);
+    const int rl = threadIdx.x / cols, RL = 256 / cols;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * n + c];
-    out[c] = s;
+    if (c < n)
+        for (int b = rl; b < nblk; b += RL) s += partial[(long long)b * n + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && c < n) {
+        for (int k = 1; k < RL; ++k) s += red[k * cols + threadIdx.x];
+        out[c] = s;
+    }
 }
 extern "C" size_t lvt_layernorm_bwd_workspace_bytes(int d) { return (size_t)2 * LN_BWD_BLOCKS * d * sizeof(float); }
 extern "C" int lvt_layernorm_bwd(const float *dy, const float *x, const float *mean, const float *rstd,
@@ -367,8 +377,8 @@ extern "C" int lvt_layernorm_bwd(const float *dy, const float *x, const float *m
     hipLaunchKernelGGL(lvt_layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, s, dy, x, mean, rstd, w, rows, d, add,
                        dx, pdw, pdb);
     LVT_CHECK_LAUNCH("lvt_layernorm_bwd_kernel");
-    hipLaunchKernelGGL(lvt_rowsum_partials_kernel, dim3((d + 255) / 256), dim3(256), 0, s, pdw, blocks, d, dw);
-    hipLaunchKernelGGL(lvt_rowsum_partials_kernel, dim3((d + 255) / 256), dim3(256), 0, s, pdb, blocks, d, db);
+    hipLaunchKernelGGL(lvt_rowsum_partials_kernel, dim3((d + 31) / 32), dim3(256), 0, s, pdw, blocks, d, dw);
+    hipLaunchKernelGGL(lvt_rowsum_partials_kernel, dim3((d + 31) / 32), dim3(256), 0, s, pdb, blocks, d, db);
     LVT_CHECK_LAUNCH("lvt_rowsum_partials_kernel");
     return LVT_OK;
 }

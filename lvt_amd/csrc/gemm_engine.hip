@@ -807,7 +807,6 @@ extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, con
     return LVT_OK;
 }
 
-#define CS_ROWS 512
 // ---- one-hot transposed GEMM (embedding / one-hot-linear weight gradients) ----------------------------
 static int onehot_splits(int M, int N, long long rows) {
     const long long tiles = lvt_cdiv(M, 128) * lvt_cdiv(N, 128);
@@ -849,9 +848,13 @@ extern "C" int lvt_onehot_tn_gemm(const long long *idx, int nslots, int V, const
     return LVT_OK;
 }
 
+// rows handled by one workgroup per stage: small enough that stage 1 fills the chip (>= ~256 workgroups
+// for 16k rows), large enough that the recursion is at most 3 launches deep for 2M rows.
+static long long cs_rows(long long rows) { return rows >= (1 << 17) ? 128 : 64; }
 extern "C" size_t lvt_colsum_workspace_bytes(long long M, int N) {
-    const long long b1 = lvt_cdiv(M, CS_ROWS), b2 = lvt_cdiv(b1, CS_ROWS);
-    return (size_t)(b1 + b2 + 2) * N * sizeof(float);
+    long long total = 2, rows = M;
+    while (rows > 1) { rows = lvt_cdiv(rows, cs_rows(rows)); total += rows; }
+    return (size_t)total * N * sizeof(float);
 }
 
 extern "C" int lvt_colsum(const float *g, long long M, int N, long long ld, float *out, void *workspace,
@@ -867,10 +870,11 @@ extern "C" int lvt_colsum(const float *g, long long M, int N, long long ld, floa
     float *buf = (float *)workspace;
     // stages: rows -> ceil(rows / CS_ROWS) until one row is left; the last stage writes `out`
     while (true) {
-        const long long nblk = lvt_cdiv(rows, CS_ROWS);
+        const long long rpb = cs_rows(rows);
+        const long long nblk = lvt_cdiv(rows, rpb);
         float *dst = (nblk == 1) ? out : buf;
         hipLaunchKernelGGL(lvt_colsum_kernel, dim3((unsigned)nblk), dim3(CS_THREADS), 0, s, src, rows, N, lds_,
-                           (long long)CS_ROWS, dst);
+                           rpb, dst);
         LVT_CHECK_LAUNCH("lvt_colsum_kernel");
         if (nblk == 1) break;
         src = dst; rows = nblk; lds_ = N; buf = dst + nblk * N;

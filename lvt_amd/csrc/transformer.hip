@@ -16,46 +16,58 @@ __device__ __forceinline__ float wmax(float v) {
     return v;
 }
 
-#define SM_MAXE 16   // row length S <= 1024
 
 struct BiasGeom { int bt, bh, bw; };   // attention block extents; S == bt*bh*bw
 
 // P[b][h][i][:] = softmax_j( s/temper + (dt[h][..] + dh[h][..]) + dw[h][..]  |  fill where j > i )
+// One wave per row; lane owns 4 consecutive columns per 256-column chunk (16-byte accesses).
+#define SM_MAXC 4    // row length S <= 1024 (float4 chunks of 256 columns)
 __global__ void lvt_attn_softmax_fwd_kernel(float *__restrict__ scores, int B, int H, int S, float temper,
                                             const float *__restrict__ dt, const float *__restrict__ dh,
                                             const float *__restrict__ dw, BiasGeom g, int masked, float fill) {
     const int lane = threadIdx.x & 63;
     const long long nrows = (long long)B * H * S;
-    const int ne = S / 64;
+    const int nc = S / 256;
     for (long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < nrows;
          row += ((long long)gridDim.x * blockDim.x) >> 6) {
         const int i = row % S; const int h = (row / S) % H;
         const int wi = i % g.bw, hi = (i / g.bw) % g.bh, ti = i / (g.bw * g.bh);
         const float *bt = dt + h * (2 * g.bt - 1), *bhp = dh + h * (2 * g.bh - 1), *bwp = dw + h * (2 * g.bw - 1);
         float *p = scores + row * S;
-        float v[SM_MAXE];
+        float v[SM_MAXC][4];
         float m = -3.4e38f;
 #pragma unroll
-        for (int e = 0; e < SM_MAXE; ++e) {
-            if (e < ne) {
-                const int j = lane + 64 * e;
-                const int wj = j % g.bw, hj = (j / g.bw) % g.bh, tj = j / (g.bw * g.bh);
-                const float bias = (bt[ti - tj + g.bt - 1] + bhp[hi - hj + g.bh - 1]) + bwp[wi - wj + g.bw - 1];
-                float x = p[j] / temper + bias;
-                if (masked && j > i) x = fill;
-                v[e] = x;
-                m = fmaxf(m, x);
+        for (int c = 0; c < SM_MAXC; ++c) {
+            if (c < nc) {
+                const int j0 = c * 256 + lane * 4;
+                const float4 x4 = *reinterpret_cast<const float4 *>(p + j0);
+                const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = j0 + e;
+                    const int wj = j % g.bw, hj = (j / g.bw) % g.bh, tj = j / (g.bw * g.bh);
+                    const float bias = (bt[ti - tj + g.bt - 1] + bhp[hi - hj + g.bh - 1]) + bwp[wi - wj + g.bw - 1];
+                    float x = xs[e] / temper + bias;
+                    if (masked && j > i) x = fill;
+                    v[c][e] = x;
+                    m = fmaxf(m, x);
+                }
             }
         }
         m = wmax(m);
         float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < SM_MAXE; ++e)
-            if (e < ne) { v[e] = expf(v[e] - m); s += v[e]; }
+        for (int c = 0; c < SM_MAXC; ++c)
+            if (c < nc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[c][e] = expf(v[c][e] - m); s += v[c][e]; }
+            }
         s = wsum(s);
 #pragma unroll
-        for (int e = 0; e < SM_MAXE; ++e)
-            if (e < ne) p[lane + 64 * e] = v[e] / s;
+        for (int c = 0; c < SM_MAXC; ++c)
+            if (c < nc)
+                *reinterpret_cast<float4 *>(p + c * 256 + lane * 4) =
+                    make_float4(v[c][0] / s, v[c][1] / s, v[c][2] / s, v[c][3] / s);
     }
 }
 
@@ -64,33 +76,40 @@ __global__ void lvt_attn_softmax_fwd_kernel(float *__restrict__ scores, int B, i
 __global__ void lvt_attn_softmax_bwd_kernel(const float *__restrict__ P, float *__restrict__ dP, int B, int H, int S,
                                             float temper, float *__restrict__ G) {
     const int lane = threadIdx.x & 63;
-    const int ne = S / 64;
+    const int nc = S / 256;
     const long long nrows = (long long)H * S;
     for (long long hr = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; hr < nrows;
          hr += ((long long)gridDim.x * blockDim.x) >> 6) {
-        float acc[SM_MAXE];
+        float4 acc[SM_MAXC];
 #pragma unroll
-        for (int e = 0; e < SM_MAXE; ++e) acc[e] = 0.f;
+        for (int c = 0; c < SM_MAXC; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int b = 0; b < B; ++b) {
-            const long long off = ((long long)b * H * S + hr) * S;
-            float pv[SM_MAXE], gv[SM_MAXE];
+            const long long off = ((long long)b * H * S + hr) * S + lane * 4;
+            float4 pv[SM_MAXC], gv[SM_MAXC];
             float dot = 0.f;
 #pragma unroll
-            for (int e = 0; e < SM_MAXE; ++e)
-                if (e < ne) { pv[e] = P[off + lane + 64 * e]; gv[e] = dP[off + lane + 64 * e]; dot += pv[e] * gv[e]; }
+            for (int c = 0; c < SM_MAXC; ++c)
+                if (c < nc) {
+                    pv[c] = *reinterpret_cast<const float4 *>(P + off + c * 256);
+                    gv[c] = *reinterpret_cast<const float4 *>(dP + off + c * 256);
+                    dot += (pv[c].x * gv[c].x + pv[c].y * gv[c].y) + (pv[c].z * gv[c].z + pv[c].w * gv[c].w);
+                }
             dot = wsum(dot);
 #pragma unroll
-            for (int e = 0; e < SM_MAXE; ++e)
-                if (e < ne) {
-                    const float gg = pv[e] * (gv[e] - dot);
-                    acc[e] += gg;
-                    dP[off + lane + 64 * e] = gg / temper;
+            for (int c = 0; c < SM_MAXC; ++c)
+                if (c < nc) {
+                    float4 gg;
+                    gg.x = pv[c].x * (gv[c].x - dot); gg.y = pv[c].y * (gv[c].y - dot);
+                    gg.z = pv[c].z * (gv[c].z - dot); gg.w = pv[c].w * (gv[c].w - dot);
+                    acc[c].x += gg.x; acc[c].y += gg.y; acc[c].z += gg.z; acc[c].w += gg.w;
+                    *reinterpret_cast<float4 *>(dP + off + c * 256) =
+                        make_float4(gg.x / temper, gg.y / temper, gg.z / temper, gg.w / temper);
                 }
         }
         if (G) {
 #pragma unroll
-            for (int e = 0; e < SM_MAXE; ++e)
-                if (e < ne) G[hr * S + lane + 64 * e] = acc[e];
+            for (int c = 0; c < SM_MAXC; ++c)
+                if (c < nc) *reinterpret_cast<float4 *>(G + hr * S + c * 256 + lane * 4) = acc[c];
         }
     }
 }
@@ -133,7 +152,7 @@ extern "C" int lvt_attn_softmax_fwd(float *scores, int B, int H, int S, float te
                                     const float *dh, const float *dw, int bt, int bh, int bw, int masked, float fill,
                                     void *stream) {
     LVT_REQUIRE(scores && dt && dh && dw && B > 0 && H > 0, "attn_softmax_fwd: bad args");
-    LVT_REQUIRE(S == bt * bh * bw && S % 64 == 0 && S <= 64 * SM_MAXE, "attn_softmax_fwd: S=%d unsupported", S);
+    LVT_REQUIRE(S == bt * bh * bw && S % 256 == 0 && S <= 256 * SM_MAXC, "attn_softmax_fwd: S=%d unsupported", S);
     BiasGeom g = {bt, bh, bw};
     const long long rows = (long long)B * H * S;
     const int blocks = (int)(lvt_cdiv(rows, 4) < 16384 ? lvt_cdiv(rows, 4) : 16384);
@@ -147,7 +166,7 @@ extern "C" int lvt_attn_softmax_fwd(float *scores, int B, int H, int S, float te
 extern "C" int lvt_attn_softmax_bwd(const float *P, float *dP, int B, int H, int S, float temper, int bt, int bh,
                                     int bw, float *G, float *ddt, float *ddh, float *ddw, void *stream) {
     LVT_REQUIRE(P && dP && G && ddt && ddh && ddw && B > 0 && H > 0, "attn_softmax_bwd: bad args");
-    LVT_REQUIRE(S == bt * bh * bw && S % 64 == 0 && S <= 64 * SM_MAXE, "attn_softmax_bwd: S=%d unsupported", S);
+    LVT_REQUIRE(S == bt * bh * bw && S % 256 == 0 && S <= 256 * SM_MAXC, "attn_softmax_bwd: S=%d unsupported", S);
     hipStream_t s = (hipStream_t)stream;
     const long long rows = (long long)H * S;
     hipLaunchKernelGGL(lvt_attn_softmax_bwd_kernel, dim3((unsigned)lvt_cdiv(rows, 4)), dim3(256), 0, s, P, dP, B, H, S,

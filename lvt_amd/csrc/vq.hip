@@ -3,7 +3,7 @@
 //
 //   lvt_vq_nearest      idx[n][g][p] = argmin_k ( |e_k|^2 + |x|^2 - 2 x.e_k ), lowest k on ties
 //   lvt_vq_gather       out[row][g*D+d] = E[g][idx][d]            (z_q_st, z_q_bar, mode "emb")
-//   lvt_vq_ema_accumulate   stats[g][k][0..D-1] += x rows, stats[g][k][D] += 1
+//   lvt_vq_ema_accumulate   stats[g][k][0..D-1] = sum of x rows with idx k, stats[g][k][D] = count (LDS-private, no atomics)
 //   lvt_vq_ema_finalize     decay-lerp of running_size / running_sum, Laplace smoothing, new codebook
 //
 // vq_nearest on MI355X: one codebook group (512 x 64 fp32 = 128 KiB) is made LDS-resident
@@ -128,20 +128,66 @@ __global__ void lvt_vq_gather_kernel(const long long *__restrict__ idx, const fl
     }
 }
 
-// stats[g][k][0..D-1] += z[row][g*D..], stats[g][k][D] += 1   (fp32 HW atomics; counts stay exact)
-__global__ void lvt_vq_ema_accumulate_kernel(const long long *__restrict__ idx, const float *__restrict__ z,
-                                             long long rows, int ldz, int num, int KC, int P,
-                                             float *__restrict__ stats) {
-    const long long pairs = rows * num;
-    const int lane = threadIdx.x & 63;
-    for (long long pr = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; pr < pairs;
-         pr += ((long long)gridDim.x * blockDim.x) >> 6) {
-        const long long row = pr / num; const int g = pr % num;
-        const long long k = idx[((row / P) * num + g) * (long long)P + row % P];
-        float *dst = stats + ((long long)g * KC + k) * (VQ_D + 1);
-        atomicAdd(dst + lane, z[row * ldz + g * VQ_D + lane]);
-        if (lane == 0) atomicAdd(dst + VQ_D, 1.0f);
+// EMA statistics: stats[g][k][0..D-1] = sum of the rows assigned to code k, stats[g][k][D] = their count.
+// A workgroup owns one (group, row chunk) and keeps a PRIVATE 512 x 65 accumulator in LDS (133 KB of the
+// 160 KB).  Wave w only accumulates rows whose code is congruent to w mod 8, walking them in row order:
+// no two waves ever touch the same accumulator row, no atomics are needed, and the summation order is a
+// pure function of the data (bit-reproducible).  Chunk partials are then summed in chunk order.
+#define EMA_THREADS 512
+template <int KC>
+__global__ __launch_bounds__(EMA_THREADS) void lvt_vq_ema_partial_kernel(
+    const long long *__restrict__ idx, const float *__restrict__ z, long long rows, int ldz, int num, int P,
+    long long rows_per_chunk, int nchunks, float *__restrict__ partial) {
+    constexpr int LDS_LD = VQ_D + 1;
+    extern __shared__ __attribute__((aligned(16))) float acc[];      // [KC][65]
+    const int g = blockIdx.x / nchunks, c = blockIdx.x % nchunks;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < KC * LDS_LD; i += EMA_THREADS) acc[i] = 0.f;
+    __syncthreads();
+    const long long r0 = (long long)c * rows_per_chunk;
+    const long long r1 = min(rows, r0 + rows_per_chunk);
+    for (long long base = r0; base < r1; base += 64) {
+        const long long r = base + lane;
+        int code = -1;
+        if (r < r1) code = (int)idx[((r / P) * num + g) * (long long)P + r % P];
+        unsigned long long m = __ballot(code >= 0 && (code & 7) == wave);
+        while (m) {
+            // gather up to 4 pending rows first (independent 256-byte loads), then apply them in order
+            int js[4], cs[4]; float vs[4]; int cnt = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (m) {
+                    const int j = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    js[q] = j; cs[q] = __shfl(code, j);
+                    vs[q] = z[(base + j) * (long long)ldz + g * VQ_D + lane];
+                    cnt = q + 1;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < cnt) {
+                    acc[cs[q] * LDS_LD + lane] += vs[q];
+                    if (lane == 0) acc[cs[q] * LDS_LD + VQ_D] += 1.0f;
+                }
+            }
+        }
     }
+    __syncthreads();
+    float *dst = partial + ((long long)g * nchunks + c) * (KC * LDS_LD);
+    for (int i = tid; i < KC * LDS_LD; i += EMA_THREADS) dst[i] = acc[i];
+}
+
+// stats[g][i] = sum_c partial[g][c][i]  (chunk order)
+__global__ void lvt_vq_ema_reduce_kernel(const float *__restrict__ partial, int nchunks, long long per_group,
+                                         float *__restrict__ stats) {
+    const int g = blockIdx.y;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_group) return;
+    const float *p = partial + (long long)g * nchunks * per_group + i;
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += p[(long long)c * per_group];
+    stats[(long long)g * per_group + i] = s;
 }
 
 // one workgroup per codebook group (vq_embedding.py:48-59)
@@ -224,19 +270,48 @@ extern "C" int lvt_vq_gather(const long long *idx, const float *codebooks, long 
     return LVT_OK;
 }
 
+static void ema_chunks(long long rows, int num, long long *rows_per_chunk, int *nchunks) {
+    long long target = LVT_NUM_CU / (num > 0 ? num : 1);          // ~one workgroup per CU
+    if (target < 1) target = 1;
+    long long rpc = lvt_cdiv(rows, target);
+    rpc = lvt_cdiv(rpc, 64) * 64;
+    if (rpc < 256) rpc = 256;
+    *rows_per_chunk = rpc;
+    *nchunks = (int)lvt_cdiv(rows, rpc);
+}
+extern "C" size_t lvt_vq_ema_workspace_bytes(long long rows, int num, int D, int KC) {
+    long long rpc; int nch;
+    ema_chunks(rows, num, &rpc, &nch);
+    return (size_t)num * nch * KC * (D + 1) * sizeof(float);
+}
 extern "C" int lvt_vq_ema_accumulate(const long long *idx, const float *z, long long rows, int ldz, int num, int D,
-                                     int KC, int P, float *stats, void *stream) {
+                                     int KC, int P, float *stats, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
     LVT_REQUIRE(idx && z && stats && D == VQ_D && rows > 0 && rows % P == 0, "vq_ema_accumulate: bad args");
-    hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(stats, 0, (size_t)num * KC * (D + 1) * sizeof(float), s) != hipSuccess) {
-        lvt_set_error("vq_ema_accumulate: memset failed");
-        return LVT_ELAUNCH;
+    LVT_REQUIRE(KC == 512 || KC == 256 || KC == 128, "vq_ema_accumulate: codebook size %d not instantiated", KC);
+    long long rpc; int nch;
+    ema_chunks(rows, num, &rpc, &nch);
+    if (!workspace || workspace_bytes < lvt_vq_ema_workspace_bytes(rows, num, D, KC)) {
+        lvt_set_error("vq_ema_accumulate: workspace too small");
+        return LVT_EWORKSPACE;
     }
-    const long long pairs = rows * num;
-    const int blocks = (int)(lvt_cdiv(pairs, 4) < 8192 ? lvt_cdiv(pairs, 4) : 8192);
-    hipLaunchKernelGGL(lvt_vq_ema_accumulate_kernel, dim3(blocks), dim3(256), 0, s, idx, z, rows, ldz, num, KC, P,
-                       stats);
-    LVT_CHECK_LAUNCH("lvt_vq_ema_accumulate_kernel");
+    hipStream_t s = (hipStream_t)stream;
+    const int smem = KC * (VQ_D + 1) * (int)sizeof(float);
+    hipError_t e;
+#define EMA_LAUNCH(KCV)                                                                                          \
+    e = hipFuncSetAttribute((const void *)lvt_vq_ema_partial_kernel<KCV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            smem);                                                                               \
+    if (e != hipSuccess) { lvt_set_error("vq_ema_accumulate: cannot get %d B LDS: %s", smem, hipGetErrorString(e)); \
+        return LVT_ELAUNCH; }                                                                                    \
+    hipLaunchKernelGGL(lvt_vq_ema_partial_kernel<KCV>, dim3(num * nch), dim3(EMA_THREADS), smem, s, idx, z, rows, ldz, \
+                       num, P, rpc, nch, (float *)workspace);
+    if (KC == 512) { EMA_LAUNCH(512) } else if (KC == 256) { EMA_LAUNCH(256) } else { EMA_LAUNCH(128) }
+#undef EMA_LAUNCH
+    LVT_CHECK_LAUNCH("lvt_vq_ema_partial_kernel");
+    const long long per_group = (long long)KC * (D + 1);
+    hipLaunchKernelGGL(lvt_vq_ema_reduce_kernel, dim3((unsigned)lvt_cdiv(per_group, 256), num), dim3(256), 0, s,
+                       (const float *)workspace, nch, per_group, stats);
+    LVT_CHECK_LAUNCH("lvt_vq_ema_reduce_kernel");
     return LVT_OK;
 }
 

@@ -34,6 +34,11 @@ class GemmDesc(C.Structure):
     ]
 
 
+class OptEntry(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("s0", C.c_void_p), ("s1", C.c_void_p),
+                ("n", C.c_longlong), ("lr", C.c_float), ("wd", C.c_float)]
+
+
 class ConvGeom(C.Structure):
     _fields_ = [(n, C.c_int) for n in
                 ("N", "Ti", "Hi", "Wi", "Ci", "To", "Ho", "Wo", "Co", "Kt", "Kh", "Kw",
@@ -64,7 +69,8 @@ def _declare(lib):
         "lvt_colsum": (ci, [vp, cll, ci, cll, vp, vp, sz, vp]),
         "lvt_vq_nearest": (ci, [vp, cll, ci, ci, ci, ci, vp, vp, ci, vp]),
         "lvt_vq_gather": (ci, [vp, vp, cll, ci, ci, ci, ci, vp, ci, vp]),
-        "lvt_vq_ema_accumulate": (ci, [vp, vp, cll, ci, ci, ci, ci, ci, vp, vp]),
+        "lvt_vq_ema_workspace_bytes": (sz, [cll, ci, ci, ci]),
+        "lvt_vq_ema_accumulate": (ci, [vp, vp, cll, ci, ci, ci, ci, ci, vp, vp, sz, vp]),
         "lvt_vq_ema_finalize": (ci, [vp, ci, ci, ci, cf, cf, vp, vp, vp, vp]),
         "lvt_to_channels_last": (ci, [vp, ci, ci, cll, ci, ci, vp, vp, vp, vp]),
         "lvt_to_channels_first": (ci, [vp, ci, ci, cll, ci, ci, vp, vp, cf, cf, vp, vp]),
@@ -86,6 +92,8 @@ def _declare(lib):
         "lvt_xent_workspace_bytes": (sz, []),
         "lvt_xent_fwd": (ci, [vp, vp, cll, cll, ci, cll, ci, cll, cf, vp, vp, vp, vp, vp, sz, vp]),
         "lvt_xent_bwd": (ci, [vp, vp, cll, cll, ci, cll, ci, cll, vp, vp, vp, cf, vp, vp]),
+        "lvt_adam_step": (ci, [P(OptEntry), ci, cf, cf, cf, ci, vp]),
+        "lvt_rmsprop_step": (ci, [P(OptEntry), ci, cf, cf, cf, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)

@@ -33,8 +33,11 @@ def ema_accumulate(idx, z, K):
     rows, ldz = z.shape
     D = ldz // num
     stats = torch.empty(num, K, D + 1, dtype=torch.float32, device=z.device)
-    L.check(L.lib().lvt_vq_ema_accumulate(L.ptr(idx), L.ptr(z), rows, ldz, num, D, K, P, L.ptr(stats),
-                                          L.stream_ptr()), "lvt_vq_ema_accumulate")
+    lib = L.lib()
+    nws = lib.lvt_vq_ema_workspace_bytes(rows, num, D, K)
+    ws = L.workspace(nws, z.device, "ema")
+    L.check(lib.lvt_vq_ema_accumulate(L.ptr(idx), L.ptr(z), rows, ldz, num, D, K, P, L.ptr(stats), L.ptr(ws), nws,
+                                      L.stream_ptr()), "lvt_vq_ema_accumulate")
     return stats
 
 

@@ -1,12 +1,14 @@
 """Optimizer / LR-scheduler factories with the reference's semantics
 (vidgen/solver/build.py:12-105): ONE param group per parameter, weight decay chosen by module type /
 parameter name, Adam(beta1, beta2 from SOLVER.ADAM.*) or RMSprop(alpha, momentum), and the
-Identity / WarmupMultiStepLR / WarmupCosineLR schedules.  Optimizer math stays on torch.optim."""
+Identity / WarmupMultiStepLR / WarmupCosineLR schedules.  On the GPU the update is a fused multi-tensor HIP launch (solver/fused.py) with torch.optim's exact rule."""
 import math
 from bisect import bisect_right
 
 import torch
 from torch.optim.lr_scheduler import LambdaLR
+
+from .fused import FusedAdam, FusedRMSprop
 
 _NORM_TYPES = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d, torch.nn.SyncBatchNorm,
                torch.nn.GroupNorm, torch.nn.InstanceNorm1d, torch.nn.InstanceNorm2d, torch.nn.InstanceNorm3d,
@@ -32,12 +34,14 @@ def build_optimizer(model, cfg, suffix=""):
                             s.WEIGHT_DECAY["BIAS" + suffix])
     models = model if isinstance(model, list) else [model]
     params = [g for m in models for g in _param_groups(m, lr, wd, wd_norm, wd_bias)]
+    on_gpu = any(p.is_cuda for g in params for p in g["params"])
     if s.OPTIMIZER_NAME == "adam":
-        return torch.optim.Adam(params, lr, betas=(s.ADAM["BETA1" + suffix], s.ADAM["BETA2" + suffix]),
-                                weight_decay=wd)
+        cls = FusedAdam if on_gpu else torch.optim.Adam          # same rule; the fused one needs device tensors
+        return cls(params, lr, betas=(s.ADAM["BETA1" + suffix], s.ADAM["BETA2" + suffix]), weight_decay=wd)
     if s.OPTIMIZER_NAME == "rmsprop":
-        return torch.optim.RMSprop(params, lr, alpha=s.RMSPROP["ALPHA" + suffix], weight_decay=wd,
-                                   momentum=s.RMSPROP["MOMENTUM" + suffix])
+        cls = FusedRMSprop if on_gpu else torch.optim.RMSprop
+        return cls(params, lr, alpha=s.RMSPROP["ALPHA" + suffix], weight_decay=wd,
+                   momentum=s.RMSPROP["MOMENTUM" + suffix])
     raise ValueError("Unknown optimizer: {}".format(s.OPTIMIZER_NAME))
 
 
