@@ -22,7 +22,13 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define BK 32
+#ifndef LVT_BK
+#define LVT_BK 32
+#endif
+#define BK LVT_BK
+#ifndef LVT_MINWAVES
+#define LVT_MINWAVES 1
+#endif
 #define NTHREADS 256
 
 enum { A_KPLAIN = 0, A_MPLAIN = 1, A_CONV_K = 2, A_CONVT_K = 3, A_CONV_M = 4, A_ONEHOT_M = 5 };
@@ -56,15 +62,18 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 template <int MODE, int BM> struct ALoader;
 
 // ---- k-contiguous family: rows r0 + 32*i (i < BM/32), k quad kq = tid & 7 ------------------------
+#define QPR (BK / 4)                 // float4 quads per tile row
+#define RPP (NTHREADS / QPR)         // tile rows covered per pass
+#define KPAD (BK == 32 ? 1 : 2)      // row pad that keeps the transposing stores conflict-free
 template <int MODE, int BM> struct AKLoaderBase {
-    static constexpr int ITERS = BM / 32;
-    static constexpr int LD = BM + 1;
+    static constexpr int ITERS = BM / RPP;
+    static constexpr int LD = BM + KPAD;
     float4 v[ITERS];
     int r0, kq;
     __device__ __forceinline__ void store(float *lds) const {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
-            const int row = r0 + 32 * i;
+            const int row = r0 + RPP * i;
             lds[(kq * 4 + 0) * LD + row] = v[i].x;
             lds[(kq * 4 + 1) * LD + row] = v[i].y;
             lds[(kq * 4 + 2) * LD + row] = v[i].z;
@@ -79,11 +88,11 @@ template <int BM> struct ALoader<A_KPLAIN, BM> : AKLoaderBase<A_KPLAIN, BM> {
     bool rowok[Base::ITERS];
     int kb; long long skb;
     __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int) {
-        this->r0 = tid >> 3; this->kq = tid & 7;
+        this->r0 = tid / QPR; this->kq = tid % QPR;
         kb = p.a_kb; skb = p.a_skb;
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i) {
-            const int m = m0 + this->r0 + 32 * i;
+            const int m = m0 + this->r0 + RPP * i;
             rowok[i] = m < p.M;
             rowp[i] = A + (long long)m * p.lda;
         }
@@ -105,11 +114,11 @@ template <int BM> struct ALoader<A_CONV_K, BM> : AKLoaderBase<A_CONV_K, BM> {
     int ti0[Base::ITERS], hi0[Base::ITERS], wi0[Base::ITERS];
     const float *x; lvt_conv_geom g;
     __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int) {
-        this->r0 = tid >> 3; this->kq = tid & 7;
+        this->r0 = tid / QPR; this->kq = tid % QPR;
         x = A; g = p.g;
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i) {
-            int m = m0 + this->r0 + 32 * i;
+            int m = m0 + this->r0 + RPP * i;
             if (m < p.M) {
                 const int wo = m % g.Wo; m /= g.Wo;
                 const int ho = m % g.Ho; m /= g.Ho;
@@ -146,7 +155,7 @@ template <int BM> struct ALoader<A_CONVT_K, BM> : AKLoaderBase<A_CONVT_K, BM> {
     int ot0[Base::ITERS], oh0[Base::ITERS], ow0[Base::ITERS];
     const float *dy; lvt_conv_geom g; int jH, jW;
     __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int cls) {
-        this->r0 = tid >> 3; this->kq = tid & 7;
+        this->r0 = tid / QPR; this->kq = tid % QPR;
         dy = A; g = p.g; jH = p.jH; jW = p.jW;
         const int fw = cls % g.sw, fh = (cls / g.sw) % g.sh, ft = cls / (g.sw * g.sh);
         // r = (phi - p) mod s ; c = (r + p - phi) / s
@@ -155,7 +164,7 @@ template <int BM> struct ALoader<A_CONVT_K, BM> : AKLoaderBase<A_CONVT_K, BM> {
         const int rw = ((fw - g.pw) % g.sw + g.sw) % g.sw, cw = (rw + g.pw - fw) / g.sw;
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i) {
-            int m = m0 + this->r0 + 32 * i;
+            int m = m0 + this->r0 + RPP * i;
             if (m < p.M) {
                 const int qw = m % p.Wq; m /= p.Wq;
                 const int qh = m % p.Hq; m /= p.Hq;
@@ -281,14 +290,15 @@ template <int BM> struct ALoader<A_ONEHOT_M, BM> : AMLoaderBase<BM> {
 template <int MODE, int BN> struct BLoader;
 
 template <int BN> struct BKLoaderBase {
-    static constexpr int ITERS = (BN >= 32) ? BN / 32 : 1;
-    static constexpr int LD = BN + 1;
+    static constexpr int ITERS = (BN >= RPP) ? BN / RPP : 1;
+    static constexpr int LD = BN + KPAD;
     float4 v[ITERS];
     int r0, kq;
     __device__ __forceinline__ void store(float *lds) const {
+        if (r0 >= BN) return;
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
-            const int row = r0 + 32 * i;
+            const int row = r0 + RPP * i;
             lds[(kq * 4 + 0) * LD + row] = v[i].x;
             lds[(kq * 4 + 1) * LD + row] = v[i].y;
             lds[(kq * 4 + 2) * LD + row] = v[i].z;
@@ -301,12 +311,12 @@ template <int BN> struct BLoader<B_KPLAIN, BN> : BKLoaderBase<BN> {
     using Base = BKLoaderBase<BN>;
     const float *rowp[Base::ITERS]; bool rowok[Base::ITERS]; int kb; long long skb;
     __device__ __forceinline__ void init(const KParams &p, int tid, int n0, const float *B, int) {
-        this->r0 = tid >> 3; this->kq = tid & 7;
+        this->r0 = tid / QPR; this->kq = tid % QPR;
         kb = p.b_kb; skb = p.b_skb;
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i) {
-            const int n = n0 + this->r0 + 32 * i;
-            rowok[i] = n < p.N;
+            const int n = n0 + this->r0 + RPP * i;
+            rowok[i] = n < p.N && this->r0 < BN;
             rowp[i] = B + (long long)n * p.ldb;
         }
     }
@@ -326,13 +336,13 @@ template <int BN> struct BLoader<B_CONVT_W, BN> : BKLoaderBase<BN> {
     const float *wp; lvt_conv_geom g; int jH, jW, ft, fh, fw;
     int nrow[Base::ITERS]; bool rowok[Base::ITERS];
     __device__ __forceinline__ void init(const KParams &p, int tid, int n0, const float *B, int cls) {
-        this->r0 = tid >> 3; this->kq = tid & 7;
+        this->r0 = tid / QPR; this->kq = tid % QPR;
         wp = B; g = p.g; jH = p.jH; jW = p.jW;
         fw = cls % g.sw; fh = (cls / g.sw) % g.sh; ft = cls / (g.sw * g.sh);
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i) {
-            nrow[i] = n0 + this->r0 + 32 * i;
-            rowok[i] = nrow[i] < p.N;
+            nrow[i] = n0 + this->r0 + RPP * i;
+            rowok[i] = nrow[i] < p.N && this->r0 < BN;
         }
     }
     __device__ __forceinline__ void fetch(int k0, int kend) {
@@ -382,7 +392,7 @@ template <int BN> struct BLoader<B_NPLAIN, BN> {
 // the kernel
 // ------------------------------------------------------------------------------------------------
 template <int AMODE, int BMODE, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(NTHREADS) void lvt_gemm_kernel(const KParams p) {
+__global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const KParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     using AL = ALoader<AMODE, BM>;
     using BL = BLoader<BMODE, BN>;
@@ -445,18 +455,31 @@ __global__ __launch_bounds__(NTHREADS) void lvt_gemm_kernel(const KParams p) {
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool has_next = k0 + BK < kend;
         if (has_next) { al.fetch(k0 + BK, kend); bl.fetch(k0 + BK, kend); }
+        // operand fragments are double-buffered in registers: the ds_reads of step kk+2 are in flight
+        // while the MFMAs of step kk issue, so the LDS latency is not exposed once per step
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = Ard[i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = Brd[j * 32];
+        __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);       // step-0 operand reads
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
+            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+            if (kk + 2 < BK) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Ard[kk * LDA + i * 32];
+                for (int i = 0; i < TM; ++i) a[nxt][i] = Ard[(kk + 2) * LDA + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Brd[kk * LDB + j * 32];
+                for (int j = 0; j < TN; ++j) b[nxt][j] = Brd[(kk + 2) * LDB + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            // pin the interleave: next step's operand reads are issued BEFORE this step's MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);   // DS reads
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                       // MFMAs
         }
         __syncthreads();
         if (has_next) { al.store(As); bl.store(Bs); }

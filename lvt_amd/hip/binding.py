@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "liblvt_hip.so")
+_LIB_PATH = os.environ.get("LVT_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "liblvt_hip.so")
 
 EPI_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_TANH, EPI_MASK, EPI_ACCUM = 1, 2, 4, 8, 16, 32
 
