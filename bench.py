@@ -186,12 +186,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     from lvt_amd.hip import binding as L
     cfg, model = build_vqvae(device, 29871897 + rank)

@@ -1,0 +1,93 @@
+"""Model-level data parallelism on the GPU box: two ranks share cuda:0 and talk over gloo (a single-GPU box
+cannot host two RCCL ranks), exercising exactly the code the 8-GPU run uses -- wrap_parallel (parameter +
+codebook broadcast), bucketed gradient averaging on a side stream, the packed EMA-statistics all-reduce --
+and comparing with one process that sees the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import seeded
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _vq_worker(rank, world, port, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from util_models import vqvae_seeded
+    from lvt_amd.utils.events import EventStorage
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model, _, _, _ = vqvae_seeded(50 + rank, scale=0.05 * (1 + rank))      # ranks start different
+        model.train()
+        model.wrap_parallel(device_ids=[0], broadcast_buffers=False)
+        x = seeded.seeded_input("dp", (8, 3, 64, 64), 9)[4 * rank:4 * rank + 4]
+        with EventStorage(0):
+            losses = model([{"image": x[i].numpy()} for i in range(4)], mode="supervised")
+        sum(losses.values()).backward()
+        model.finish_gradient_sync()
+        torch.cuda.synchronize()
+        ret[rank] = {
+            "w0": model.encoder.layers[0].weight.detach().cpu(),
+            "g_enc": model.encoder.layers[4].weight.grad.cpu(), "g_dec": model.generator.layers[6].weight.grad.cpu(),
+            "g_b": model.encoder.layers[0].bias.grad.cpu(),
+            "cb": {k: v.cpu() for k, v in model.codebook.state_dict().items()},
+            "loss": {k: float(v.detach()) for k, v in losses.items()},
+        }
+    finally:
+        dist.destroy_process_group()
+
+
+def test_vqvae_two_ranks_equal_one_big_batch():
+    from util_models import vqvae_seeded
+    from lvt_amd.utils.events import EventStorage
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_vq_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    a, b = ret[0], ret[1]
+    # replicas are identical after the step: same weights, same averaged grads, same codebook
+    assert torch.equal(a["w0"], b["w0"])
+    for k in ("g_enc", "g_dec", "g_b"):
+        assert torch.equal(a[k], b[k]), k
+    for k in a["cb"]:
+        assert torch.equal(a["cb"][k], b["cb"][k]), k
+    # and equal to a single process on the 8-frame batch starting from rank 0's weights
+    model, _, _, _ = vqvae_seeded(50, scale=0.05)
+    model.train()
+    x = seeded.seeded_input("dp", (8, 3, 64, 64), 9)
+    with EventStorage(0):
+        losses = model([{"image": x[i].numpy()} for i in range(8)], mode="supervised")
+    sum(losses.values()).backward()
+    assert rel_err(a["g_enc"], model.encoder.layers[4].weight.grad) < 1e-4
+    assert rel_err(a["g_dec"], model.generator.layers[6].weight.grad) < 1e-4
+    assert rel_err(a["g_b"], model.encoder.layers[0].bias.grad) < 1e-4
+    one = model.codebook.state_dict()
+    for k in one:
+        assert rel_err(a["cb"][k], one[k]) < 1e-5, k
+    mean_loss = 0.5 * (a["loss"]["loss_reconstruction"] + b["loss"]["loss_reconstruction"])
+    assert abs(mean_loss - float(losses["loss_reconstruction"].detach())) < 1e-5 * mean_loss
