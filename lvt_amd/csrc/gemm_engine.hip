@@ -639,8 +639,10 @@ static int launch_tile(const KParams &p, int zcount, hipStream_t s) {
 }
 
 static int choose_splits(long long tiles, int K, int min_k) {
-    // enough workgroups to cover the chip ~3x, but never less than min_k of reduction per split
-    int s = (int)lvt_cdiv(3 * LVT_NUM_CU, tiles);
+    // Two workgroups are resident per CU (176 registers/lane), i.e. 512 slots on the chip: aim for the
+    // largest split count whose grid still fits in two full waves of workgroups (tiles * splits <= 1024),
+    // so that no partially filled tail wave is paid; never less than min_k of reduction per split.
+    int s = (int)((4 * LVT_NUM_CU) / (tiles > 0 ? tiles : 1));
     const int maxs = K / min_k > 0 ? K / min_k : 1;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;

@@ -81,7 +81,8 @@ class MultiHeadAttention(nn.Module):
 
 
 def _splits(tiles, k):
-    s = max(1, -(-768 // max(1, tiles)))
+    """split-K factor: fill two full waves of workgroups (2 resident per CU -> 512 slots), >= 512 rows each."""
+    s = max(1, 1024 // max(1, tiles))
     return max(1, min(s, k // 512 if k >= 1024 else 1))
 
 

@@ -1,0 +1,145 @@
+#!/usr/bin/env python
+"""Training / evaluation entry point with the reference's command line (tools/train_net.py:94-104,
+engine/defaults.py:37-69):
+
+    python tools/train_net.py --config-file configs/vqvae/PR-DVQVAE2.yaml --num-gpus 8 [--eval-only] [--resume] KEY VAL ...
+
+Data: `--data-dir` points at a latent-code tree in the reference's on-disk format (for VideoTransformerModel) or
+at a `.npy` of frames/clips (N,[T,]3,H,W) in [0,1] (for VQVAEModel); `--synthetic` uses random data of the
+configured shape.  Dataset catalogs / image decoding of the reference are I/O and out of scope.
+"""
+import argparse
+import logging
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+from lvt_amd.config import get_cfg  # noqa: E402
+from lvt_amd.data import DatasetMapper  # noqa: E402
+from lvt_amd.data.latents import list_latent_videos, load_video_codes  # noqa: E402
+from lvt_amd.data.samplers import TrainingSampler  # noqa: E402
+from lvt_amd.engine.trainer import Trainer  # noqa: E402
+from lvt_amd.modeling import build_model  # noqa: E402
+from lvt_amd.utils import comm  # noqa: E402
+
+
+def default_argument_parser():
+    p = argparse.ArgumentParser(description="lvt_amd training")
+    p.add_argument("--config-file", default="", metavar="FILE")
+    p.add_argument("--resume", action="store_true")
+    p.add_argument("--eval-only", action="store_true")
+    p.add_argument("--num-gpus", type=int, default=1)
+    p.add_argument("--num-machines", type=int, default=1)
+    p.add_argument("--machine-rank", type=int, default=0)
+    p.add_argument("--dist-url", default="tcp://127.0.0.1:{}".format(2 ** 15 + 2 ** 14 + hash(os.getuid()) % 2 ** 14))
+    p.add_argument("--data-dir", default="")
+    p.add_argument("--synthetic", action="store_true")
+    p.add_argument("--max-iter", type=int, default=None)
+    p.add_argument("opts", default=None, nargs=argparse.REMAINDER)
+    return p
+
+
+def setup(args):
+    cfg = get_cfg()
+    cfg.merge_from_file(args.config_file)
+    cfg.merge_from_list(args.opts)
+    if cfg.MODEL.DEVICE == "cuda":
+        cfg.MODEL.DEVICE = "cuda:%d" % comm.get_local_rank()
+    cfg.freeze()
+    os.makedirs(cfg.OUTPUT_DIR, exist_ok=True)
+    if comm.is_main_process():
+        with open(os.path.join(cfg.OUTPUT_DIR, "config.yaml"), "w") as f:
+            f.write(cfg.dump())
+    seed = cfg.SEED if cfg.SEED >= 0 else 0
+    torch.manual_seed(seed + comm.get_rank())            # per-rank seed, defaults.py:113
+    np.random.seed(seed + comm.get_rank())
+    return cfg
+
+
+def data_iterator(cfg, args):
+    """Infinite iterator of list[dict] batches, IMS_PER_BATCH / world per rank (data/build.py:62-74)."""
+    world = comm.get_world_size()
+    assert cfg.SOLVER.IMS_PER_BATCH % world == 0
+    per_rank = cfg.SOLVER.IMS_PER_BATCH // world
+    is_vt = cfg.MODEL.META_ARCHITECTURE == "VideoTransformerModel"
+    seed = cfg.SEED if cfg.SEED >= 0 else 0
+    if is_vt:
+        mapper = DatasetMapper(cfg, True)
+        if args.synthetic or not args.data_dir:
+            v = cfg.MODEL.AUTOREGRESSIVE.VT
+            rng = np.random.default_rng(seed)
+            videos = [rng.integers(0, v.NV, (16, v.NC, 16, 16), dtype=np.int64) for _ in range(256)]
+            load = lambda i: videos[i]                     # noqa: E731
+            n = len(videos)
+        else:
+            vids = list_latent_videos(args.data_dir)
+            load = lambda i: load_video_codes(vids[i][0], vids[i][1])      # noqa: E731
+            n = len(vids)
+        it = iter(TrainingSampler(n, seed=seed))
+        while True:
+            batch = []
+            while len(batch) < per_rank:
+                d = mapper({"image_sequence": load(next(it))})
+                if d is not None:
+                    batch.append(d)
+            yield batch
+    else:
+        if args.synthetic or not args.data_dir:
+            frames = np.random.default_rng(seed).random((1024, 3, 64, 64), dtype=np.float32)
+        else:
+            frames = np.load(args.data_dir, mmap_mode="r")
+        key = "image_sequence" if frames.ndim == 5 else "image"
+        it = iter(TrainingSampler(len(frames), seed=seed))
+        while True:
+            yield [{key: np.asarray(frames[next(it)], dtype=np.float32)} for _ in range(per_rank)]
+
+
+def main(args):
+    logging.basicConfig(level=logging.INFO if comm.is_main_process() else logging.WARNING,
+                        format="[%(asctime)s] %(name)s %(levelname)s: %(message)s")
+    cfg = setup(args)
+    model = build_model(cfg)
+    if args.eval_only:
+        _, checkpointers = model.configure_optimizers_and_checkpointers()
+        for item in checkpointers:
+            item["checkpointer"].resume_or_load(item["pretrained"], resume=False)
+        model.eval()
+        batch = next(data_iterator(cfg, args))
+        if cfg.MODEL.META_ARCHITECTURE == "VideoTransformerModel":
+            raise SystemExit("--eval-only for the transformer needs the reference's evaluators (out of scope); "
+                             "use VideoTransformerModel.calculate_logits_for_entire_video / sample_videos directly")
+        with torch.no_grad():
+            out = model(batch, mode="inference")
+        logging.getLogger("lvt_amd").info("inference OK: %d outputs, latent %s", len(out), tuple(out[0]["latent"].shape))
+        return out
+    trainer = Trainer(cfg, model, data_iterator(cfg, args))
+    trainer.resume_or_load(resume=args.resume)
+    return trainer.train(args.max_iter)
+
+
+def _worker(local_rank, args):
+    os.environ["LOCAL_RANK"] = str(local_rank)
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", init_method=args.dist_url, world_size=args.num_gpus * args.num_machines,
+                            rank=args.machine_rank * args.num_gpus + local_rank,
+                            device_id=torch.device("cuda:%d" % local_rank))
+    comm.synchronize()
+    try:
+        main(args)
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    args = default_argument_parser().parse_args()
+    print("Command Line Args:", args)
+    if args.num_gpus * args.num_machines > 1:
+        mp.spawn(_worker, nprocs=args.num_gpus, args=(args,))          # one process per GPU (launch.py:25-64)
+    else:
+        main(args)
