@@ -406,9 +406,18 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, half = lane >> 5;
 
-    // blockIdx.x -> (m tile, n tile): n fastest so that consecutive workgroups share the A panel
+    // blockIdx.x -> (m tile, n tile).  Workgroup b is dispatched to XCD b % 8 and every XCD has a private
+    // L2, so the linear id is first remapped to give each XCD one CONTIGUOUS run of tiles (bijective for
+    // any grid size): the n tiles that share an A panel, and the neighbouring m tiles that share im2col
+    // halo rows / the same image, then hit the same L2 instead of each XCD fetching its own copy.
     const int ntn = (p.N + BN - 1) / BN;
-    const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+    int wg = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = wg & 7, slot = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tile_n = wg % ntn, tile_m = wg / ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     int z = blockIdx.y;                 // batch (or conv phase class)
     const int split = blockIdx.z;

@@ -374,3 +374,68 @@ extern "C" int lvt_xent_bwd(const float *logits, const long long *target, long l
     LVT_CHECK_LAUNCH("lvt_xent_bwd_kernel");
     return LVT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// single-query attention against a K/V cache (incremental sampling):
+//   o[b][h][:] = softmax_j<=i( q.K_j / temper + bias(i, j) ) V_j     for the one query position i.
+// One wave per (b, h).  q (B, H*DA), caches (B, S, H*DA) token-major, o (B, H*DA).  DA == 128.
+// Same arithmetic as row i of the full causal layer (the masked columns j > i carry exp(-1e4 - m) == 0).
+// ------------------------------------------------------------------------------------------------
+#define DEC_DA 128
+__global__ __launch_bounds__(64) void lvt_attn_decode_kernel(const float *__restrict__ q, const float *__restrict__ Kc,
+                                                             const float *__restrict__ Vc, int H, int S, int qi,
+                                                             float temper, const float *__restrict__ dt,
+                                                             const float *__restrict__ dh, const float *__restrict__ dw,
+                                                             BiasGeom g, float *__restrict__ o) {
+    __shared__ float qs[DEC_DA];
+    __shared__ float ps[1024];
+    const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+    const int hd = H * DEC_DA;
+    const float *qp = q + (long long)b * hd + h * DEC_DA;
+    qs[lane] = qp[lane]; qs[lane + 64] = qp[lane + 64];
+    __syncthreads();
+    const int nk = qi + 1;
+    const int wi = qi % g.bw, hi = (qi / g.bw) % g.bh, ti = qi / (g.bw * g.bh);
+    const float *bt = dt + h * (2 * g.bt - 1), *bhp = dh + h * (2 * g.bh - 1), *bwp = dw + h * (2 * g.bw - 1);
+    float m = -3.4e38f;
+    for (int j = lane; j < nk; j += 64) {
+        const float4 *kp = reinterpret_cast<const float4 *>(Kc + ((long long)b * S + j) * hd + h * DEC_DA);
+        float s = 0.f;
+#pragma unroll 8
+        for (int d4 = 0; d4 < DEC_DA / 4; ++d4) {
+            const float4 kv = kp[d4];
+            s = fmaf(qs[d4 * 4 + 0], kv.x, s); s = fmaf(qs[d4 * 4 + 1], kv.y, s);
+            s = fmaf(qs[d4 * 4 + 2], kv.z, s); s = fmaf(qs[d4 * 4 + 3], kv.w, s);
+        }
+        const int wj = j % g.bw, hj = (j / g.bw) % g.bh, tj = j / (g.bw * g.bh);
+        const float x = s / temper + ((bt[ti - tj + g.bt - 1] + bhp[hi - hj + g.bh - 1]) + bwp[wi - wj + g.bw - 1]);
+        ps[j] = x;
+        m = fmaxf(m, x);
+    }
+    m = wmax(m);
+    float sum = 0.f;
+    for (int j = lane; j < nk; j += 64) { const float e = expf(ps[j] - m); ps[j] = e; sum += e; }
+    sum = wsum(sum);
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f;
+    const float *vp = Vc + (long long)b * S * hd + h * DEC_DA;
+    for (int j = 0; j < nk; ++j) {
+        const float p = ps[j];
+        a0 = fmaf(p, vp[(long long)j * hd + lane], a0);
+        a1 = fmaf(p, vp[(long long)j * hd + lane + 64], a1);
+    }
+    float *op = o + (long long)b * hd + h * DEC_DA;
+    op[lane] = a0 / sum; op[lane + 64] = a1 / sum;
+}
+
+extern "C" int lvt_attn_decode(const float *q, const float *Kc, const float *Vc, int B, int H, int S, int da, int qi,
+                               float temper, const float *dt, const float *dh, const float *dw, int bt, int bh, int bw,
+                               float *o, void *stream) {
+    LVT_REQUIRE(q && Kc && Vc && dt && dh && dw && o && B > 0 && H > 0, "attn_decode: bad args");
+    LVT_REQUIRE(da == DEC_DA && S == bt * bh * bw && S <= 1024 && qi >= 0 && qi < S, "attn_decode: unsupported shape");
+    BiasGeom g = {bt, bh, bw};
+    hipLaunchKernelGGL(lvt_attn_decode_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, q, Kc, Vc, H, S, qi,
+                       temper, dt, dh, dw, g, o);
+    LVT_CHECK_LAUNCH("lvt_attn_decode_kernel");
+    return LVT_OK;
+}

@@ -292,8 +292,13 @@ class ChannelPredictor(nn.Module):
         probabilities against the reference since torch.multinomial streams are device specific)."""
         d = yl_tok.shape[-1]
         rows = yl_tok.view(b, P, d)[:, pos].contiguous()                      # (b, d)
+        return self.sample_from_rows(rows, temp, forced_codes, return_probs)
+
+    def sample_from_rows(self, rows, temp=1.0, forced_codes=None, return_probs=False):
+        """rows (b, d): decoder hidden state of ONE position per sample -> codes (b, nc)."""
+        b, d = rows.shape
         y, _, _ = ew.layernorm_fwd(rows, self.layer_norm.weight, self.layer_norm.bias, save_stats=False)
-        codes = torch.zeros(b, self.nc, 1, dtype=torch.int64, device=yl_tok.device)
+        codes = torch.zeros(b, self.nc, 1, dtype=torch.int64, device=rows.device)
         probs = []
         for k in range(self.nc):
             uw, pw = self.U[k].weight, self.P[k].weight

@@ -142,9 +142,14 @@ class VideoTransformerModel(nn.Module):
 
     # ---- sampling (vt.py:82-136, 210-228) -----------------------------------------------------------------
     @torch.no_grad()
-    def sample_video(self, video, temp=1.0, n_prime=1, class_idx=None):
+    def sample_video(self, video, temp=1.0, n_prime=1, class_idx=None, incremental=True):
         """video (B, nc, T, H, W) int64 with the first n_prime frames given; returns the completed grid.
-        Same schedule as the reference (encoder once per slice, full decoder pass per generated pixel)."""
+
+        incremental=True (default): encoder once per slice, then ONE single-token decoder step per position
+        against K/V caches (modeling/autoregressive/incremental.py).  incremental=False reproduces the
+        reference's schedule (full decoder pass per generated pixel, vt.py:121-131); both draw from the same
+        per-pixel distributions."""
+        from ..autoregressive.incremental import IncrementalDecoder
         self._require_gpu()
         v = self._vt
         video = video.to(self.device).clone()
@@ -155,6 +160,7 @@ class VideoTransformerModel(nn.Module):
         prime = torch.zeros(T, H, W, dtype=torch.bool)
         if n_prime > 0:
             prime[:n_prime] = True
+        pred = self.model.ch_predictor
         for si, (a, b_, c) in enumerate(idx2abc):
             sl, ctx = slice_and_context(video, a, b_, c, v.STRIDE, v.KERNEL, v.PAD_VALUE)
             prime_sl = prime[a::st, b_::sh, c::sw]
@@ -162,14 +168,20 @@ class VideoTransformerModel(nn.Module):
                 continue
             sidx = torch.full((B,), si, dtype=torch.long, device=video.device)
             zl = self.model.encoder.forward_tokens(ctx.contiguous(), sidx)     # context is fixed per slice
+            dec = IncrementalDecoder(self.model.decoder, zl, B, (t, h, w)) if incremental else None
             for ti in range(t):
                 for hi in range(h):
                     for wi in range(w):
+                        pos = (ti * h + hi) * w + wi
                         if prime_sl[ti, hi, wi]:
+                            if dec is not None:
+                                dec.step(sl, pos)                 # known pixel: only its keys / values are needed
                             continue
-                        yl = self.model.decoder.forward_tokens(sl, zl)
-                        sl[:, :, ti, hi, wi] = self.model.ch_predictor.sample_pixel_tokens(
-                            yl, B, t * h * w, (ti * h + hi) * w + wi, temp)
+                        if dec is not None:
+                            sl[:, :, ti, hi, wi] = pred.sample_from_rows(dec.step(sl, pos), temp)
+                        else:
+                            yl = self.model.decoder.forward_tokens(sl, zl)
+                            sl[:, :, ti, hi, wi] = pred.sample_pixel_tokens(yl, B, t * h * w, pos, temp)
             video[:, :, a::st, b_::sh, c::sw] = sl
         return video
 

@@ -1,0 +1,79 @@
+"""Incremental (KV-cache) decoding == the reference's full-pass-per-pixel schedule, position by position,
+and the end-to-end sampler contract."""
+import pytest
+import torch
+
+import seeded
+from conftest import rel_err
+from oracle import lvt_oracle as O
+from util_models import dsfvt_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def vt():
+    from lvt_amd.modeling import build_model
+    cfg = dsfvt_cfg()
+    cfg.TEST.EVALUATORS = "VTSampler"
+    model = build_model(cfg)
+    model.model.load_state_dict(seeded.seeded_params(seeded.dsfvt_shapes(), 4321), strict=False)
+    model.eval()
+    return model
+
+
+def test_incremental_step_equals_full_pass_rows(vt, golden):
+    from lvt_amd.modeling.autoregressive.incremental import IncrementalDecoder
+    codes = torch.stack([seeded.seeded_codes("s%d" % i, (16, 4, 16, 16), 3) for i in range(3)])
+    data = [O.prepare_slices(codes[i], (6, 0, 0), (16, 1, 1), (7, 1, 1), 1) for i in range(3)]
+    ctx = torch.stack([d["context"] for d in data]).to(DEV)
+    sl = torch.stack([d["slice"] for d in data]).to(DEV)
+    si = torch.stack([d["slice_idx"] for d in data]).to(DEV)
+    with torch.no_grad():
+        zl = vt.model.encoder.forward_tokens(ctx, si)
+        full = vt.model.decoder.forward_tokens(sl, zl).view(3, 256, 512)
+        dec = IncrementalDecoder(vt.model.decoder, zl, 3, (1, 16, 16))
+        worst = 0.0
+        for i in range(256):
+            y = dec.step(sl, i)
+            if i in (0, 1, 15, 16, 17, 100, 254, 255):
+                worst = max(worst, rel_err(y, full[:, i]))
+        assert worst < 2e-5, worst
+        # teacher-forced probabilities of the golden pixel set through the incremental path
+        g = golden("g13_sample_probs")
+        g12 = golden("g12_dsfvt_loss")
+        d = O.prepare_slices(g12["codes"][0], (3, 0, 0), (16, 1, 1), (7, 1, 1), 1)
+        ctx1, sl1, si1 = d["context"][None].to(DEV), d["slice"][None].to(DEV), d["slice_idx"][None].to(DEV)
+        zl1 = vt.model.encoder.forward_tokens(ctx1, si1)
+        dec1 = IncrementalDecoder(vt.model.decoder, zl1, 1, (1, 16, 16))
+        for i in range(256):
+            y = dec1.step(sl1, i)
+            hi, wi = divmod(i, 16)
+            if (hi, wi) in ((0, 0), (7, 9), (15, 15)):
+                _, probs = vt.model.ch_predictor.sample_from_rows(y, 1.0, forced_codes=sl1[:, :, 0, hi, wi], return_probs=True)
+                assert rel_err(probs[0], g["probs_%d_%d" % (hi, wi)]) < 1e-4
+
+
+def test_sample_videos_contract_and_priming(vt):
+    codes = torch.stack([seeded.seeded_codes("v%d" % i, (16, 4, 16, 16), 8) for i in range(2)])
+    n_prime = 14                                           # generate the last two frames only (512 positions)
+    with torch.no_grad():
+        video = codes.transpose(1, 2).contiguous().to(DEV)
+        video[:, :, n_prime:] = 0
+        torch.manual_seed(0)
+        out = vt.sample_video(video, n_prime=n_prime)
+        assert tuple(out.shape) == (2, 4, 16, 16, 16) and out.dtype == torch.int64
+        assert torch.equal(out[:, :, :n_prime].cpu(), codes.transpose(1, 2)[:, :, :n_prime])      # primed frames untouched
+        assert 0 <= int(out.min()) and int(out.max()) < 512
+        assert int((out[:, :, n_prime:] != 0).sum()) > 0.9 * out[:, :, n_prime:].numel()
+        # the reference schedule draws from the same distributions: with the same seed and temperature -> 0 both
+        # paths pick the arg-max codes, which must coincide wherever the top-2 probability gap is not a rounding tie
+        a = vt.sample_video(video, n_prime=15, temp=1e-4, incremental=True)
+        b = vt.sample_video(video, n_prime=15, temp=1e-4, incremental=False)
+        assert float((a != b).float().mean()) < 0.01
+    # the inference-mode contract used by generate_videos.py / VTSampler
+    vt.cfg.TEST.VT_SAMPLER.N_PRIME = 15
+    with torch.no_grad():
+        res = vt([{"image_sequence": codes[0]}], mode="inference")
+    assert len(res) == 1 and len(res[0]["samples"]) == 1 and tuple(res[0]["samples"][0].shape) == (4, 16, 16, 16)
