@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dsfvt", action="store_true", help="skip the secondary DSFVT train-step figure")
     ap.add_argument("--dsfvt-batch", type=int, default=64)
+    ap.add_argument("--no-generate", action="store_true", help="skip the secondary generation figure")
+    ap.add_argument("--generate-batch", type=int, default=16)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
@@ -133,6 +135,46 @@ def bench_dsfvt(device, world, rank, steps, warmup, batch):
             "engine_ms_per_step": round(eng_ms / steps, 2),
             "note": "one subscale slice (256 tokens x 4 code channels) of one 16-frame clip per sample; "
                     "fp32; 49.87M parameters; engine_tflops counts executed GEMM FLOPs of the fp32-MFMA engine"}
+
+
+def bench_generate(device, batch):
+    """Secondary figure (BASELINE.json configs[4]): end-to-end generation -- VQ encode of 5 priming frames,
+    DSFVT autoregressive sampling of the remaining 11 frames (incremental K/V-cache decode), VQ decode of all
+    16 frames -- for `batch` videos at once on one GPU.  frames/s = 16 * batch / wall time."""
+    from lvt_amd.config import get_cfg
+    from lvt_amd.modeling import build_model
+    cfgs = []
+    for path in ("configs/vt/DSFVT.yaml", "configs/vqvae/PR-DVQVAE2.yaml"):
+        cfg = get_cfg()
+        cfg.merge_from_file(os.path.join(ROOT, path))
+        cfg.MODEL.DEVICE = device
+        cfg.OUTPUT_DIR = "/tmp/lvt_bench_out"
+        cfgs.append(cfg)
+    cfgs[0].TEST.EVALUATORS = "VTSampler"
+    torch.manual_seed(29871897)
+    vt, vqvae = build_model(cfgs[0]).eval(), build_model(cfgs[1]).eval()
+    n_prime = cfgs[0].TEST.VT_SAMPLER.N_PRIME
+    frames = torch.rand(batch, n_prime, 3, 64, 64, generator=torch.Generator().manual_seed(5)).to(device)
+
+    def run():
+        with torch.no_grad():
+            out = vqvae([{"image_sequence": frames[i]} for i in range(batch)], mode="inference")
+            lat = torch.stack([o["latent"] for o in out])                       # (B, 5, 4, 16, 16)
+            video = lat.new_zeros(batch, 16, lat.shape[2], 16, 16)
+            video[:, :n_prime] = lat
+            sample = vt.sample_video(video.transpose(1, 2).contiguous(), n_prime=n_prime)     # (B, 4, 16, 16, 16)
+            rec = vqvae.decode(sample.transpose(1, 2).reshape(batch * 16, -1, 16, 16))
+            return rec
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rec = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"frames_per_s": round(16 * batch / dt, 2), "videos_per_s": round(batch / dt, 3), "batch_videos": batch,
+            "seconds": round(dt, 3), "decoder_steps": 11 * 256,
+            "note": "5 priming + 11 generated frames per video; random-init weights; sampling is sequential "
+                    "(2816 single-token decoder steps per batch), videos are replicas across GPUs"}
 
 
 def cpu_baseline(batch_clips, budget_s):
@@ -231,6 +273,9 @@ def main():
         del model, optimizers, clips, data
         torch.cuda.empty_cache()
         extra["dsfvt"] = bench_dsfvt(device, world, rank, max(3, args.steps // 4), 2, args.dsfvt_batch)
+    if not args.no_generate and rank == 0 and world == 1:
+        torch.cuda.empty_cache()
+        extra["generate"] = bench_generate(device, args.generate_batch)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

@@ -69,6 +69,13 @@ typedef struct {
 size_t lvt_gemm_workspace_bytes(const lvt_gemm_desc *d);
 int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Small-M variant (M <= 64 rows, e.g. one token per sample in incremental decoding): same addressing as
+ * lvt_gemm_f32 with ta == 0, a single batch level (A shared, B += z*sB, C += z*sC), flags BIAS|RESIDUAL|RELU. */
+int lvt_gemm_smallm_f32(int M, int N, int K, int tb, const float *A, long long lda, const float *B,
+                        long long ldb, float *C, long long ldc, int batch, long long sB, long long sC,
+                        float alpha, int flags, const float *bias, const float *res, long long ldr,
+                        void *stream);
+
 /* ---- 3-D convolution family, channels-last  (torch conv2d / conv3d / conv_transpose2d: K1-K6,K16) --
  * Geometry of the *forward* convolution  y[n,to,ho,wo,co] = sum x[n,to*st-pt+kt, ...,ci] w[co,ci,kt,kh,kw].
  * Ci / Co are the channel counts of the device buffers (multiples of 4; a 3-channel image is carried

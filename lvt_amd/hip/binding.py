@@ -60,6 +60,7 @@ def _declare(lib):
         "lvt_device_info": (ci, [C.c_char_p, ci, P(ci), P(ci), P(cll)]),
         "lvt_gemm_workspace_bytes": (sz, [P(GemmDesc)]),
         "lvt_gemm_f32": (ci, [P(GemmDesc), vp, sz, vp]),
+        "lvt_gemm_smallm_f32": (ci, [ci, ci, ci, ci, vp, cll, vp, cll, vp, cll, ci, cll, cll, cf, ci, vp, vp, cll, vp]),
         "lvt_conv3d_pack_weight": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
         "lvt_conv3d_fwd": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
         "lvt_conv3d_bwd_data": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),

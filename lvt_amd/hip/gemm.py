@@ -39,6 +39,21 @@ def gemm(A, B, C_out, M, N, K, ta=0, tb=0, lda=None, ldb=None, ldc=None, a_kb=0,
     return C_out
 
 
+def gemm_small(A, B, C_out, M, N, K, tb=0, lda=None, ldb=None, ldc=None, batch=1, sB=0, sC=0, alpha=1.0, flags=0,
+               bias=None, res=None, ldr=0):
+    """C = epi(alpha * A @ B) for M <= 64 rows (incremental decoding); see lvt_gemm_smallm_f32."""
+    L.require(A, B, bias, res)
+    if M > 64:
+        return gemm(A, B, C_out, M, N, K, ta=0, tb=tb, lda=lda, ldb=ldb, ldc=ldc, batch_inner=batch, sB=(0, sB),
+                    sC=(0, sC), alpha=alpha, flags=flags, bias=bias, res=res, ldr=ldr)
+    L.check(L.lib().lvt_gemm_smallm_f32(M, N, K, tb, L.ptr(A), lda if lda is not None else K, L.ptr(B),
+                                        ldb if ldb is not None else (K if tb == 0 else N), L.ptr(C_out),
+                                        ldc if ldc is not None else N, batch, sB, sC, alpha, flags, L.ptr(bias),
+                                        L.ptr(res), ldr if ldr else (ldc if ldc is not None else N), L.stream_ptr()),
+            "lvt_gemm_smallm_f32")
+    return C_out
+
+
 def conv_geom(N, Ti, Hi, Wi, Ci, Co, kernel, stride, pad, out=None):
     """Forward-conv geometry; `pad` is the FRONT padding per dim; `out` overrides (To,Ho,Wo)
     (needed for asymmetric padding such as the causal conv)."""

@@ -307,10 +307,10 @@ class ChannelPredictor(nn.Module):
                 ut = _permute_cols(uw, d, k * self.nv)
                 res = tx.embbag_fwd(codes, self.nc, 1, b, list(range(k)), [c * self.nv for c in range(k)], ut, d)
             u = torch.empty(b, d, dtype=torch.float32, device=y.device)
-            G.gemm(y, uw, u, b, d, d, ldb=uw.shape[1], flags=L.EPI_BIAS | L.EPI_RELU | (L.EPI_RESIDUAL if k else 0),
-                   bias=self.U[k].bias, res=res)
+            G.gemm_small(y, uw, u, b, d, d, ldb=uw.shape[1], flags=L.EPI_BIAS | L.EPI_RELU | (L.EPI_RESIDUAL if k else 0),
+                         bias=self.U[k].bias, res=res)
             o = torch.empty(b, self.nv, dtype=torch.float32, device=y.device)
-            G.gemm(u, pw, o, b, self.nv, d, flags=L.EPI_BIAS, bias=self.P[k].bias)
+            G.gemm_small(u, pw, o, b, self.nv, d, flags=L.EPI_BIAS, bias=self.P[k].bias)
             prob = torch.softmax(o / temp, 1)
             probs.append(prob)
             codes[:, k, 0] = (torch.multinomial(prob, 1).squeeze(-1) if forced_codes is None

@@ -149,7 +149,7 @@ class VideoTransformerModel(nn.Module):
         against K/V caches (modeling/autoregressive/incremental.py).  incremental=False reproduces the
         reference's schedule (full decoder pass per generated pixel, vt.py:121-131); both draw from the same
         per-pixel distributions."""
-        from ..autoregressive.incremental import IncrementalDecoder
+        from ..autoregressive.incremental import GraphedSliceSampler
         self._require_gpu()
         v = self._vt
         video = video.to(self.device).clone()
@@ -161,6 +161,13 @@ class VideoTransformerModel(nn.Module):
         if n_prime > 0:
             prime[:n_prime] = True
         pred = self.model.ch_predictor
+        sampler = None
+        if incremental:
+            key = (B, t, h, w, float(temp))
+            sampler = self._samplers.get(key) if hasattr(self, "_samplers") else None
+            if sampler is None:
+                sampler = GraphedSliceSampler(self.model, B, (t, h, w), temp)
+                self._samplers = {key: sampler}           # keep the most recent geometry's graphs
         for si, (a, b_, c) in enumerate(idx2abc):
             sl, ctx = slice_and_context(video, a, b_, c, v.STRIDE, v.KERNEL, v.PAD_VALUE)
             prime_sl = prime[a::st, b_::sh, c::sw]
@@ -168,20 +175,20 @@ class VideoTransformerModel(nn.Module):
                 continue
             sidx = torch.full((B,), si, dtype=torch.long, device=video.device)
             zl = self.model.encoder.forward_tokens(ctx.contiguous(), sidx)     # context is fixed per slice
-            dec = IncrementalDecoder(self.model.decoder, zl, B, (t, h, w)) if incremental else None
-            for ti in range(t):
-                for hi in range(h):
-                    for wi in range(w):
-                        pos = (ti * h + hi) * w + wi
-                        if prime_sl[ti, hi, wi]:
-                            if dec is not None:
-                                dec.step(sl, pos)                 # known pixel: only its keys / values are needed
-                            continue
-                        if dec is not None:
-                            sl[:, :, ti, hi, wi] = pred.sample_from_rows(dec.step(sl, pos), temp)
-                        else:
+            if sampler is not None:
+                sampler.begin_slice(zl, sl)
+                flat = prime_sl.reshape(-1).tolist()
+                for pos in range(t * h * w):
+                    sampler.step(pos, sample=not flat[pos])     # primed pixels only fill the K/V caches
+                sl = sampler.sl.clone()
+            else:
+                for ti in range(t):
+                    for hi in range(h):
+                        for wi in range(w):
+                            if prime_sl[ti, hi, wi]:
+                                continue
                             yl = self.model.decoder.forward_tokens(sl, zl)
-                            sl[:, :, ti, hi, wi] = pred.sample_pixel_tokens(yl, B, t * h * w, pos, temp)
+                            sl[:, :, ti, hi, wi] = pred.sample_pixel_tokens(yl, B, t * h * w, (ti * h + hi) * w + wi, temp)
             video[:, :, a::st, b_::sh, c::sw] = sl
         return video
 
