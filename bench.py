@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--no-dsfvt", action="store_true", help="skip the secondary DSFVT train-step figure")
     ap.add_argument("--dsfvt-batch", type=int, default=64)
     ap.add_argument("--no-generate", action="store_true", help="skip the secondary generation figure")
-    ap.add_argument("--generate-batch", type=int, default=16)
+    ap.add_argument("--generate-batch", type=int, default=64)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 

@@ -1,0 +1,5 @@
+from .evaluator import (BitsEvaluator, CodesExtractor, DatasetEvaluator, DatasetEvaluators, MSEEvaluator,
+                        build_evaluator, inference_on_dataset)
+
+__all__ = ["BitsEvaluator", "CodesExtractor", "DatasetEvaluator", "DatasetEvaluators", "MSEEvaluator",
+           "build_evaluator", "inference_on_dataset"]

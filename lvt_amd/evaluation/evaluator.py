@@ -1,0 +1,162 @@
+"""Evaluation callers of the hot path (reference: vidgen/evaluation/evaluator.py:14-166,
+codes_extractor.py:36-53, mse_evaluation.py:28-47, bits_evaluation.py:28-58).  They only consume the
+dicts `model(inputs)` returns in inference mode; statistics are accumulated on the device and reduced across
+ranks with one all-reduce at the end (the reference gathers pickled python objects over gloo)."""
+import logging
+import math
+import os
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ..data.latents import save_video_codes
+from ..layers import all_reduce_sum_
+from ..utils import comm
+
+
+class DatasetEvaluator:
+    def reset(self):
+        pass
+
+    def process(self, inputs, outputs):
+        pass
+
+    def evaluate(self):
+        pass
+
+
+class DatasetEvaluators(DatasetEvaluator):
+    def __init__(self, evaluators):
+        self._evaluators = list(evaluators)
+
+    def reset(self):
+        for e in self._evaluators:
+            e.reset()
+
+    def process(self, inputs, outputs):
+        for e in self._evaluators:
+            e.process(inputs, outputs)
+
+    def evaluate(self):
+        results = OrderedDict()
+        for e in self._evaluators:
+            r = e.evaluate()
+            if comm.is_main_process() and r is not None:
+                for k, v in r.items():
+                    assert k not in results, "Different evaluators produce results with the same key {}".format(k)
+                    results[k] = v
+        return results
+
+
+class CodesExtractor(DatasetEvaluator):
+    """Writes `output['latent']` (T, nc, h, w) as one .npy per frame under
+    <output_dir>/<dataset_name>/video_<idx>/<frame>.npy -- the training data format of the transformer."""
+
+    def __init__(self, dataset_name, distributed=True, output_dir=None):
+        self._root = os.path.join(output_dir, dataset_name)
+
+    def process(self, inputs, outputs):
+        for inp, out in zip(inputs, outputs):
+            latent = out["latent"]
+            if latent.dim() == 3:
+                latent = latent.unsqueeze(1)
+            save_video_codes(self._root, int(inp["video_idx"]), latent.detach().cpu().numpy())
+
+    def evaluate(self):
+        comm.synchronize()
+        return {}
+
+
+class _SumEvaluator(DatasetEvaluator):
+    def __init__(self, dataset_name, distributed=True, output_dir=None):
+        self._logger = logging.getLogger(__name__)
+        self._distributed = distributed
+        self.reset()
+
+    def reset(self):
+        self._acc = None                      # [sum, count] on the device of the first output
+
+    def _add(self, s, n):
+        v = torch.stack([s.double().reshape(()), torch.tensor(float(n), dtype=torch.float64, device=s.device)])
+        self._acc = v if self._acc is None else self._acc + v
+
+    def _totals(self):
+        acc = self._acc.clone()
+        if self._distributed:
+            all_reduce_sum_(acc)
+        return float(acc[0]), float(acc[1])
+
+
+class MSEEvaluator(_SumEvaluator):
+    def process(self, inputs, outputs):
+        for inp, out in zip(inputs, outputs):
+            rec = out["reconstruction"].detach()
+            tgt = torch.as_tensor(inp["image"] if "image" in inp else inp["image_sequence"], device=rec.device)
+            self._add(F.mse_loss(rec, tgt.to(rec.dtype), reduction="sum"), tgt.numel())
+
+    def evaluate(self):
+        s, n = self._totals()
+        if not comm.is_main_process():
+            return None
+        results = OrderedDict({"reconstruction": {"mse": s / n}})
+        self._logger.info(results)
+        return results
+
+
+class BitsEvaluator(_SumEvaluator):
+    def process(self, inputs, outputs):
+        for inp, out in zip(inputs, outputs):
+            logits = out["logits"]                                   # nc, nv, T, H, W
+            target = torch.as_tensor(inp["image_sequence"], device=logits.device).transpose(0, 1)   # nc, T, H, W
+            keep = ~out["ignore_mask"].expand(target.size(0), -1, -1, -1)
+            ce = F.cross_entropy(logits.permute(1, 0, 2, 3, 4).unsqueeze(0), target.unsqueeze(0), reduction="none")[0]
+            self._add(ce[keep].sum(), int(keep.sum()))
+
+    def evaluate(self):
+        s, n = self._totals()
+        if not comm.is_main_process():
+            return None
+        results = OrderedDict({"likelihood": {"bits_per_dim": (s / math.log(2)) / n}})
+        self._logger.info(results)
+        return results
+
+
+def build_evaluator(cfg, dataset_name, output_folder=None):
+    """Substring dispatch on cfg.TEST.EVALUATORS like tools/train_net.py:35-57 of the reference."""
+    if output_folder is None:
+        output_folder = os.path.join(cfg.OUTPUT_DIR, "inference")
+    evs = []
+    if "CodesExtractor" in cfg.TEST.EVALUATORS:
+        evs.append(CodesExtractor(dataset_name, True, output_folder))
+    if "MSEEvaluator" in cfg.TEST.EVALUATORS:
+        evs.append(MSEEvaluator(dataset_name, True, output_folder))
+    if "BitsEvaluator" in cfg.TEST.EVALUATORS:
+        evs.append(BitsEvaluator(dataset_name, True, output_folder))
+    if not evs:
+        raise NotImplementedError(cfg.TEST.EVALUATORS)
+    return evs[0] if len(evs) == 1 else DatasetEvaluators(evs)
+
+
+def inference_on_dataset(model, data_loader, evaluator):
+    """Run `model(inputs)` in eval mode / no_grad over an iterable of batches and evaluate."""
+    logger = logging.getLogger(__name__)
+    evaluator = evaluator or DatasetEvaluators([])
+    evaluator.reset()
+    was_training = model.training
+    model.eval()
+    n, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        for inputs in data_loader:
+            outputs = model(inputs)
+            evaluator.process(inputs, outputs)
+            n += len(inputs)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    model.train(was_training)
+    logger.info("Total inference time: %.3f s (%.6f s / sample per device, on %d devices)",
+                time.perf_counter() - t0, (time.perf_counter() - t0) / max(n, 1), comm.get_world_size())
+    results = evaluator.evaluate()
+    return {} if results is None else results
