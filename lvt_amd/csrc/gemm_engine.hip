@@ -804,6 +804,16 @@ static int bwd_weight_splits(const lvt_conv_geom *g) {
     return s < 2 ? 2 : s;   // always go through the partial buffer (the unpack kernel reduces it)
 }
 
+int lvt_unpack_wgrad(const void *partial, long long stride, int splits, float *dw, int taps, int Ci, int Co,
+                     int Ci_real, int Co_real, void *stream) {
+    const long long total = (long long)taps * Ci * Co;
+    const int blocks = (int)(lvt_cdiv(total, 256) < 4096 ? lvt_cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(lvt_unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)partial,
+                       stride, splits, dw, taps, Ci, Co, Ci_real, Co_real);
+    LVT_CHECK_LAUNCH("lvt_unpack_wgrad_kernel");
+    return LVT_OK;
+}
+
 extern "C" size_t lvt_conv3d_bwd_weight_workspace_bytes(const lvt_conv_geom *g) {
     if (!g) return 0;
     const long long Mg = (long long)g->Kt * g->Kh * g->Kw * g->Ci;

@@ -70,6 +70,9 @@ def stack_forward(layers, x, params):
         bias = _padded_bias(ly, b)
         if ly.kind == "conv":
             y = G.conv_fwd(g, cur, wp, bias=bias, res=res, flags=_act_flag(ly.act))
+        elif (ly.cout <= 3 and ly.kernel == (1, 4, 4) and ly.stride == (1, 2, 2) and ly.pad == (0, 1, 1)
+              and ly.cin % 16 == 0 and res is None and ly.act in ("", "tanh")):
+            y = G.convT4_fwd(cur, w, b, ly.act == "tanh")          # image-side layer: dedicated kernel
         else:
             y = G.conv_bwd_data(g, cur, wp, bias=bias, res=res, flags=_act_flag(ly.act))
         outs.append(y)

@@ -116,10 +116,38 @@ def conv_bwd_data(g, dy, wp, bias=None, res=None, mask=None, flags=0):
     return dx
 
 
+def convT4_fwd(x, w, bias, act_tanh):
+    """ConvTranspose2d(Ci -> <=3, k4 s2 p1) forward on the dedicated image-side kernel.
+    x (N,1,Hi,Wi,Ci) -> (N,1,2Hi,2Wi,4)."""
+    L.require(x, w, bias)
+    N, _, Hi, Wi, Ci = x.shape
+    y = torch.empty(N, 1, 2 * Hi, 2 * Wi, 4, dtype=torch.float32, device=x.device)
+    t0 = L.TIMER.begin() if L.TIMER is not None else None
+    L.check(L.lib().lvt_convt4_fwd(L.ptr(x), L.ptr(w), L.ptr(bias), N, Hi, Wi, Ci, w.shape[1], 1 if act_tanh else 0,
+                                   L.ptr(y), L.stream_ptr()), "lvt_convt4_fwd")
+    if t0 is not None:
+        L.TIMER.end("thin_convT_fwd", 2.0 * N * 4 * Hi * Wi * 4 * 4 * Ci, t0)
+    return y
+
+
+def thin_wgrad_ok(g):
+    return (g.Ci == 4 and g.Kt == 1 and g.Ti == 1 and g.To == 1 and (g.Kh, g.Kw) in ((3, 3), (4, 4)) and 256 % g.Co == 0
+            and g.Wo % 32 == 0)
+
+
 def conv_bwd_weight(g, x, dy, Ci_real, Co_real):
     L.require(x, dy)
     lib = L.lib()
     dw = torch.empty(Co_real, Ci_real, g.Kt, g.Kh, g.Kw, dtype=torch.float32, device=x.device)
+    if thin_wgrad_ok(g):
+        nws = lib.lvt_conv4_bwd_weight_workspace_bytes(C.byref(g))
+        ws = L.workspace(nws, x.device, "wgrad4")
+        t0 = L.TIMER.begin() if L.TIMER is not None else None
+        L.check(lib.lvt_conv4_bwd_weight(C.byref(g), L.ptr(x), L.ptr(dy), L.ptr(dw), Ci_real, Co_real, L.ptr(ws), nws,
+                                         L.stream_ptr()), "lvt_conv4_bwd_weight")
+        if t0 is not None:
+            L.TIMER.end("thin_bwd_weight", conv_flops(g), t0)
+        return dw
     nws = lib.lvt_conv3d_bwd_weight_workspace_bytes(C.byref(g))
     ws = L.workspace(nws, x.device, "wgrad")
     t0 = L.TIMER.begin() if L.TIMER is not None else None
