@@ -288,6 +288,12 @@ def main():
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         per_kind = {k: {"launches": v["launches"], "avg_us": round(v["ms"] / v["launches"] * 1e3, 1),
                         "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in sorted(eng.items())}
+        traffic = None
+        try:      # HBM bytes per engine launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate runs)
+            with open(os.path.join(ROOT, "profiles", "r01_vqvae_pmc_hbm_traffic.json")) as f:
+                traffic = round(json.load(f)["hbm_bytes_per_launch"])
+        except Exception:
+            pass
         out = {
             "metric": "video-clips/sec/node (VQ-VAE PR-DVQVAE2 train step, BAIR 64x64x16)",
             "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
@@ -298,7 +304,9 @@ def main():
                        "global_batch_clips": args.batch_clips * world, "parallelism": "dp%d" % world,
                        "loss": {k: round(float(v.detach()), 6) for k, v in losses.items()}},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, "
+                                         "profiles/r01_vqvae_pmc_hbm_traffic.txt); algorithmic flops per launch = %.3e" % (tot_fl / max(launches, 1)),
                          "kernel": "lvt_gemm_kernel<*> (fp32 MFMA implicit-GEMM engine: conv fwd / bwd-data / "
                                    "bwd-weight), %d launches, %.2f ms of %.2f ms per step"
                                    % (launches // args.steps, tot_ms / args.steps, ms),
