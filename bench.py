@@ -14,6 +14,7 @@ timed per launch with HIP events on the launch stream inside the timed region) a
 CPU oracle (a port of the reference's PyTorch-CPU path) timed on the host cores of the same box.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -28,7 +29,28 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2516.6     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+
+
+def engine_peak(mode):
+    """Ceiling of the engine in ALGORITHMIC fp32 FLOP/s: the fp32 MFMA peak in 'f32' mode; in 'bf16x3' mode every
+    algorithmic product is six bf16 MFMA products (a1b1 a1b2 a2b1 a1b3 a3b1 a2b2), so the ceiling is bf16 peak / 6."""
+    return FP32_MFMA_PEAK_TFLOPS if mode == "f32" else BF16_MFMA_PEAK_TFLOPS / 6.0
 CLIP_FRAMES = 16
+
+
+MATH_NOTE = {
+    "f32": "fp32 in, fp32 out, v_mfma_f32_32x32x2_f32 products, fp32 accumulation",
+    "bf16x3": "fp32 in, fp32 out, fp32 accumulation; every fp32 product formed exactly from a 3-way bf16 split of both "
+              "operands (six v_mfma_f32_32x32x16_bf16 per block, dropped terms < 2^-24 |a||b|); measured error against "
+              "fp64 is not larger than the plain fp32 MFMA path's (profiles/r01_math_mode_accuracy.txt, "
+              "tests/test_gpu_engine.py::test_math_modes_accuracy); LVT_MATH=f32 selects the plain fp32 instruction",
+}
+PEAK_NOTE = {
+    "f32": "dense fp32 MFMA peak (MI355X_MICROARCH.md)",
+    "bf16x3": "dense bf16 MFMA peak 2516.6 TFLOP/s / 6 MFMA products per algorithmic fp32 product; `achieved` counts "
+              "ALGORITHMIC fp32 FLOPs only (not the 6x executed bf16 FLOPs)",
+}
 
 
 def parse():
@@ -42,6 +64,7 @@ def parse():
     ap.add_argument("--dsfvt-batch", type=int, default=64)
     ap.add_argument("--no-generate", action="store_true", help="skip the secondary generation figure")
     ap.add_argument("--generate-batch", type=int, default=64)
+    ap.add_argument("--no-strict-f32", action="store_true", help="skip the secondary LVT_MATH=f32 figure")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
@@ -112,9 +135,9 @@ def bench_dsfvt(device, world, rank, steps, warmup, batch):
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
+    gc.collect()
     if world > 1:
         dist.barrier()
-    L.TIMER = L.KernelTimer()
     t0 = time.perf_counter()
     for i in range(steps):
         loss = step(warmup + i)
@@ -122,10 +145,14 @@ def bench_dsfvt(device, world, rank, steps, warmup, batch):
     if world > 1:
         dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-    timer, L.TIMER = L.TIMER, None
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    L.TIMER = L.KernelTimer()          # instrumented pass (per-launch events), see main()
+    for i in range(steps):
+        step(warmup + steps + i)
+    torch.cuda.synchronize()
+    timer, L.TIMER = L.TIMER, None
     summ = timer.summary()
     eng_ms = sum(v_["ms"] for v_ in summ.values())
     eng_fl = sum(v_["flops"] for v_ in summ.values())
@@ -134,7 +161,7 @@ def bench_dsfvt(device, world, rank, steps, warmup, batch):
             "engine_tflops": round(eng_fl / (eng_ms * 1e-3) / 1e12, 2) if eng_ms else None,
             "engine_ms_per_step": round(eng_ms / steps, 2),
             "note": "one subscale slice (256 tokens x 4 code channels) of one 16-frame clip per sample; "
-                    "fp32; 49.87M parameters; engine_tflops counts executed GEMM FLOPs of the fp32-MFMA engine"}
+                    "fp32 data; 49.87M parameters; engine_tflops counts algorithmic fp32 GEMM FLOPs of the engine launches (event-timed in a second pass)"}
 
 
 def bench_generate(device, batch):
@@ -249,11 +276,15 @@ def main():
     for i in range(args.warmup):
         vqvae_step(model, optimizers, data, i)
     torch.cuda.synchronize()
+    # a full (generation-2) Python GC pass with torch loaded takes 60-70 ms of host time; right after a barrier the
+    # host has no lead over the GPU, so one such pause would stall the device for 3 steps' worth of launches
+    gc.collect()
+    gc.freeze()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
 
-    L.TIMER = L.KernelTimer()
+    # Pass 1 -- the timed region: exactly K steps, nothing but the product path between the two barriers.
     t0 = time.perf_counter()
     for i in range(args.steps):
         losses = vqvae_step(model, optimizers, data, args.warmup + i)
@@ -262,11 +293,46 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer, L.TIMER = L.TIMER, None
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+
+    # Pass 2 -- the same K steps again with a HIP event pair around every engine launch (on the launch stream) for
+    # the roofline block.  It is a separate pass because a timing event is a barrier packet: it serialises
+    # consecutive launches (the next kernel can no longer fill CUs while the previous one drains), which costs
+    # ~15% of the step and would be charged to `value` if both ran together.
+    L.TIMER = L.KernelTimer()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        vqvae_step(model, optimizers, data, args.warmup + args.steps + i)
+    torch.cuda.synchronize()
+    instrumented_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    timer, L.TIMER = L.TIMER, None
+    math_mode = L.get_math_mode()
+
+    strict = None
+    if math_mode != "f32" and not args.no_strict_f32:
+        # the same timed region on the plain fp32 MFMA instruction (v_mfma_f32_32x32x2_f32), for reference
+        L.set_math_mode("f32")
+        for i in range(2):
+            vqvae_step(model, optimizers, data, i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t2 = time.perf_counter()
+        for i in range(args.steps):
+            vqvae_step(model, optimizers, data, i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        e2 = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(e2, op=dist.ReduceOp.MAX)
+        strict = {"clips_per_s": round(args.batch_clips * world * args.steps / float(e2.item()), 3),
+                  "ms_per_step": round(float(e2.item()) / args.steps * 1e3, 3),
+                  "note": "LVT_MATH=f32: identical step on v_mfma_f32_32x32x2_f32 (peak 157.3 TFLOP/s)"}
+        L.set_math_mode(math_mode)
 
     extra = {}
     if not args.no_dsfvt:
@@ -298,20 +364,24 @@ def main():
             "metric": "video-clips/sec/node (VQ-VAE PR-DVQVAE2 train step, BAIR 64x64x16)",
             "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "math": MATH_NOTE[math_mode],
             "config": {"workload": "PR-DVQVAE2 train step (fwd+bwd+Adam), %d clips x 16 frames x 3x64x64 per GPU, "
                                    "4x512 EMA codebooks" % args.batch_clips,
                        "global_batch_clips": args.batch_clips * world, "parallelism": "dp%d" % world,
                        "loss": {k: round(float(v.detach()), 6) for k, v in losses.items()}},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(engine_peak(math_mode), 1),
+                         "unit": "TFLOP/s", "frac": round(achieved / engine_peak(math_mode), 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, "
                                          "profiles/r01_vqvae_pmc_hbm_traffic.txt); algorithmic flops per launch = %.3e" % (tot_fl / max(launches, 1)),
-                         "kernel": "lvt_gemm_kernel<*> (fp32 MFMA implicit-GEMM engine: conv fwd / bwd-data / "
-                                   "bwd-weight), %d launches, %.2f ms of %.2f ms per step"
-                                   % (launches // args.steps, tot_ms / args.steps, ms),
+                         "kernel": "lvt_gemm_kernel<*> (implicit-GEMM engine: conv fwd / bwd-data / bwd-weight), %d "
+                                   "launches per step; event-timed in a second pass of the same %d steps: %.2f ms of "
+                                   "engine time in a %.2f ms instrumented step (unperturbed step: %.2f ms)"
+                                   % (launches // args.steps, args.steps, tot_ms / args.steps, instrumented_ms, ms),
+                         "peak_note": PEAK_NOTE[math_mode],
                          "per_kind": per_kind},
         }
+        if strict is not None:
+            extra["strict_f32_mfma"] = strict
         out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch_clips, args.cpu_seconds)

@@ -34,6 +34,15 @@ int lvt_version(void);
 /* Device probe: name, CU count, clock (kHz), HBM bytes.  Returns LVT_ENODEVICE without a GPU. */
 int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long long *hbm_bytes);
 
+/* Arithmetic of the GEMM / conv engine.  Operands, results and accumulators are fp32 in both modes.
+ *   1 (default) "bf16x3": every fp32 operand is split exactly into three bf16 terms (24 mantissa bits) while it is
+ *       staged in LDS, and each product block is six v_mfma_f32_32x32x16_bf16 (a1b1 a1b2 a2b1 a1b3 a3b1 a2b2, each
+ *       bf16 x bf16 product exact in the fp32 accumulator; dropped terms are below 2^-24 |a||b|).  Measured error
+ *       against fp64 is not larger than mode 0's (tests/test_gpu_engine.py::test_math_modes_accuracy).
+ *   0 "f32": plain v_mfma_f32_32x32x2_f32.                                                                   */
+int lvt_set_math_mode(int mode);
+int lvt_get_math_mode(void);
+
 /* ---- epilogue flags shared by GEMM / conv ------------------------------------------------------ */
 #define LVT_EPI_BIAS        1   /* + bias[n]                                                  */
 #define LVT_EPI_RESIDUAL    2   /* + res[m][n]                                                 */

@@ -53,13 +53,72 @@ struct KParams {
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+// ---- bf16x3 split (opt-in math mode): a = a1 + a2 + a3 with three bf16 terms = 24 mantissa bits, every
+// residual exact in fp32.  v_cvt_pk_bf16_f32 rounds to nearest even and packs (src0 -> low half).
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float bf_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+// 4 floats -> three planes of 4 packed bf16 (uint2 = elements 0..3 in memory order)
+__device__ __forceinline__ void split3(const float4 v, uint2 &p1, uint2 &p2, uint2 &p3) {
+    p1.x = cvt_pk_bf16(v.x, v.y); p1.y = cvt_pk_bf16(v.z, v.w);
+    const float r0 = v.x - bf_lo(p1.x), r1 = v.y - bf_hi(p1.x), r2 = v.z - bf_lo(p1.y), r3 = v.w - bf_hi(p1.y);
+    p2.x = cvt_pk_bf16(r0, r1); p2.y = cvt_pk_bf16(r2, r3);
+    const float s0 = r0 - bf_lo(p2.x), s1 = r1 - bf_hi(p2.x), s2 = r2 - bf_lo(p2.y), s3 = r3 - bf_hi(p2.y);
+    p3.x = cvt_pk_bf16(s0, s1); p3.y = cvt_pk_bf16(s2, s3);
+}
+#define HLD 40          // bf16 per staged row: BK (32) + 8 pad -> 80-byte rows
+// Staged-row placement of the bf16 planes.  128-row tiles are stored "4x32 transposed" (logical row m lives at
+// physical row (m & 3) * 32 + (m >> 2)) with 64 pad bytes after every 32 physical rows: the 16-byte MFMA operand
+// reads and the 8-byte stores of the k-contiguous loaders are bank-conflict free, the 8-byte stores of the
+// m-contiguous loaders (4 consecutive rows per lane) are 2-way.  Narrow (32-row) tiles keep the identity order.
+template <int ROWS> __device__ __forceinline__ int hrow(int m) {
+    if (ROWS >= 128) {
+        const int r = (m & ~127) + ((m & 3) << 5) + ((m & 127) >> 2);
+        return r * HLD + (r >> 5) * 32;
+    }
+    return m * HLD;
+}
+template <int ROWS> struct HPlane { static constexpr int SIZE = ROWS * HLD + (ROWS >= 128 ? ROWS : 0); };
+// 4 consecutive k of one row -> one 8-byte store per plane
+template <int ROWS> __device__ __forceinline__ void store_split_k(unsigned short *lds, int row, int k4, const float4 v) {
+    uint2 p1, p2, p3;
+    split3(v, p1, p2, p3);
+    unsigned short *d = lds + hrow<ROWS>(row) + k4;
+    *reinterpret_cast<uint2 *>(d) = p1;
+    *reinterpret_cast<uint2 *>(d + HPlane<ROWS>::SIZE) = p2;
+    *reinterpret_cast<uint2 *>(d + 2 * HPlane<ROWS>::SIZE) = p3;
+}
+// 4 consecutive rows at one k (narrow tiles only) -> transposing 2-byte stores
+template <int ROWS> __device__ __forceinline__ void store_split_m(unsigned short *lds, int row4, int k, const float4 v) {
+    uint2 p[3];
+    split3(v, p[0], p[1], p[2]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        unsigned short *d = lds + q * HPlane<ROWS>::SIZE + k;
+        d[hrow<ROWS>(row4)] = (unsigned short)(p[q].x & 0xffffu); d[hrow<ROWS>(row4 + 1)] = (unsigned short)(p[q].x >> 16);
+        d[hrow<ROWS>(row4 + 2)] = (unsigned short)(p[q].y & 0xffffu); d[hrow<ROWS>(row4 + 3)] = (unsigned short)(p[q].y >> 16);
+    }
+}
+// m-contiguous fetch with 4 consecutive k per lane: a 4(k) x 4(m) register block is transposed in registers
+// and leaves as one 8-byte store per row and plane
+template <int ROWS> __device__ __forceinline__ void store_split_block(unsigned short *lds, int row4, int k4, const float4 *v) {
+    store_split_k<ROWS>(lds, row4 + 0, k4, make_float4(v[0].x, v[1].x, v[2].x, v[3].x));
+    store_split_k<ROWS>(lds, row4 + 1, k4, make_float4(v[0].y, v[1].y, v[2].y, v[3].y));
+    store_split_k<ROWS>(lds, row4 + 2, k4, make_float4(v[0].z, v[1].z, v[2].z, v[3].z));
+    store_split_k<ROWS>(lds, row4 + 3, k4, make_float4(v[0].w, v[1].w, v[2].w, v[3].w));
+}
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // ------------------------------------------------------------------------------------------------
 // A-side loaders.  K-contiguous modes fetch float4 along k and scatter 4 scalars into the k-major
 // LDS tile; M-contiguous modes fetch float4 along m and store it as one 16-byte LDS write.
 // ------------------------------------------------------------------------------------------------
-template <int MODE, int BM> struct ALoader;
+template <int MODE, int BM, int MATH> struct ALoader;
 
 // ---- k-contiguous family: rows r0 + 32*i (i < BM/32), k quad kq = tid & 7 ------------------------
 #define QPR (BK / 4)                 // float4 quads per tile row
@@ -80,9 +139,13 @@ template <int MODE, int BM> struct AKLoaderBase {
             lds[(kq * 4 + 3) * LD + row] = v[i].w;
         }
     }
+    __device__ __forceinline__ void store_split(unsigned short *lds) const {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) store_split_k<BM>(lds, r0 + RPP * i, kq * 4, v[i]);
+    }
 };
 
-template <int BM> struct ALoader<A_KPLAIN, BM> : AKLoaderBase<A_KPLAIN, BM> {
+template <int BM, int MATH> struct ALoader<A_KPLAIN, BM, MATH> : AKLoaderBase<A_KPLAIN, BM> {
     using Base = AKLoaderBase<A_KPLAIN, BM>;
     const float *rowp[Base::ITERS];
     bool rowok[Base::ITERS];
@@ -108,7 +171,7 @@ template <int BM> struct ALoader<A_KPLAIN, BM> : AKLoaderBase<A_KPLAIN, BM> {
 };
 
 // forward convolution: row m -> (n,to,ho,wo); k -> (tap, ci)
-template <int BM> struct ALoader<A_CONV_K, BM> : AKLoaderBase<A_CONV_K, BM> {
+template <int BM, int MATH> struct ALoader<A_CONV_K, BM, MATH> : AKLoaderBase<A_CONV_K, BM> {
     using Base = AKLoaderBase<A_CONV_K, BM>;
     long long nbase[Base::ITERS];
     int ti0[Base::ITERS], hi0[Base::ITERS], wi0[Base::ITERS];
@@ -149,7 +212,7 @@ template <int BM> struct ALoader<A_CONV_K, BM> : AKLoaderBase<A_CONV_K, BM> {
 
 // backward-data / ConvTranspose forward.  Rows are dx positions of ONE stride phase (blockIdx.z):
 // i = s*q + r.  k -> (phase tap j, co); gathered dy position o = q + c - j per dimension.
-template <int BM> struct ALoader<A_CONVT_K, BM> : AKLoaderBase<A_CONVT_K, BM> {
+template <int BM, int MATH> struct ALoader<A_CONVT_K, BM, MATH> : AKLoaderBase<A_CONVT_K, BM> {
     using Base = AKLoaderBase<A_CONVT_K, BM>;
     long long nbase[Base::ITERS];
     int ot0[Base::ITERS], oh0[Base::ITERS], ow0[Base::ITERS];
@@ -194,11 +257,13 @@ template <int BM> struct ALoader<A_CONVT_K, BM> : AKLoaderBase<A_CONVT_K, BM> {
 };
 
 // ---- m-contiguous family: k rows kk0 + KPP*i, m quad mq -----------------------------------------
-template <int BM> struct AMLoaderBase {
+template <int BM, int MATH> struct AMLoaderBase {
     static constexpr int UPK = BM / 4;              // float4 units per k row
     static constexpr int KPP = NTHREADS / UPK;      // k rows per pass
     static constexpr int ITERS = BK / KPP;
     static constexpr int LD = BM + 4;
+    // k row of fetch i: strided over the passes for the fp32 tile, consecutive per lane for the bf16 planes
+    static constexpr int KMUL = MATH ? ITERS : 1, KSTEP = MATH ? 1 : KPP;
     float4 v[ITERS];
     int kk0, mq;
     __device__ __forceinline__ void store(float *lds) const {
@@ -206,10 +271,15 @@ template <int BM> struct AMLoaderBase {
         for (int i = 0; i < ITERS; ++i)
             *reinterpret_cast<float4 *>(&lds[(kk0 + KPP * i) * LD + mq * 4]) = v[i];
     }
+    __device__ __forceinline__ void store_split(unsigned short *lds) const {
+        if (ITERS == 4) { store_split_block<BM>(lds, mq * 4, kk0 * 4, v); return; }
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) store_split_m<BM>(lds, mq * 4, kk0 * KMUL + KSTEP * i, v[i]);
+    }
 };
 
-template <int BM> struct ALoader<A_MPLAIN, BM> : AMLoaderBase<BM> {
-    using Base = AMLoaderBase<BM>;
+template <int BM, int MATH> struct ALoader<A_MPLAIN, BM, MATH> : AMLoaderBase<BM, MATH> {
+    using Base = AMLoaderBase<BM, MATH>;
     const float *colp; bool mok; long long lda;
     __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int) {
         this->kk0 = tid / Base::UPK; this->mq = tid % Base::UPK;
@@ -219,15 +289,15 @@ template <int BM> struct ALoader<A_MPLAIN, BM> : AMLoaderBase<BM> {
     __device__ __forceinline__ void fetch(int k0, int kend) {
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i) {
-            const int k = k0 + this->kk0 + Base::KPP * i;
+            const int k = k0 + this->kk0 * Base::KMUL + Base::KSTEP * i;
             this->v[i] = (mok && k < kend) ? ldg4(colp + (long long)k * lda) : zero4();
         }
     }
 };
 
 // backward-weight: GEMM row = (tap, ci), GEMM k = output pixel (n,to,ho,wo)
-template <int BM> struct ALoader<A_CONV_M, BM> : AMLoaderBase<BM> {
-    using Base = AMLoaderBase<BM>;
+template <int BM, int MATH> struct ALoader<A_CONV_M, BM, MATH> : AMLoaderBase<BM, MATH> {
+    using Base = AMLoaderBase<BM, MATH>;
     const float *x; lvt_conv_geom g; bool mok; int kt, kh, kw, ci;
     __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int) {
         this->kk0 = tid / Base::UPK; this->mq = tid % Base::UPK;
@@ -241,7 +311,7 @@ template <int BM> struct ALoader<A_CONV_M, BM> : AMLoaderBase<BM> {
     __device__ __forceinline__ void fetch(int k0, int kend) {
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i) {
-            int pix = k0 + this->kk0 + Base::KPP * i;
+            int pix = k0 + this->kk0 * Base::KMUL + Base::KSTEP * i;
             bool ok = mok && pix < kend;
             const int wo = pix % g.Wo; pix /= g.Wo;
             const int ho = pix % g.Ho; pix /= g.Ho;
@@ -256,8 +326,8 @@ template <int BM> struct ALoader<A_CONV_M, BM> : AMLoaderBase<BM> {
 };
 
 // scatter-add as a GEMM: dTable[(slot, code)][:] = sum_rows onehot(row, slot)[code] * dOut[row][:]
-template <int BM> struct ALoader<A_ONEHOT_M, BM> : AMLoaderBase<BM> {
-    using Base = AMLoaderBase<BM>;
+template <int BM, int MATH> struct ALoader<A_ONEHOT_M, BM, MATH> : AMLoaderBase<BM, MATH> {
+    using Base = AMLoaderBase<BM, MATH>;
     const long long *ip; long long bstride, pstride; int P, code0; bool mok;
     __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *, int) {
         this->kk0 = tid / Base::UPK; this->mq = tid % Base::UPK;
@@ -271,7 +341,7 @@ template <int BM> struct ALoader<A_ONEHOT_M, BM> : AMLoaderBase<BM> {
     __device__ __forceinline__ void fetch(int k0, int kend) {
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i) {
-            const int row = k0 + this->kk0 + Base::KPP * i;
+            const int row = k0 + this->kk0 * Base::KMUL + Base::KSTEP * i;
             float4 v = zero4();
             if (mok && row < kend) {
                 const int b = row / P, pos = row - b * P;
@@ -287,7 +357,7 @@ template <int BM> struct ALoader<A_ONEHOT_M, BM> : AMLoaderBase<BM> {
 // ------------------------------------------------------------------------------------------------
 // B-side loaders
 // ------------------------------------------------------------------------------------------------
-template <int MODE, int BN> struct BLoader;
+template <int MODE, int BN, int MATH> struct BLoader;
 
 template <int BN> struct BKLoaderBase {
     static constexpr int ITERS = (BN >= RPP) ? BN / RPP : 1;
@@ -305,9 +375,14 @@ template <int BN> struct BKLoaderBase {
             lds[(kq * 4 + 3) * LD + row] = v[i].w;
         }
     }
+    __device__ __forceinline__ void store_split(unsigned short *lds) const {
+        if (r0 >= BN) return;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) store_split_k<BN>(lds, r0 + RPP * i, kq * 4, v[i]);
+    }
 };
 
-template <int BN> struct BLoader<B_KPLAIN, BN> : BKLoaderBase<BN> {
+template <int BN, int MATH> struct BLoader<B_KPLAIN, BN, MATH> : BKLoaderBase<BN> {
     using Base = BKLoaderBase<BN>;
     const float *rowp[Base::ITERS]; bool rowok[Base::ITERS]; int kb; long long skb;
     __device__ __forceinline__ void init(const KParams &p, int tid, int n0, const float *B, int) {
@@ -331,7 +406,7 @@ template <int BN> struct BLoader<B_KPLAIN, BN> : BKLoaderBase<BN> {
 };
 
 // packed conv weights wp[tap][ci][co] read as B(k=(phase tap j, co), n=ci) for one stride phase
-template <int BN> struct BLoader<B_CONVT_W, BN> : BKLoaderBase<BN> {
+template <int BN, int MATH> struct BLoader<B_CONVT_W, BN, MATH> : BKLoaderBase<BN> {
     using Base = BKLoaderBase<BN>;
     const float *wp; lvt_conv_geom g; int jH, jW, ft, fh, fw;
     int nrow[Base::ITERS]; bool rowok[Base::ITERS];
@@ -359,11 +434,12 @@ template <int BN> struct BLoader<B_CONVT_W, BN> : BKLoaderBase<BN> {
     }
 };
 
-template <int BN> struct BLoader<B_NPLAIN, BN> {
+template <int BN, int MATH> struct BLoader<B_NPLAIN, BN, MATH> {
     static constexpr int UPK = BN / 4;
     static constexpr int KPP = (NTHREADS / UPK) > BK ? BK : (NTHREADS / UPK);
     static constexpr int ITERS = BK / KPP;
     static constexpr int LD = BN + 4;
+    static constexpr int KMUL = MATH ? ITERS : 1, KSTEP = MATH ? 1 : KPP;
     float4 v[ITERS];
     int kk0, nq; bool active;
     const float *colp; bool nok; long long ldb;
@@ -376,7 +452,7 @@ template <int BN> struct BLoader<B_NPLAIN, BN> {
     __device__ __forceinline__ void fetch(int k0, int kend) {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
-            const int k = k0 + kk0 + KPP * i;
+            const int k = k0 + kk0 * KMUL + KSTEP * i;
             v[i] = (nok && k < kend) ? ldg4(colp + (long long)k * ldb) : zero4();
         }
     }
@@ -386,20 +462,36 @@ template <int BN> struct BLoader<B_NPLAIN, BN> {
         for (int i = 0; i < ITERS; ++i)
             *reinterpret_cast<float4 *>(&lds[(kk0 + KPP * i) * LD + nq * 4]) = v[i];
     }
+    __device__ __forceinline__ void store_split(unsigned short *lds) const {
+        if (!active) return;
+        if (ITERS == 4) { store_split_block<BN>(lds, nq * 4, kk0 * 4, v); return; }
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) store_split_m<BN>(lds, nq * 4, kk0 * KMUL + KSTEP * i, v[i]);
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
-template <int AMODE, int BMODE, int BM, int BN, int WM, int WN>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// MATH == 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
+// MATH == 1: bf16x3 split -- every fp32 operand is staged as three bf16 planes and each 32x32x16 block is six
+//            v_mfma_f32_32x32x16_bf16 (a1b1, a1b2, a2b1, a1b3, a3b1, a2b2: all product terms above 2^-24 |ab|,
+//            each bf16 x bf16 product exact in the fp32 accumulator).  fp32-class accuracy at ~2.7x the rate.
+template <int AMODE, int BMODE, int BM, int BN, int WM, int WN, int MATH>
 __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const KParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    using AL = ALoader<AMODE, BM>;
-    using BL = BLoader<BMODE, BN>;
+    using AL = ALoader<AMODE, BM, MATH>;
+    using BL = BLoader<BMODE, BN, MATH>;
     constexpr int LDA = AL::LD, LDB = BL::LD;
-    __shared__ __attribute__((aligned(16))) float lds[BK * LDA + BK * LDB + 8];
+    constexpr int PSA = HPlane<BM>::SIZE, PSB = HPlane<BN>::SIZE;                       // bf16 plane strides (MATH == 1)
+    constexpr int LDS_FLOATS = MATH == 0 ? (BK * LDA + BK * LDB + 8) : (3 * (PSA + PSB) / 2 + 8);
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float *As = lds;
     float *Bs = lds + ((BK * LDA + 3) & ~3);
+    unsigned short *Ah = reinterpret_cast<unsigned short *>(lds);
+    unsigned short *Bh = Ah + 3 * PSA;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -454,7 +546,8 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
 
     if (kbeg < kend) {
         al.fetch(kbeg, kend); bl.fetch(kbeg, kend);
-        al.store(As); bl.store(Bs);
+        if (MATH == 0) { al.store(As); bl.store(Bs); }
+        else { al.store_split(Ah); bl.store_split(Bh); }
     }
     __syncthreads();
 
@@ -464,34 +557,72 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool has_next = k0 + BK < kend;
         if (has_next) { al.fetch(k0 + BK, kend); bl.fetch(k0 + BK, kend); }
-        // operand fragments are double-buffered in registers: the ds_reads of step kk+2 are in flight
-        // while the MFMAs of step kk issue, so the LDS latency is not exposed once per step
-        float a[2][TM], b[2][TN];
+        if (MATH == 0) {
+            // operand fragments are double-buffered in registers: the ds_reads of step kk+2 are in flight
+            // while the MFMAs of step kk issue, so the LDS latency is not exposed once per step
+            float a[2][TM], b[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[0][i] = Ard[i * 32];
+            for (int i = 0; i < TM; ++i) a[0][i] = Ard[i * 32];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[0][j] = Brd[j * 32];
-        __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);       // step-0 operand reads
+            for (int j = 0; j < TN; ++j) b[0][j] = Brd[j * 32];
+            __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);   // step-0 operand reads
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
-            if (kk + 2 < BK) {
+            for (int kk = 0; kk < BK; kk += 2) {
+                const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+                if (kk + 2 < BK) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[nxt][i] = Ard[(kk + 2) * LDA + i * 32];
+                    for (int i = 0; i < TM; ++i) a[nxt][i] = Ard[(kk + 2) * LDA + i * 32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[nxt][j] = Brd[(kk + 2) * LDB + j * 32];
+                    for (int j = 0; j < TN; ++j) b[nxt][j] = Brd[(kk + 2) * LDB + j * 32];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                // pin the interleave: next step's operand reads are issued BEFORE this step's MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);   // DS reads
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                       // MFMAs
             }
+        } else {
+            // lane l feeds row (l & 31) and the 8 consecutive k starting at 8 * (l >> 5) of each 16-wide k step
+            const unsigned short *Arh[TM], *Brh[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) Arh[i] = Ah + hrow<BM>(wm * (TM * 32) + i * 32 + l31) + 8 * half;
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-            // pin the interleave: next step's operand reads are issued BEFORE this step's MFMAs
-            __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);   // DS reads
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                       // MFMAs
+            for (int j = 0; j < TN; ++j) Brh[j] = Bh + hrow<BN>(wn * (TN * 32) + j * 32 + l31) + 8 * half;
+#pragma unroll
+            for (int ks = 0; ks < BK; ks += 16) {
+                bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        a[q][i] = *reinterpret_cast<const bf16x8 *>(Arh[i] + q * PSA + ks);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        b[q][j] = *reinterpret_cast<const bf16x8 *>(Brh[j] + q * PSB + ks);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        f32x16 c = acc[i][j];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);   // 2^-16 terms first
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);   // 2^-8 terms
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);   // leading term
+                        acc[i][j] = c;
+                    }
+            }
         }
         __syncthreads();
-        if (has_next) { al.store(As); bl.store(Bs); }
+        if (has_next) {
+            if (MATH == 0) { al.store(As); bl.store(Bs); }
+            else { al.store_split(Ah); bl.store_split(Bh); }
+        }
         __syncthreads();
     }
 
@@ -634,6 +765,14 @@ __global__ __launch_bounds__(CS_THREADS) void lvt_colsum_kernel(const float *__r
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+static int g_math_mode = 1;     // 0: plain fp32 MFMA, 1: bf16x3 split MFMA (default)
+extern "C" int lvt_set_math_mode(int mode) {
+    LVT_REQUIRE(mode == 0 || mode == 1, "set_math_mode: unknown mode %d", mode);
+    g_math_mode = mode;
+    return LVT_OK;
+}
+extern "C" int lvt_get_math_mode(void) { return g_math_mode; }
+
 template <int AMODE, int BMODE, int BM, int BN, int WM, int WN>
 static int launch_tile(const KParams &p, int zcount, hipStream_t s) {
     const long long ntm = lvt_cdiv(p.M, BM), ntn = lvt_cdiv(p.N, BN);
@@ -642,7 +781,10 @@ static int launch_tile(const KParams &p, int zcount, hipStream_t s) {
         return LVT_EINVAL;
     }
     dim3 grid((unsigned)(ntm * ntn), (unsigned)zcount, (unsigned)(p.splits > 1 ? p.splits : 1));
-    hipLaunchKernelGGL((lvt_gemm_kernel<AMODE, BMODE, BM, BN, WM, WN>), grid, dim3(NTHREADS), 0, s, p);
+    if (g_math_mode == 1 && BK == 32)
+        hipLaunchKernelGGL((lvt_gemm_kernel<AMODE, BMODE, BM, BN, WM, WN, 1>), grid, dim3(NTHREADS), 0, s, p);
+    else
+        hipLaunchKernelGGL((lvt_gemm_kernel<AMODE, BMODE, BM, BN, WM, WN, 0>), grid, dim3(NTHREADS), 0, s, p);
     LVT_CHECK_LAUNCH("lvt_gemm_kernel");
     return LVT_OK;
 }

@@ -58,6 +58,8 @@ def _declare(lib):
         "lvt_last_error": (C.c_char_p, []),
         "lvt_version": (ci, []),
         "lvt_device_info": (ci, [C.c_char_p, ci, P(ci), P(ci), P(cll)]),
+        "lvt_set_math_mode": (ci, [ci]),
+        "lvt_get_math_mode": (ci, []),
         "lvt_gemm_workspace_bytes": (sz, [P(GemmDesc)]),
         "lvt_gemm_f32": (ci, [P(GemmDesc), vp, sz, vp]),
         "lvt_gemm_smallm_f32": (ci, [ci, ci, ci, ci, vp, cll, vp, cll, vp, cll, ci, cll, cll, cf, ci, vp, vp, cll, vp]),
@@ -121,7 +123,21 @@ def lib():
         handle = C.CDLL(_LIB_PATH)
         handle._lvt_sigs = _declare(handle)
         _lib = handle
+        mode = os.environ.get("LVT_MATH", "bf16x3")
+        if mode not in ("f32", "bf16x3"):
+            raise LvtError("LVT_MATH must be 'f32' or 'bf16x3' (got %r)" % mode)
+        handle.lvt_set_math_mode(1 if mode == "bf16x3" else 0)
     return _lib
+
+
+def set_math_mode(mode):
+    """'bf16x3' (default: exact 3-way bf16 split of fp32 operands on the bf16 matrix cores, fp32 accumulation) or
+    'f32' (plain fp32 MFMA).  Process-wide; also selectable with the LVT_MATH environment variable."""
+    check(lib().lvt_set_math_mode({"f32": 0, "bf16x3": 1}[mode]), "lvt_set_math_mode")
+
+
+def get_math_mode():
+    return ("f32", "bf16x3")[lib().lvt_get_math_mode()]
 
 
 def declared_symbols():

@@ -1,6 +1,7 @@
-"""GPU parity of the fp32 MFMA tile engine (GEMM / conv fwd / bwd-data / bwd-weight) against plain
+"""GPU parity of the MFMA tile engine (GEMM / conv fwd / bwd-data / bwd-weight) against plain
 torch-CPU fp32 ops (the ops the oracle is made of).  Tolerances: fp32 accumulate in a different
-order -> max-abs error relative to the output scale < 2e-5 (stated per test)."""
+order -> max-abs error relative to the output scale < 2e-5 (stated per test).  Every test runs in both
+arithmetic modes of the engine ('bf16x3', the default, and 'f32') at the SAME tolerance."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -9,6 +10,15 @@ from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
+
+
+@pytest.fixture(autouse=True, params=["bf16x3", "f32"])
+def math_mode(request):
+    from lvt_amd.hip import binding as L
+    before = L.get_math_mode()
+    L.set_math_mode(request.param)
+    yield request.param
+    L.set_math_mode(before)
 
 
 def _dev():
@@ -184,3 +194,34 @@ def test_conv3d_causal_geometry():
     assert rel_err(dx.permute(0, 4, 1, 2, 3), x.grad) < TOL
     dw = G.conv_bwd_weight(g, xd, gd, Ci, Co)
     assert rel_err(dw, w.grad) < 5e-5
+
+
+def test_math_modes_accuracy(math_mode):
+    """The split-bf16 mode is an fp32 computation: against an fp64 product its error (scaled by sum |a||b|, the
+    natural error unit of a dot product) must not exceed the plain fp32 MFMA path's by more than 25%, on normal,
+    all-positive, tiny and heavy-tailed operands; and both stay within 4 ulp-class bounds."""
+    from lvt_amd.hip import gemm as G, binding as L
+    if math_mode != "bf16x3":
+        pytest.skip("comparison test, run once")
+    d = _dev()
+    g = torch.Generator().manual_seed(5)
+    cases = {
+        "normal": (torch.randn(384, 4096, generator=g), torch.randn(256, 4096, generator=g)),
+        "positive": (torch.rand(384, 4096, generator=g), torch.rand(256, 4096, generator=g)),
+        "tiny": (torch.randn(384, 1024, generator=g) * 1e-6, torch.randn(256, 1024, generator=g) * 1e-5),
+        "heavy_tail": (torch.randn(384, 2048, generator=g) * torch.exp(3 * torch.randn(384, 2048, generator=g)),
+                       torch.randn(256, 2048, generator=g) * torch.exp(3 * torch.randn(256, 2048, generator=g))),
+    }
+    for name, (a, b) in cases.items():
+        ref = a.double() @ b.double().t()
+        unit = a.double().abs() @ b.double().abs().t()
+        err = {}
+        for mode in ("f32", "bf16x3"):
+            L.set_math_mode(mode)
+            out = torch.empty(a.shape[0], b.shape[0], device=d)
+            G.gemm(a.to(d), b.to(d), out, a.shape[0], b.shape[0], a.shape[1])
+            e = (out.double().cpu() - ref).abs() / unit
+            err[mode] = (float(e.pow(2).mean().sqrt()), float(e.max()))
+        assert err["bf16x3"][0] <= 1.25 * err["f32"][0], (name, err)
+        assert err["bf16x3"][1] <= 1.5 * err["f32"][1] + 1e-7, (name, err)
+        assert err["bf16x3"][1] < 1e-5, (name, err)
