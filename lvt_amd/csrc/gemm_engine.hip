@@ -603,19 +603,16 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
                     for (int j = 0; j < TN; ++j)
                         b[q][j] = *reinterpret_cast<const bf16x8 *>(Brh[j] + q * PSB + ks);
                 }
+                // term-major order: consecutive MFMAs go to different accumulators (TM*TN apart), so no MFMA
+                // waits on the result of its predecessor; small terms first (2^-16, then 2^-8, then the leading one)
+                constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int t = 0; t < 6; ++t)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        f32x16 c = acc[i][j];
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);   // 2^-16 terms first
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);   // 2^-8 terms
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);   // leading term
-                        acc[i][j] = c;
-                    }
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]][i], b[TB[t]][j], acc[i][j], 0, 0, 0);
             }
         }
         __syncthreads();

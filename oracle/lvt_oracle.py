@@ -246,19 +246,20 @@ class _StraightThrough(torch.autograd.Function):
 
 
 def vqvae_supervised_loss(enc, dec, cb_state, x, beta=1.0, lam=1.0, num=4, all_reduce=None,
-                          alias_running_sum=False, force_idx=None):
+                          alias_running_sum=False, force_idx=None, n_layers=2):
     """compute_supervised_loss (vqvae.py:66-91).  x already normalised, (N,3,H,W) or (B,T,3,H,W).
+    n_layers = residual blocks per side (2: PR-DVQVAE2, 4: K-DVQVAE).
 
     Returns (loss_dict, new_codebook_state, aux) with aux = dict(z_e, z_q_st, x_tilde, idx).
     """
     if x.dim() == 5:
         b, t, c, h, w = x.shape
         x = x.reshape(b * t, c, h, w)
-    z_e = res_encoder(enc, x)
+    z_e = res_encoder(enc, x, n_layers)
     z_q_st_val, z_q_bar, new_state, idx = dvq_straight_through(
         cb_state, z_e.detach(), num, all_reduce, alias_running_sum, force_idx)
     z_q_st = _StraightThrough.apply(z_e, z_q_st_val)
-    x_tilde = res_decoder(dec, z_q_st)
+    x_tilde = res_decoder(dec, z_q_st, n_layers)
     losses = {
         "loss_reconstruction": lam * F.mse_loss(x_tilde, x),
         "loss_commitment": beta * F.mse_loss(z_e, z_q_bar.detach()),
@@ -417,20 +418,32 @@ def multi_head_attention(p, pre, x, B, masked):
 
 
 def block_local_attention(p, pre, x, block, masked):
-    """BlockLocalAttention.forward, block == whole slice branch (vt_attention.py:182-188).
+    """BlockLocalAttention.forward (vt_attention.py:176-202).
 
-    x: (b, C, T, H, W) with (T,H,W) == block.  ffn = LN -> Linear -> ReLU -> Linear, + x (:138,186).
+    x: (b, C, T, H, W).  (T,H,W) == block: the whole slice is one block (:182-188).  Otherwise (:189-200) the
+    volume is cut into (T/t)*(H/h)*(W/w) blocks of (t,h,w) tokens that are attended independently (folded into
+    the batch dimension, block order (st, sh, sw)) and put back in place.
+    ffn = LN -> Linear -> ReLU -> Linear, + x (:138,186).
     """
     b, c, T, H, W = x.shape
-    assert (T, H, W) == tuple(block), "block-split branch (vt_attention.py:189-200) not restated"
-    tok = x.view(b, c, -1).transpose(1, 2).contiguous()
+    t, h, w = block
     B = rel_position_bias(p[pre + "dt_bank"], p[pre + "dh_bank"], p[pre + "dw_bank"], block)
-    tok = multi_head_attention(p, pre + "mha.", tok, B, masked)
-    f = layer_norm(tok, p[pre + "ffn.0.weight"], p[pre + "ffn.0.bias"])
-    f = torch.relu(F.linear(f, p[pre + "ffn.1.weight"], p[pre + "ffn.1.bias"]))
-    f = F.linear(f, p[pre + "ffn.3.weight"], p[pre + "ffn.3.bias"])
-    tok = f + tok
-    return tok.transpose(1, 2).contiguous().view(b, c, T, H, W)
+
+    def layer(tok):
+        tok = multi_head_attention(p, pre + "mha.", tok, B, masked)
+        f = layer_norm(tok, p[pre + "ffn.0.weight"], p[pre + "ffn.0.bias"])
+        f = torch.relu(F.linear(f, p[pre + "ffn.1.weight"], p[pre + "ffn.1.bias"]))
+        f = F.linear(f, p[pre + "ffn.3.weight"], p[pre + "ffn.3.bias"])
+        return f + tok
+
+    if (T, H, W) == (t, h, w):
+        tok = layer(x.view(b, c, -1).transpose(1, 2).contiguous())
+        return tok.transpose(1, 2).contiguous().view(b, c, T, H, W)
+    nt, nh, nw = T // t, H // h, W // w
+    xb = x.view(b, c, nt, t, nh, h, nw, w).permute(0, 2, 4, 6, 1, 3, 5, 7)      # b, nt, nh, nw, c, t, h, w
+    tok = layer(xb.reshape(b * nt * nh * nw, c, t * h * w).transpose(1, 2).contiguous())
+    xb = tok.transpose(1, 2).reshape(b, nt, nh, nw, c, t, h, w).permute(0, 4, 1, 5, 2, 6, 3, 7)
+    return xb.contiguous().view(b, c, T, H, W)
 
 
 # --------------------------------------------------------------------------------------------
@@ -455,8 +468,9 @@ def masked_conv3d(weight, bias, x):
 # --------------------------------------------------------------------------------------------
 # A9 / A11 / A15 / A16  the video transformer  (autoregressive/videotransformer.py)
 # --------------------------------------------------------------------------------------------
-def vt_encoder(p, context, slice_idx, blocks, stride, nv=512, pad_value=-1):
-    """VTEncoder.forward, class_num == 0 (videotransformer.py:35-59).
+def vt_encoder(p, context, slice_idx, blocks, stride, nv=512, pad_value=-1, class_idx=None):
+    """VTEncoder.forward (videotransformer.py:35-59).  With class_idx (class_num > 0, :54-56) the class
+    embedding is broadcast over the volume and concatenated on the channel axis before the 2*de -> d projector.
 
     context (b, nc, T', H, W) int64 with pads == pad_value.  One-hot (pads -> all-zero rows),
     Conv3d(nc*nv -> de, kernel, stride, bias), + slice_embedding, 1x1x1 projector (no bias),
@@ -471,6 +485,9 @@ def vt_encoder(p, context, slice_idx, blocks, stride, nv=512, pad_value=-1):
     w = p[pre + "conv.weight"]
     x = F.conv3d(oh.view(b, nc * nv, T, H, W).to(w.dtype), w, p[pre + "conv.bias"], stride=stride)
     x = x + F.embedding(slice_idx, p[pre + "slice_embedding.weight"])[:, :, None, None, None]
+    if class_idx is not None:
+        ce = F.embedding(class_idx, p[pre + "class_embedding.weight"])[:, :, None, None, None].expand_as(x)
+        x = torch.cat([x, ce], dim=1)
     x = F.conv3d(x, p[pre + "linear_projector.weight"])
     for i, blk in enumerate(blocks):
         x = block_local_attention(p, pre + "block_local_attention.%d." % i, x, blk, masked=False)
@@ -545,9 +562,9 @@ def channel_predictor_pixel_probs(p, yl, pixel, uniforms, nv=512, temp=1.0):
 
 
 def video_transformer_logits(p, context, sl, slice_idx, blocks_e, blocks_d, stride, nv=512,
-                             pad_value=-1, return_hidden=False):
+                             pad_value=-1, return_hidden=False, class_idx=None):
     """VideoTransformer.forward mode='logits' (videotransformer.py:231-239)."""
-    zl = vt_encoder(p, context, slice_idx, blocks_e, stride, nv, pad_value)
+    zl = vt_encoder(p, context, slice_idx, blocks_e, stride, nv, pad_value, class_idx)
     yl = vt_decoder(p, sl, zl, blocks_d)
     pred = channel_predictor_logits(p, sl, yl, nv)
     return (pred, zl, yl) if return_hidden else pred
@@ -557,10 +574,10 @@ def video_transformer_logits(p, context, sl, slice_idx, blocks_e, blocks_d, stri
 # A17 / A18  transformer meta-architecture     (meta_arch/vt.py:230-314)
 # --------------------------------------------------------------------------------------------
 def vt_supervised_loss(p, context, sl, slice_idx, ignore_mask, blocks_e, blocks_d, stride, nv=512,
-                       ignore_index=-100):
+                       ignore_index=-100, class_idx=None):
     """compute_supervised_loss (vt.py:301-314): mean_k CE(pred_k, target_k, ignore_index)."""
     target = sl.masked_fill(ignore_mask, ignore_index)
-    pred = video_transformer_logits(p, context, sl, slice_idx, blocks_e, blocks_d, stride, nv)
+    pred = video_transformer_logits(p, context, sl, slice_idx, blocks_e, blocks_d, stride, nv, class_idx=class_idx)
     loss = 0
     for k in range(len(pred)):
         loss = loss + F.cross_entropy(pred[k], target[:, k], ignore_index=ignore_index)
@@ -568,7 +585,7 @@ def vt_supervised_loss(p, context, sl, slice_idx, ignore_mask, blocks_e, blocks_
 
 
 def vt_logits_for_entire_video(p, video_btchw, blocks_e, blocks_d, stride, kernel, nv=512,
-                               pad_value=-1):
+                               pad_value=-1, class_idx=None):
     """calculate_logits_for_entire_video (vt.py:230-282): (B,T,nc,H,W) codes -> (B,nc,nv,T,H,W)."""
     video = video_btchw.transpose(1, 2).contiguous()
     B, nc, T, H, W = video.shape
@@ -583,7 +600,7 @@ def vt_logits_for_entire_video(p, video_btchw, blocks_e, blocks_d, stride, kerne
         ctx = ss_shift(video.masked_fill(~vmask, pad_value), a, b, c, st, sh, sw, T, H, W, *kernel,
                        pad_value=pad_value)
         pred = video_transformer_logits(p, ctx, sl, torch.full((B,), si, dtype=torch.long),
-                                        blocks_e, blocks_d, stride, nv, pad_value)
+                                        blocks_e, blocks_d, stride, nv, pad_value, class_idx=class_idx)
         for k in range(nc):
             logits[:, k] = logits[:, k].masked_scatter(smask, pred[k].reshape(-1))
     return logits

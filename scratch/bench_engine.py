@@ -44,3 +44,6 @@ print("QK^T b64h8          %7.1f us %6.1f TF" % (t * 1e3, 2 * 512 * 256 * 256 * 
 wq = torch.randn(8, 512, 128, device=dev)
 t = timeit(lambda: G.gemm(x, wq, q, M, 128, 512, ta=0, tb=1, lda=512, ldb=128, ldc=1024, batch_inner=8, sB=(0, 65536), sC=(0, 128)))
 print("QKV proj (8 heads)  %7.1f us %6.1f TF" % (t * 1e3, 2 * M * 1024 * 512 / t / 1e9))
+Mb = 8192
+xb = torch.randn(Mb, 4096, device=dev); wb = torch.randn(8192, 4096, device=dev); ob = torch.empty(Mb, 8192, device=dev)
+t = timeit(lambda: G.gemm(xb, wb, ob, Mb, 8192, 4096), 5); print("NT big 8192x8192x4096 %7.1f us %6.1f TF" % (t * 1e3, 2 * Mb * 8192 * 4096 / t / 1e9))

@@ -329,9 +329,116 @@ def golden_vt():
          ignore_mask=out["ignore_mask"])
 
 
+# ------------------------------------------------------------------------------------------------
+def golden_variants():
+    """G15-G18: the other shipped shapes -- DSSVT (spatial subscaling, block-split attention at test length),
+    DSTSVT (spatio-temporal subscaling), class-conditional DSFVT (CLASS_NUM > 0), K-DVQVAE (4 residual blocks)."""
+    from vidgen.modeling.meta_arch.build import build_model
+    import vidgen.modeling.meta_arch  # noqa: F401
+    from vidgen.data.dataset_mapper import DatasetMapper
+    from vidgen.utils.events import EventStorage
+    import random
+
+    SEED = 777
+    real_randint = random.randint
+
+    def vt_case(tag, cfg_path, block, kernel, n_slices, frames, abcs, class_num=0, classes=None, eval_frames=0):
+        over = {"MODEL.AUTOREGRESSIVE.VT.CLASS_NUM": class_num} if class_num else {}
+        cfg = ref_cfg(cfg_path, **over)
+        model = build_model(cfg)
+        vt = model.model
+        params = seeded.seeded_params(seeded.dsfvt_shapes(block=block, kernel=kernel, n_slices=n_slices,
+                                                          class_num=class_num), SEED)
+        load_into(vt, params)
+        mapper = DatasetMapper(cfg, True)
+        codes = [seeded.seeded_codes("%s.codes%d" % (tag, i), (frames, 4, 16, 16), SEED).numpy() for i in range(len(abcs))]
+        data = []
+        for i, (a, b, c) in enumerate(abcs):
+            seq = iter([0, a, b, c])          # start_end() draws first (dataset_mapper.py:44), then a, b, c
+            random.randint = lambda lo, hi: next(seq)
+            try:
+                d = {"image_sequence": codes[i].copy()}
+                if classes is not None:
+                    d["class"] = int(classes[i])
+                data.append(mapper(d))
+            finally:
+                random.randint = real_randint
+        model.train()
+        vt.zero_grad()
+        with EventStorage(0):
+            losses = model(data, mode="supervised")
+        losses["loss_cross_entropy"].backward()
+        with torch.no_grad():
+            ctx = torch.stack([d["context"] for d in data])
+            slc = torch.stack([d["slice"] for d in data])
+            sidx = torch.stack([d["slice_idx"] for d in data])
+            cls = torch.stack([d["class"] for d in data]) if classes is not None else None
+            zl = vt.encoder(ctx, sidx, class_idx=cls)
+            pred = vt.ch_predictor(slc, vt.decoder(slc, zl), mode="logits")
+        names = [n for n, _ in vt.named_parameters()]
+        gd = dict(vt.named_parameters())
+        out = dict(seed=SEED, codes=np.stack(codes), abc=np.array(abcs), loss=losses["loss_cross_entropy"],
+                   context=ctx, slice_idx=sidx, zl_slice=zl[:, ::16, :, ::3, ::3],
+                   logits0_slice=pred[0][:, ::8, :, ::3, ::3], logits3_slice=pred[3][:, ::8, :, ::3, ::3],
+                   grad_names=np.array(names), grad_norms=np.array([float(p.grad.norm()) for _, p in vt.named_parameters()]),
+                   grad_enc_conv_rows=gd["encoder.conv.weight"].grad[:2],
+                   grad_slice_emb=gd["encoder.slice_embedding.weight"].grad,
+                   grad_dec3_dt=gd["decoder.block_local_attention.3.dt_bank"].grad,
+                   grad_enc_proj_rows=gd["encoder.linear_projector.weight"].grad[:4, :, 0, 0, 0])
+        if classes is not None:
+            out["classes"] = np.array(classes)
+            out["grad_class_emb"] = gd["encoder.class_embedding.weight"].grad
+        if eval_frames:
+            cfg.TEST.EVALUATORS = "BitsEvaluator"
+            model.eval()
+            vid = seeded.seeded_codes(tag + ".eval", (eval_frames, 4, 16, 16), SEED)
+            with torch.no_grad():
+                o = model([{"image_sequence": vid}], mode="inference")[0]
+            lg = o["logits"]
+            nll = torch.nn.functional.cross_entropy(lg.permute(1, 0, 2, 3, 4)[None], vid.transpose(0, 1)[None],
+                                                    reduction="none")[0]
+            out.update(eval_video=vid, eval_logits_slice=lg[:, ::64, ::3, ::5, ::5], eval_nll=nll,
+                       eval_ignore_mask=o["ignore_mask"])
+        save(tag, **out)
+
+    # G15 DSSVT: stride (1,2,2), kernel (1,3,3), 4-frame training clips -> slices (4,8,8); at the 16-frame test
+    # length the slice is (16,8,8) and every attention layer runs block-split over four (4,8,8) blocks
+    vt_case("g15_dssvt", "configs/vt/DSSVT.yaml", (4, 8, 8), (1, 3, 3), 4, 4, [(0, 1, 0), (0, 1, 1)], eval_frames=16)
+    # G16 DSTSVT: stride (4,2,2), kernel (5,3,3), 16-frame clips -> slices (4,8,8)
+    vt_case("g16_dstsvt", "configs/vt/DSTSVT.yaml", (4, 8, 8), (5, 3, 3), 16, 16, [(2, 1, 0), (3, 0, 1)])
+    # G17 class-conditional DSFVT (CLASS_NUM 10)
+    vt_case("g17_dsfvt_class", "configs/vt/DSFVT.yaml", (1, 16, 16), (7, 1, 1), 16, 16, [(5, 0, 0), (12, 0, 0)],
+            class_num=10, classes=[3, 7])
+
+    # G18 K-DVQVAE: 4 residual blocks in encoder and decoder, frame mode, B = 2 frames
+    cfg = ref_cfg("configs/vqvae/K-DVQVAE.yaml")
+    model = build_model(cfg)
+    es, ds = seeded.vqvae_shapes(4)
+    load_into(model.encoder, seeded.seeded_params(es, SEED, "enc."))
+    load_into(model.generator, seeded.seeded_params(ds, SEED, "dec."))
+    state = seeded.seeded_codebook_state(SEED, scale=0.6)
+    dealias_codebook(model.codebook, state)
+    x = seeded.seeded_input("g18.x", (2, 3, 64, 64), SEED)
+    model.train()
+    with EventStorage(0):
+        losses = model([{"image": x[i].numpy()} for i in range(2)], mode="supervised")
+    sum(losses.values()).backward()
+    ge, gg = dict(model.encoder.named_parameters()), dict(model.generator.named_parameters())
+    with torch.no_grad():
+        z_e = model.encoder(model.normalizer(x))
+    save("g18_kdvqvae", seed=SEED, x=x, z_e_slice=z_e[:, ::8, ::2, ::2],
+         **{k: v for k, v in losses.items()},
+         enc_grad_norms=np.array([float(p.grad.norm()) for p in ge.values()]), enc_grad_names=np.array(list(ge)),
+         dec_grad_norms=np.array([float(p.grad.norm()) for p in gg.values()]), dec_grad_names=np.array(list(gg)),
+         grad_enc_l8_b3=ge["layers.8.block.3.weight"].grad[:8, :, 0, 0], grad_dec_l8_rows=gg["layers.8.weight"].grad[:2],
+         **{"new_" + k: v for k, v in cb_state_of(model.codebook).items() if "running_size" in k})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["vqvae", "vt"]
+    which = sys.argv[1:] or ["vqvae", "vt", "variants"]
     if "vqvae" in which:
         golden_vqvae()
     if "vt" in which:
         golden_vt()
+    if "variants" in which:
+        golden_variants()

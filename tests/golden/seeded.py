@@ -32,6 +32,26 @@ VQVAE_DECODER_SHAPES = {
 }
 
 
+def vqvae_shapes(n_layers=2):
+    """(encoder, decoder) state_dict shapes of ResEncoder / ResDecoder (stride 4) with n_layers residual blocks
+    (2: PR-DVQVAE2, 4: K-DVQVAE)."""
+    enc = {"layers.0.weight": (128, 3, 4, 4), "layers.0.bias": (128,),
+           "layers.2.weight": (256, 128, 4, 4), "layers.2.bias": (256,),
+           "layers.4.weight": (256, 256, 3, 3), "layers.4.bias": (256,)}
+    dec = {"layers.0.weight": (256, 256, 3, 3), "layers.0.bias": (256,)}
+    for i in range(n_layers):
+        for pre, d in (("layers.%d." % (5 + i), enc), ("layers.%d." % (1 + i), dec)):
+            d[pre + "block.1.weight"] = (128, 256, 3, 3)
+            d[pre + "block.1.bias"] = (128,)
+            d[pre + "block.3.weight"] = (256, 128, 1, 1)
+            d[pre + "block.3.bias"] = (256,)
+    dec["layers.%d.weight" % (n_layers + 2)] = (256, 128, 4, 4)      # ConvTranspose2d (in,out,k,k)
+    dec["layers.%d.bias" % (n_layers + 2)] = (128,)
+    dec["layers.%d.weight" % (n_layers + 4)] = (128, 3, 4, 4)
+    dec["layers.%d.bias" % (n_layers + 4)] = (3,)
+    return enc, dec
+
+
 def _rng(seed, name):
     return np.random.default_rng([int(seed), zlib.crc32(name.encode())])
 
@@ -82,12 +102,15 @@ def seeded_codes(name, shape, seed, nv=512):
 
 
 def dsfvt_shapes(nc=4, nv=512, de=128, d=512, da=128, na=8, n_enc=8, n_dec=8, block=(1, 16, 16),
-                 kernel=(7, 1, 1), n_slices=16):
-    """state_dict parameter shapes of VideoTransformer for the DSFVT config (parameters only)."""
+                 kernel=(7, 1, 1), n_slices=16, class_num=0):
+    """state_dict parameter shapes of VideoTransformer (parameters only).  Defaults: DSFVT; DSSVT is
+    block (4,8,8), kernel (1,3,3), n_slices 4; DSTSVT is block (4,8,8), kernel (5,3,3), n_slices 16."""
     t, h, w = block
     s = {"encoder.conv.weight": (de, nc * nv) + tuple(kernel), "encoder.conv.bias": (de,),
          "encoder.slice_embedding.weight": (n_slices, de),
-         "encoder.linear_projector.weight": (d, de, 1, 1, 1)}
+         "encoder.linear_projector.weight": (d, de * (2 if class_num > 0 else 1), 1, 1, 1)}
+    if class_num > 0:
+        s["encoder.class_embedding.weight"] = (class_num, de)
     for i in range(nc):
         s["decoder.ch_embedder.%d.weight" % i] = (nv, de)
     s["decoder.conv.conv.weight"] = (d, de, 3, 3, 3)

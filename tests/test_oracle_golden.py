@@ -249,3 +249,85 @@ def test_g14_entire_video_logits(golden, vtp):
     tgt = codes.transpose(0, 1)
     nll = torch.nn.functional.cross_entropy(lg.permute(1, 0, 2, 3, 4)[None], tgt[None], reduction="none")[0]
     assert rel_err(nll, g["nll"]) < 1e-4
+
+
+# ---- G15-G18: the other shipped shapes ---------------------------------------------------------------------
+VARIANTS = {
+    "g15_dssvt": dict(block=(4, 8, 8), kernel=(1, 3, 3), stride=(1, 2, 2), n_slices=4),
+    "g16_dstsvt": dict(block=(4, 8, 8), kernel=(5, 3, 3), stride=(4, 2, 2), n_slices=16),
+    "g17_dsfvt_class": dict(block=(1, 16, 16), kernel=(7, 1, 1), stride=(16, 1, 1), n_slices=16, class_num=10),
+}
+
+
+def variant_case(g, tag):
+    """-> (params, batch tensors, geometry kwargs) of a G15-G17 fixture."""
+    v = VARIANTS[tag]
+    seed = int(g["seed"])
+    params = seeded.seeded_params(seeded.dsfvt_shapes(block=v["block"], kernel=v["kernel"], n_slices=v["n_slices"],
+                                                      class_num=v.get("class_num", 0)), seed)
+    data = [O.prepare_slices(g["codes"][i], tuple(int(x) for x in g["abc"][i]), v["stride"], v["kernel"], 1)
+            for i in range(g["codes"].shape[0])]
+    batch = tuple(torch.stack([d[k] for d in data]) for k in ("context", "slice", "slice_idx", "ignore_mask"))
+    geo = dict(blocks_e=(v["block"],) * 8, blocks_d=(v["block"],) * 8, stride=v["stride"])
+    cls = g["classes"].long() if "class_num" in v else None
+    return params, batch, geo, cls
+
+
+@pytest.mark.parametrize("tag", sorted(VARIANTS))
+def test_g15_g17_variant_loss_and_grads(golden, tag):
+    g = golden(tag)
+    params, (ctx, sl, si, ig), geo, cls = variant_case(g, tag)
+    assert torch.equal(ctx, g["context"]) and torch.equal(si, g["slice_idx"])
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    loss, pred = O.vt_supervised_loss(p, ctx, sl, si, ig, class_idx=cls, **geo)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 2e-5 * float(g["loss"])
+    assert rel_err(pred[0][:, ::8, :, ::3, ::3], g["logits0_slice"]) < 1e-4
+    assert rel_err(pred[3][:, ::8, :, ::3, ::3], g["logits3_slice"]) < 1e-4
+    names = [str(n) for n in g["grad_names"]]
+    norms = torch.tensor([float(p[n].grad.norm()) for n in names], dtype=torch.float64)
+    ref = g["grad_norms"].double()
+    assert float(((norms - ref).abs() / (ref + 1e-6)).max()) < 1e-3
+    assert rel_err(p["encoder.conv.weight"].grad[:2], g["grad_enc_conv_rows"]) < 1e-4
+    assert rel_err(p["encoder.slice_embedding.weight"].grad, g["grad_slice_emb"]) < 1e-4
+    if VARIANTS[tag]["block"][0] > 1:      # for t == 1 the bank is a per-head constant shift: gradient exactly 0
+        assert rel_err(p["decoder.block_local_attention.3.dt_bank"].grad, g["grad_dec3_dt"]) < 1e-4
+    assert rel_err(p["encoder.linear_projector.weight"].grad[:4, :, 0, 0, 0], g["grad_enc_proj_rows"]) < 1e-4
+    if cls is not None:
+        assert rel_err(p["encoder.class_embedding.weight"].grad, g["grad_class_emb"]) < 1e-4
+
+
+def test_g15_block_split_entire_video_logits(golden):
+    """DSSVT at the 16-frame test length: slices are (16,8,8), every layer attends within (4,8,8) blocks."""
+    g = golden("g15_dssvt")
+    params, _, geo, _ = variant_case(g, "g15_dssvt")
+    with torch.no_grad():
+        lg = O.vt_logits_for_entire_video(params, g["eval_video"][None], kernel=(1, 3, 3), **geo)[0]
+    assert rel_err(lg[:, ::64, ::3, ::5, ::5], g["eval_logits_slice"]) < 1e-4
+    nll = torch.nn.functional.cross_entropy(lg.permute(1, 0, 2, 3, 4)[None], g["eval_video"].transpose(0, 1)[None],
+                                            reduction="none")[0]
+    assert rel_err(nll, g["eval_nll"]) < 1e-4
+
+
+def test_g18_kdvqvae_loss_and_grads(golden):
+    g = golden("g18_kdvqvae")
+    seed = int(g["seed"])
+    es, ds = seeded.vqvae_shapes(4)
+    enc, dec = seeded.seeded_params(es, seed, "enc."), seeded.seeded_params(ds, seed, "dec.")
+    for p in list(enc.values()) + list(dec.values()):
+        p.requires_grad_(True)
+    st0 = seeded.seeded_codebook_state(seed, scale=0.6)
+    losses, new, aux = O.vqvae_supervised_loss(enc, dec, st0, O.normalize(g["x"], MEAN, STD), n_layers=4)
+    sum(losses.values()).backward()
+    assert abs(float(losses["loss_reconstruction"]) - float(g["loss_reconstruction"])) < 1e-6
+    assert abs(float(losses["loss_commitment"]) - float(g["loss_commitment"])) < 1e-6 * float(g["loss_commitment"]) + 1e-6
+    assert rel_err(aux["z_e"][:, ::8, ::2, ::2], g["z_e_slice"]) < 1e-5
+    for side, params, pre in (("enc", enc, "enc"), ("dec", dec, "dec")):
+        names = [str(n) for n in g[pre + "_grad_names"]]
+        norms = torch.tensor([float(params[n].grad.norm()) for n in names], dtype=torch.float64)
+        ref = g[pre + "_grad_norms"].double()
+        assert float(((norms - ref).abs() / (ref + 1e-9)).max()) < 1e-3, side
+    assert rel_err(enc["layers.8.block.3.weight"].grad[:8, :, 0, 0], g["grad_enc_l8_b3"]) < 1e-4
+    assert rel_err(dec["layers.8.weight"].grad[:2], g["grad_dec_l8_rows"]) < 1e-4
+    for i in range(4):
+        assert rel_err(new["ve.%d.running_size" % i], g["new_ve.%d.running_size" % i]) < 1e-6
