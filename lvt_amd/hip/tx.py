@@ -4,6 +4,7 @@ import ctypes as C
 import torch
 
 from . import binding as L
+from . import ew
 
 
 def _iarr(vals):
@@ -32,8 +33,10 @@ def attn_softmax_bwd_(P, dP, temper, block):
     return ddt, ddh, ddw
 
 
-def embbag_fwd(idx, bstride, P, rows, slot_off, tab_row, table, D, bias=None, btable=None, bindex=None):
-    L.require(idx, table, bias, btable, bindex)
+MAX_SLOTS = 32          # slot tables travel as kernel arguments (BagSlots / KParams.oh_off)
+
+
+def _embbag_once(idx, bstride, P, rows, slot_off, tab_row, table, D, bias, btable, bindex):
     out = torch.empty(rows, D, dtype=torch.float32, device=idx.device)
     L.check(L.lib().lvt_embbag_fwd(L.ptr(idx), bstride, P, rows, len(slot_off), _iarr(slot_off), _iarr(tab_row),
                                    L.ptr(table), D, L.ptr(bias), L.ptr(btable), L.ptr(bindex), L.ptr(out),
@@ -41,9 +44,19 @@ def embbag_fwd(idx, bstride, P, rows, slot_off, tab_row, table, D, bias=None, bt
     return out
 
 
-def onehot_tn_gemm(idx, V, slot_off, bstride, pstride, P, rows, dout, N, ldb=None):
-    """-> (nslots*V, N) gradient of the gathered table."""
-    L.require(idx, dout)
+def embbag_fwd(idx, bstride, P, rows, slot_off, tab_row, table, D, bias=None, btable=None, bindex=None):
+    """Bags wider than MAX_SLOTS (the (kt,kh,kw) x nc taps of the DSSVT / DSTSVT context conv) are summed in
+    MAX_SLOTS-wide pieces; the piece order is fixed, so the result is reproducible."""
+    L.require(idx, table, bias, btable, bindex)
+    out = _embbag_once(idx, bstride, P, rows, slot_off[:MAX_SLOTS], tab_row[:MAX_SLOTS], table, D, bias, btable, bindex)
+    for s in range(MAX_SLOTS, len(slot_off), MAX_SLOTS):
+        part = _embbag_once(idx, bstride, P, rows, slot_off[s:s + MAX_SLOTS], tab_row[s:s + MAX_SLOTS], table, D,
+                            None, None, None)
+        out = ew.axpy(part, add=out)
+    return out
+
+
+def _onehot_once(idx, V, slot_off, bstride, pstride, P, rows, dout, N, ldb):
     lib = L.lib()
     ns = len(slot_off)
     out = torch.empty(ns * V, N, dtype=torch.float32, device=dout.device)
@@ -56,6 +69,15 @@ def onehot_tn_gemm(idx, V, slot_off, bstride, pstride, P, rows, dout, N, ldb=Non
     if t0 is not None:
         L.TIMER.end("gemm_onehot_tn", 2.0 * ns * V * N * rows, t0)
     return out
+
+
+def onehot_tn_gemm(idx, V, slot_off, bstride, pstride, P, rows, dout, N, ldb=None):
+    """-> (nslots*V, N) gradient of the gathered table."""
+    L.require(idx, dout)
+    if len(slot_off) <= MAX_SLOTS:
+        return _onehot_once(idx, V, slot_off, bstride, pstride, P, rows, dout, N, ldb)
+    return torch.cat([_onehot_once(idx, V, slot_off[s:s + MAX_SLOTS], bstride, pstride, P, rows, dout, N, ldb)
+                      for s in range(0, len(slot_off), MAX_SLOTS)], 0)
 
 
 def permute3(x, strides, shape):

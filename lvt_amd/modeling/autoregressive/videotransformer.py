@@ -46,50 +46,88 @@ class MaskedConv3d(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # encoder front end: one-hot Conv3d (as a gather) + slice embedding + 1x1x1 projector
 # ------------------------------------------------------------------------------------------------
+def _flat_tail(w, offset):
+    """1-D view of a contiguous weight starting `offset` floats in (a column block of a row-major matrix; the
+    GEMM addresses it through its leading dimension)."""
+    return w.reshape(-1)[offset:]
+
+
 class _EncoderFrontFn(torch.autograd.Function):
+    """one-hot -> Conv3d(nc*nv -> de, kernel, stride, bias) -> + slice embedding -> [cat class embedding] ->
+    1x1x1 projector, token-major (videotransformer.py:35-57).  Slot (tap, channel) of the bag reads one code;
+    pads (negative codes) contribute nothing."""
+
     @staticmethod
-    def forward(ctx, context, slice_idx, conv_w, conv_b, slice_emb, proj_w, nv):
-        L.require(context, slice_idx)
-        b, nc, kt, H, W = context.shape
-        de = conv_w.shape[0]
-        d = proj_w.shape[0]
-        P = H * W
+    def forward(ctx, context, slice_idx, class_idx, conv_w, conv_b, slice_emb, class_emb, proj_w, nv, stride):
+        L.require(context, slice_idx, class_idx)
+        b, nc, T, H, W = context.shape
+        de, d = conv_w.shape[0], proj_w.shape[0]
+        kt, kh, kw = conv_w.shape[2:]
+        st, sh, sw = stride
+        KK = kt * kh * kw
+        if kh == 1 and kw == 1 and T == kt:
+            # DSFVT: one output frame, pointwise in space -> slot (tau, c) indexes the context tensor directly
+            thw = (1, H, W)
+            P = H * W
+            idx, bstride = context, nc * kt * P
+            off = [(c * kt + tau) * P for tau in range(kt) for c in range(nc)]
+        else:
+            # general kernel / stride: im2col of the integer codes (index plumbing, no arithmetic):
+            # (b, kt, kh, kw, nc, to, ho, wo), slot = (tap, c)
+            idx = context.unfold(2, kt, st).unfold(3, kh, sh).unfold(4, kw, sw).permute(0, 5, 6, 7, 1, 2, 3, 4).contiguous()
+            thw = tuple(idx.shape[5:])
+            P = thw[0] * thw[1] * thw[2]
+            bstride = KK * nc * P
+            off = [s_ * P for s_ in range(KK * nc)]
         rows = b * P
-        # conv weight (de, nc*nv, kt,1,1) -> packed (kt, nc*nv, de): row (tau*nc + c)*nv + code
-        wt = tx.permute3(conv_w, (1, kt, nc * nv * kt), (kt, nc * nv, de))
-        slots = [(tau, c) for tau in range(kt) for c in range(nc)]
-        off = [(c * kt + tau) * P for tau, c in slots]
-        tab = [(tau * nc + c) * nv for tau, c in slots]
-        e = tx.embbag_fwd(context, nc * kt * P, P, rows, off, tab, wt, de, bias=conv_b, btable=slice_emb,
-                          bindex=slice_idx)
+        # conv weight (de, nc*nv, kt,kh,kw) -> packed (KK, nc*nv, de): row (tap*nc + c)*nv + code
+        wt = tx.permute3(conv_w, (1, KK, nc * nv * KK), (KK, nc * nv, de))
+        tab = [s_ * nv for s_ in range(KK * nc)]
+        e = tx.embbag_fwd(idx, bstride, P, rows, off, tab, wt, de, bias=conv_b, btable=slice_emb, bindex=slice_idx)
         z = torch.empty(rows, d, dtype=torch.float32, device=e.device)
-        G.gemm(e, proj_w, z, rows, d, de)
-        ctx.save_for_backward(context, slice_idx, e, proj_w)
-        ctx.geo = (b, nc, kt, P, de, d, nv, off, slice_emb.shape[0])
+        ce = None
+        if class_idx is None:
+            G.gemm(e, proj_w, z, rows, d, de)
+        else:
+            # cat([x, class_emb], channel) @ W^T == x @ W[:, :de]^T + class_emb[cls] @ W[:, de:]^T
+            z1 = torch.empty(rows, d, dtype=torch.float32, device=e.device)
+            G.gemm(e, proj_w, z1, rows, d, de, ldb=2 * de)
+            ce = tx.embbag_fwd(class_idx.repeat_interleave(P).contiguous(), 0, rows, rows, [0], [0], class_emb, de)
+            G.gemm(ce, _flat_tail(proj_w, de), z, rows, d, de, ldb=2 * de, flags=L.EPI_RESIDUAL, res=z1)
+        ctx.save_for_backward(idx, slice_idx, class_idx, e, ce, proj_w)
+        ctx.geo = (b, nc, (kt, kh, kw), P, de, d, nv, off, bstride, slice_emb.shape[0],
+                   class_emb.shape[0] if class_emb is not None else 0)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        context, slice_idx, e, proj_w = ctx.saved_tensors
-        b, nc, kt, P, de, d, nv, off, n_slices = ctx.geo
+        idx, slice_idx, class_idx, e, ce, proj_w = ctx.saved_tensors
+        b, nc, (kt, kh, kw), P, de, d, nv, off, bstride, n_slices, n_classes = ctx.geo
+        KK = kt * kh * kw
         rows = b * P
         dz = dz.contiguous()
+        ldp = de if class_idx is None else 2 * de
         de_ = torch.empty(rows, de, dtype=torch.float32, device=dz.device)
-        G.gemm(dz, proj_w, de_, rows, de, d, ta=0, tb=1, ldb=de)
-        dproj = linear_wgrad(dz, e, d, de, rows).view(d, de, 1, 1, 1)
+        G.gemm(dz, proj_w, de_, rows, de, d, ta=0, tb=1, ldb=ldp)
+        dproj = linear_wgrad(dz, e, d, de, rows)
+        dclass = None
+        if class_idx is not None:
+            dce = torch.empty(rows, de, dtype=torch.float32, device=dz.device)
+            G.gemm(dz, _flat_tail(proj_w, de), dce, rows, de, d, ta=0, tb=1, ldb=ldp)
+            dproj = torch.cat([dproj, linear_wgrad(dz, ce, d, de, rows)], 1)
+            dclass = tx.onehot_tn_gemm(class_idx, (n_classes + 3) // 4 * 4, [0], 1, 0, P, rows, dce, de)[:n_classes].contiguous()
+        dproj = dproj.view(d, ldp, 1, 1, 1)
         dbias = G.colsum(de_, rows, de)
         # slice embedding: one index per sample (position stride 0)
         dslice = tx.onehot_tn_gemm(slice_idx, (n_slices + 3) // 4 * 4, [0], 1, 0, P, rows, de_, de)[:n_slices]
-        dwt = tx.onehot_tn_gemm(context, nv, off, nc * kt * P, 1, P, rows, de_, de)      # (kt*nc*nv, de)
-        dconv = tx.permute3(dwt, (1, de, nc * nv * de), (de, nc * nv, kt)).view(de, nc * nv, kt, 1, 1)
-        return None, None, dconv, dbias, dslice.contiguous(), dproj, None
+        dwt = tx.onehot_tn_gemm(idx, nv, off, bstride, 1, P, rows, de_, de)                  # (KK*nc*nv, de)
+        dconv = tx.permute3(dwt, (1, de, nc * nv * de), (de, nc * nv, KK)).view(de, nc * nv, kt, kh, kw)
+        return None, None, None, dconv, dbias, dslice.contiguous(), dclass, dproj, None, None
 
 
 class VTEncoder(nn.Module):
     def __init__(self, nc, nv, da, de, d, blocks, n_heads, kernel_size, stride, pad_value=-1, class_num=0):
         super().__init__()
-        if class_num > 0:
-            raise NotImplementedError("class-conditional encoder (CLASS_NUM > 0) is not used by the BAIR configs")
         self.nc, self.nv, self.stride, self.pad_value, self.class_num = nc, nv, tuple(stride), pad_value, class_num
         self.kernel_size = tuple(kernel_size)
         self.conv = nn.Conv3d(nc * nv, de, kernel_size, stride, bias=True)
@@ -98,24 +136,36 @@ class VTEncoder(nn.Module):
                                                      for blk, nh in zip(blocks, n_heads)])
         st, sh, sw = stride
         self.slice_embedding = nn.Embedding(st * sh * sw, de)
-        self.linear_projector = nn.Conv3d(de, d, 1, bias=False)
+        if class_num > 0:
+            self.class_embedding = nn.Embedding(class_num, de)
+            self.linear_projector = nn.Conv3d(2 * de, d, 1, bias=False)
+        else:
+            self.linear_projector = nn.Conv3d(de, d, 1, bias=False)
 
-    def forward_tokens(self, context, slice_idx):
-        """context (b, nc, kt, H, W) int64 -> token-major (b*H*W, d)."""
-        b, nc, T, H, W = context.shape
-        kt, kh, kw = self.kernel_size
-        if not (kh == 1 and kw == 1 and T == kt):
-            raise NotImplementedError("only (kt,1,1) context kernels with a single output frame (DSFVT/KDSFVT) are built")
-        z = _EncoderFrontFn.apply(context.contiguous(), slice_idx.contiguous(), self.conv.weight, self.conv.bias,
-                                  self.slice_embedding.weight, self.linear_projector.weight, self.nv)
+    def out_thw(self, context_shape):
+        T, H, W = context_shape[2:]
+        (kt, kh, kw), (st, sh, sw) = self.kernel_size, self.stride
+        return ((T - kt) // st + 1, (H - kh) // sh + 1, (W - kw) // sw + 1)
+
+    def forward_tokens(self, context, slice_idx, class_idx=None):
+        """context (b, nc, T', H', W') int64 (already shifted / padded for the conv) -> token-major (b*t*h*w, d)."""
+        if self.pad_value >= 0:
+            raise L.LvtError("PAD_VALUE must be negative (the gather skips negative codes)")
+        use_class = self.class_num > 0 and class_idx is not None
+        z = _EncoderFrontFn.apply(context.contiguous(), slice_idx.contiguous(),
+                                  class_idx.contiguous() if use_class else None, self.conv.weight, self.conv.bias,
+                                  self.slice_embedding.weight, self.class_embedding.weight if use_class else None,
+                                  self.linear_projector.weight, self.nv, self.stride)
+        thw = self.out_thw(context.shape)
         for layer in self.block_local_attention:
-            z = layer.forward_tokens(z)
+            z = layer.forward_tokens(z, thw)
         return z
 
     def forward(self, x, slice_idx, class_idx=None):
-        b, nc, T, H, W = x.shape
-        z = self.forward_tokens(x, slice_idx)
-        return convstack._TokensOut.apply(z, b, z.shape[-1], 1, H, W)
+        b = x.shape[0]
+        z = self.forward_tokens(x, slice_idx, class_idx)
+        t, h, w = self.out_thw(x.shape)
+        return convstack._TokensOut.apply(z, b, z.shape[-1], t, h, w)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -180,7 +230,7 @@ class VTDecoder(nn.Module):
         y = _DecoderFrontFn.apply(sl.contiguous(), zl_tok, tables, self.conv.conv.weight, self.conv.conv.bias,
                                   self.linear_projector.weight, pos, (t, h, w))
         for layer in self.block_local_attention:
-            y = layer.forward_tokens(y)
+            y = layer.forward_tokens(y, (t, h, w))
         return y
 
     def forward(self, slice, zl):
@@ -350,8 +400,8 @@ class VideoTransformer(Autoregressive):
         self.ch_predictor = ChannelPredictor(d, nc, nv, de, share_p=share_p, share_embeddings=share_embeddings)
 
     # token-major fast path used by VideoTransformerModel -----------------------------------------------
-    def logits_tokens(self, context, slice, slice_idx):
-        zl = self.encoder.forward_tokens(context, slice_idx)
+    def logits_tokens(self, context, slice, slice_idx, class_idx=None):
+        zl = self.encoder.forward_tokens(context, slice_idx, class_idx)
         yl = self.decoder.forward_tokens(slice, zl)
         return self.ch_predictor.logits_tokens(slice, yl)
 
@@ -361,10 +411,10 @@ class VideoTransformer(Autoregressive):
         ((b, nc) codes, zl) with zl in the reference's (b, d, t, h, w) layout."""
         b, nc, t, h, w = slice.shape
         if mode == "logits":
-            outs = self.logits_tokens(context, slice, slice_idx)
+            outs = self.logits_tokens(context, slice, slice_idx, class_idx)
             return [convstack._TokensOut.apply(o, b, self.nv, t, h, w) for o in outs]
         if mode == "sample_pixel":
-            zl_tok = (self.encoder.forward_tokens(context, slice_idx) if zl is None
+            zl_tok = (self.encoder.forward_tokens(context, slice_idx, class_idx) if zl is None
                       else convstack._TokensIn.apply(zl))
             yl = self.decoder.forward_tokens(slice, zl_tok)
             ti, hi, wi = pixel

@@ -217,21 +217,65 @@ class BlockLocalAttention(nn.Module):
         return (self.dt_bank.index_select(1, self.dt) + self.dh_bank.index_select(1, self.dh)
                 + self.dw_bank.index_select(1, self.dw)).view(self.n_head, 1, s, s)
 
-    def forward_tokens(self, x_tok):
-        """(b*S, d) token-major -> same."""
+    def forward_tokens(self, x_tok, thw=None):
+        """(b*T*H*W, d) token-major -> same.  thw = (T, H, W) of the incoming volume; when it differs from the
+        block size the tokens are regrouped block by block (vt_attention.py:189-200)."""
         m, f = self.mha, self.ffn
-        return _BlockLocalAttentionFn.apply(
+        split = thw is not None and tuple(thw) != self.block_size
+        if split:
+            perm, inv = _block_permutation(tuple(thw), self.block_size, x_tok.device)
+            S = perm.numel()
+            x_tok = _RowPermuteFn.apply(x_tok, perm, inv, S)
+        y = _BlockLocalAttentionFn.apply(
             x_tok, self.block_size, self.masked, self.dt_bank, self.dh_bank, self.dw_bank,
             m.layer_norm.weight, m.layer_norm.bias, m.w_q, m.w_k, m.w_v, m.proj.weight,
             f[0].weight, f[0].bias, f[1].weight, f[1].bias, f[3].weight, f[3].bias)
+        if split:
+            y = _RowPermuteFn.apply(y, inv, perm, S)
+        return y
 
     def forward(self, x):
         """Reference contract: (B, C, T, H, W) -> same shape."""
         from .. import convstack
         B, C, T, H, W = x.shape
-        if (T, H, W) != self.block_size:
-            raise NotImplementedError("block-split attention (vt_attention.py:189-200) is only needed by the "
-                                      "DSSVT/DSTSVT evaluation configs and is not built yet")
         tok = convstack._TokensIn.apply(x)
-        tok = self.forward_tokens(tok)
+        tok = self.forward_tokens(tok, (T, H, W))
         return convstack._TokensOut.apply(tok, B, C, T, H, W)
+
+
+_perm_cache = {}
+
+
+def _block_permutation(thw, block, device):
+    """Token order of the block-split branch: raster (T,H,W) -> (nt, nh, nw, t, h, w).  Returns (perm, inv) with
+    blocked[i] = raster[perm[i]] and raster[j] = blocked[inv[j]] (per sample)."""
+    key = (thw, block, str(device))
+    hit = _perm_cache.get(key)
+    if hit is None:
+        (T, H, W), (t, h, w) = thw, block
+        if T % t or H % h or W % w:
+            raise ValueError("volume %s is not a multiple of the attention block %s" % (thw, block))
+        r = torch.arange(T * H * W).view(T // t, t, H // h, h, W // w, w)
+        perm = r.permute(0, 2, 4, 1, 3, 5).reshape(-1)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel())
+        hit = _perm_cache[key] = (perm.to(device), inv.to(device))
+    return hit
+
+
+class _RowPermuteFn(torch.autograd.Function):
+    """Per-sample row gather of a (b*S, d) token matrix (pure data movement; the inverse permutation is its
+    own backward, so no scatter / atomics are involved)."""
+
+    @staticmethod
+    def forward(ctx, x, perm, inv, S):
+        ctx.save_for_backward(perm, inv)
+        ctx.S = S
+        d = x.shape[-1]
+        return x.view(-1, S, d).index_select(1, perm).view(-1, d)
+
+    @staticmethod
+    def backward(ctx, g):
+        perm, inv = ctx.saved_tensors
+        d = g.shape[-1]
+        return g.contiguous().view(-1, ctx.S, d).index_select(1, inv).view(-1, d), None, None, None

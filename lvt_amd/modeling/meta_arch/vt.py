@@ -84,15 +84,19 @@ class VideoTransformerModel(nn.Module):
         sl = stack_to_device([x["slice"] for x in data], self.device)
         sidx = stack_to_device([x["slice_idx"] for x in data], self.device)
         ign = stack_to_device([x["ignore_mask"] for x in data], self.device)
-        if "class" in data[0]:
-            raise NotImplementedError("class-conditional training (CLASS_NUM > 0) is not built")
-        return ctx, sl, sidx, ign, None
+        return ctx, sl, sidx, ign, self._class_idx(data)
+
+    def _class_idx(self, data):
+        """(b,) int64 class labels when the samples carry them (vt.py:216-219, 235-238, 294-297)."""
+        if "class" not in data[0]:
+            return None
+        return stack_to_device([torch.as_tensor(x["class"]).long() for x in data], self.device)
 
     def compute_supervised_loss(self, context, slice, slice_idx, ignore_mask, iter=0, class_idx=None):
         ignore = self.cfg.MODEL.IGNORE_INDEX
         b, nc = slice.shape[:2]
         target = torch.masked_fill(slice, ignore_mask, ignore).reshape(b, nc, -1).contiguous()
-        logits = self.model.logits_tokens(context.contiguous(), slice.contiguous(), slice_idx.contiguous())
+        logits = self.model.logits_tokens(context.contiguous(), slice.contiguous(), slice_idx.contiguous(), class_idx)
         loss = 0
         for k in range(nc):
             loss = loss + _XentFn.apply(logits[k], target, k, ignore, 1.0 / nc)
@@ -122,6 +126,7 @@ class VideoTransformerModel(nn.Module):
         video = stack_to_device([torch.as_tensor(x["image_sequence"]) for x in data], self.device)
         B, T, nc, H, W = video.shape
         video = video.transpose(1, 2).contiguous()                   # B, nc, T, H, W
+        class_idx = self._class_idx(data)
         st, sh, sw = v.STRIDE
         idx2abc, _ = subscale_order(st, sh, sw)
         t, h, w = T // st, H // sh, W // sw
@@ -129,7 +134,7 @@ class VideoTransformerModel(nn.Module):
         for si, (a, b_, c) in enumerate(idx2abc):
             sl, ctx = slice_and_context(video, a, b_, c, v.STRIDE, v.KERNEL, v.PAD_VALUE)
             sidx = torch.full((B,), si, dtype=torch.long, device=video.device)
-            pred = self.model.logits_tokens(ctx.contiguous(), sl, sidx)          # nc x (B*t*h*w, nv)
+            pred = self.model.logits_tokens(ctx.contiguous(), sl, sidx, class_idx)   # nc x (B*t*h*w, nv)
             for k in range(nc):
                 logits[:, k, :, a::st, b_::sh, c::sw] = pred[k].view(B, t, h, w, v.NV).permute(0, 4, 1, 2, 3)
         ignore_mask = torch.zeros(1, T, H, W, dtype=torch.bool, device=video.device)
@@ -162,6 +167,10 @@ class VideoTransformerModel(nn.Module):
             prime[:n_prime] = True
         pred = self.model.ch_predictor
         sampler = None
+        # the K/V-cache decoder attends over the whole slice; block-split layers (slice larger than the attention
+        # block, e.g. DSSVT at 16 frames) fall back to the reference schedule
+        if any(tuple(l.block_size) != (t, h, w) for l in self.model.decoder.block_local_attention):
+            incremental = False
         if incremental:
             key = (B, t, h, w, float(temp))
             sampler = self._samplers.get(key) if hasattr(self, "_samplers") else None
@@ -174,7 +183,7 @@ class VideoTransformerModel(nn.Module):
             if bool(prime_sl.all()):
                 continue
             sidx = torch.full((B,), si, dtype=torch.long, device=video.device)
-            zl = self.model.encoder.forward_tokens(ctx.contiguous(), sidx)     # context is fixed per slice
+            zl = self.model.encoder.forward_tokens(ctx.contiguous(), sidx, class_idx)   # context is fixed per slice
             if sampler is not None:
                 sampler.begin_slice(zl, sl)
                 flat = prime_sl.reshape(-1).tolist()
@@ -196,7 +205,7 @@ class VideoTransformerModel(nn.Module):
     def sample_slice(self, context, slice_idx, slice_size, temp=0.9, class_idx=None):
         sl = torch.zeros(size=slice_size, device=context.device, dtype=torch.long)
         B, _, t, h, w = sl.shape
-        zl = self.model.encoder.forward_tokens(context.contiguous(), slice_idx.contiguous())
+        zl = self.model.encoder.forward_tokens(context.contiguous(), slice_idx.contiguous(), class_idx)
         for ti in range(t):
             for hi in range(h):
                 for wi in range(w):
@@ -209,9 +218,8 @@ class VideoTransformerModel(nn.Module):
         video = stack_to_device([torch.as_tensor(x["image_sequence"]) for x in data], self.device)
         video = video.transpose(1, 2).contiguous()                   # B, nc, T, H, W
         video[:, :, n_prime:] = 0
-        if "class" in data[0]:
-            raise NotImplementedError("class-conditional sampling is not built")
-        samples = [self.sample_video(video.clone(), n_prime=n_prime) for _ in range(num_samples)]
+        class_idx = self._class_idx(data)
+        samples = [self.sample_video(video.clone(), n_prime=n_prime, class_idx=class_idx) for _ in range(num_samples)]
         assert video.size(0) == len(output)
         for i in range(video.size(0)):
             output[i]["samples"] = [s[i] for s in samples]

@@ -197,3 +197,19 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("lvt_oracle_unused", ""), os.path.join(root, f)
+
+
+@pytest.mark.parametrize("tag,stride,kernel", [("g15_dssvt", (1, 2, 2), (1, 3, 3)), ("g16_dstsvt", (4, 2, 2), (5, 3, 3))])
+def test_mapper_general_strides_match_reference_contexts(golden, tag, stride, kernel):
+    """The product's slice / context builder on the spatial and spatio-temporal subscale geometries against the
+    contexts the reference's DatasetMapper produced (fixtures G15 / G16)."""
+    from lvt_amd.data.dataset_mapper import prepare_slices, prepare_slices_batch
+    g = golden(tag)
+    abcs = [tuple(int(x) for x in g["abc"][i]) for i in range(g["codes"].shape[0])]
+    ds = [prepare_slices(g["codes"][i].numpy(), abcs[i], stride, kernel, 1, -1) for i in range(len(abcs))]
+    assert torch.equal(torch.stack([torch.as_tensor(d["context"]) for d in ds]), g["context"])
+    assert torch.equal(torch.stack([torch.as_tensor(d["slice_idx"]) for d in ds]), g["slice_idx"])
+    ctx, sl, sidx, ign = prepare_slices_batch(g["codes"], abcs, stride, kernel, 1, -1)
+    assert torch.equal(ctx, g["context"]) and torch.equal(sidx, g["slice_idx"])
+    assert torch.equal(sl, torch.stack([torch.as_tensor(d["slice"]) for d in ds]))
+    assert torch.equal(ign, torch.stack([torch.as_tensor(d["ignore_mask"]) for d in ds]))
