@@ -114,6 +114,26 @@ template <int ROWS> __device__ __forceinline__ void store_split_block(unsigned s
 }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// Mixed-radix digits of a running GEMM-k index, k = ((t*nH + h)*nW + w)*nC + c.  Every loader decodes its
+// k position ONCE (seek, with integer divisions) and then steps it tile by tile with compares only: the main
+// loop is issue-bound (measured 10.6 VALU instructions per MFMA before this), and the three signed divisions
+// per fetch were a fifth of that.
+struct Cursor4 {
+    int c, w, h, t;
+    __device__ __forceinline__ void seek(int k, int nC, int nW, int nH) {
+        int q = k / nC; c = k - q * nC;
+        w = q % nW; q /= nW;
+        h = q % nH; t = q / nH;
+    }
+    __device__ __forceinline__ void advance(int step, int nC, int nW, int nH) {
+        c += step;
+        while (c >= nC) {
+            c -= nC;
+            if (++w == nW) { w = 0; if (++h == nH) { h = 0; ++t; } }
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // A-side loaders.  K-contiguous modes fetch float4 along k and scatter 4 scalars into the k-major
 // LDS tile; M-contiguous modes fetch float4 along m and store it as one 16-byte LDS write.
@@ -149,7 +169,7 @@ template <int BM, int MATH> struct ALoader<A_KPLAIN, BM, MATH> : AKLoaderBase<A_
     using Base = AKLoaderBase<A_KPLAIN, BM>;
     const float *rowp[Base::ITERS];
     bool rowok[Base::ITERS];
-    int kb; long long skb;
+    int kb, kcur, kin; long long skb, kbase;
     __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int) {
         this->r0 = tid / QPR; this->kq = tid % QPR;
         kb = p.a_kb; skb = p.a_skb;
@@ -160,25 +180,33 @@ template <int BM, int MATH> struct ALoader<A_KPLAIN, BM, MATH> : AKLoaderBase<A_
             rowp[i] = A + (long long)m * p.lda;
         }
     }
-    __device__ __forceinline__ void fetch(int k0, int kend) {
-        const int k = k0 + this->kq * 4;
-        const bool kok = k < kend;
-        const long long koff = (long long)(k / kb) * skb + (k % kb);
+    __device__ __forceinline__ void seek(int k0) {
+        kcur = k0 + this->kq * 4;
+        const int blk = kcur / kb;
+        kin = kcur - blk * kb; kbase = (long long)blk * skb;
+    }
+    __device__ __forceinline__ void fetch(int kend) {
+        const bool kok = kcur < kend;
+        const long long koff = kbase + kin;
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i)
             this->v[i] = (kok && rowok[i]) ? ldg4(rowp[i] + koff) : zero4();
+        kcur += BK; kin += BK;
+        while (kin >= kb) { kin -= kb; kbase += skb; }
     }
 };
 
 // forward convolution: row m -> (n,to,ho,wo); k -> (tap, ci)
 template <int BM, int MATH> struct ALoader<A_CONV_K, BM, MATH> : AKLoaderBase<A_CONV_K, BM> {
     using Base = AKLoaderBase<A_CONV_K, BM>;
-    long long nbase[Base::ITERS];
+    const float *rowp[Base::ITERS];          // x at (n, ti0, hi0, wi0, 0): the tap-(0,0,0) corner of the window
     int ti0[Base::ITERS], hi0[Base::ITERS], wi0[Base::ITERS];
-    const float *x; lvt_conv_geom g;
+    int Ci, Kw, Kh, Ti, Hi, Wi, kcur;
+    Cursor4 cur;                              // (ci, kw, kh, kt)
     __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int) {
         this->r0 = tid / QPR; this->kq = tid % QPR;
-        x = A; g = p.g;
+        const lvt_conv_geom &g = p.g;
+        Ci = g.Ci; Kw = g.Kw; Kh = g.Kh; Ti = g.Ti; Hi = g.Hi; Wi = g.Wi;
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i) {
             int m = m0 + this->r0 + RPP * i;
@@ -187,26 +215,27 @@ template <int BM, int MATH> struct ALoader<A_CONV_K, BM, MATH> : AKLoaderBase<A_
                 const int ho = m % g.Ho; m /= g.Ho;
                 const int to = m % g.To; const int n = m / g.To;
                 ti0[i] = to * g.st - g.pt; hi0[i] = ho * g.sh - g.ph; wi0[i] = wo * g.sw - g.pw;
-                nbase[i] = (long long)n * g.Ti * g.Hi * g.Wi;
+                rowp[i] = A + ((((long long)n * Ti + ti0[i]) * Hi + hi0[i]) * Wi + wi0[i]) * Ci;
             } else {
-                ti0[i] = -(1 << 28); hi0[i] = 0; wi0[i] = 0; nbase[i] = 0;
+                ti0[i] = -(1 << 28); hi0[i] = 0; wi0[i] = 0; rowp[i] = A;
             }
         }
     }
-    __device__ __forceinline__ void fetch(int k0, int kend) {
-        const int k = k0 + this->kq * 4;
-        const bool kok = k < kend;
-        int tap = k / g.Ci; const int ci = k - tap * g.Ci;
-        const int kw = tap % g.Kw; tap /= g.Kw;
-        const int kh = tap % g.Kh; const int kt = tap / g.Kh;
+    __device__ __forceinline__ void seek(int k0) {
+        kcur = k0 + this->kq * 4;
+        cur.seek(kcur, Ci, Kw, Kh);
+    }
+    __device__ __forceinline__ void fetch(int kend) {
+        const bool kok = kcur < kend;
+        const int tapoff = ((cur.t * Hi + cur.h) * Wi + cur.w) * Ci + cur.c;     // same for every row of the lane
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i) {
-            const int ti = ti0[i] + kt, hi = hi0[i] + kh, wi = wi0[i] + kw;
-            const bool ok = kok && (unsigned)ti < (unsigned)g.Ti && (unsigned)hi < (unsigned)g.Hi &&
-                            (unsigned)wi < (unsigned)g.Wi;
-            const long long off = (nbase[i] + ((long long)ti * g.Hi + hi) * g.Wi + wi) * g.Ci + ci;
-            this->v[i] = ok ? ldg4(x + off) : zero4();
+            const bool ok = kok && (unsigned)(ti0[i] + cur.t) < (unsigned)Ti && (unsigned)(hi0[i] + cur.h) < (unsigned)Hi &&
+                            (unsigned)(wi0[i] + cur.w) < (unsigned)Wi;
+            this->v[i] = ok ? ldg4(rowp[i] + tapoff) : zero4();
         }
+        kcur += BK;
+        cur.advance(BK, Ci, Kw, Kh);
     }
 };
 
@@ -214,12 +243,14 @@ template <int BM, int MATH> struct ALoader<A_CONV_K, BM, MATH> : AKLoaderBase<A_
 // i = s*q + r.  k -> (phase tap j, co); gathered dy position o = q + c - j per dimension.
 template <int BM, int MATH> struct ALoader<A_CONVT_K, BM, MATH> : AKLoaderBase<A_CONVT_K, BM> {
     using Base = AKLoaderBase<A_CONVT_K, BM>;
-    long long nbase[Base::ITERS];
+    const float *rowp[Base::ITERS];          // dy at (n, ot0, oh0, ow0, 0): the phase-tap-(0,0,0) position
     int ot0[Base::ITERS], oh0[Base::ITERS], ow0[Base::ITERS];
-    const float *dy; lvt_conv_geom g; int jH, jW;
+    int Co, jH, jW, To, Ho, Wo, kcur;
+    Cursor4 cur;                              // (co, jw, jh, jt)
     __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int cls) {
         this->r0 = tid / QPR; this->kq = tid % QPR;
-        dy = A; g = p.g; jH = p.jH; jW = p.jW;
+        const lvt_conv_geom &g = p.g;
+        Co = g.Co; jH = p.jH; jW = p.jW; To = g.To; Ho = g.Ho; Wo = g.Wo;
         const int fw = cls % g.sw, fh = (cls / g.sw) % g.sh, ft = cls / (g.sw * g.sh);
         // r = (phi - p) mod s ; c = (r + p - phi) / s
         const int rt = ((ft - g.pt) % g.st + g.st) % g.st, ct = (rt + g.pt - ft) / g.st;
@@ -233,26 +264,27 @@ template <int BM, int MATH> struct ALoader<A_CONVT_K, BM, MATH> : AKLoaderBase<A
                 const int qh = m % p.Hq; m /= p.Hq;
                 const int qt = m % p.Tq; const int n = m / p.Tq;
                 ot0[i] = qt + ct; oh0[i] = qh + ch; ow0[i] = qw + cw;
-                nbase[i] = (long long)n * g.To * g.Ho * g.Wo;
+                rowp[i] = A + ((((long long)n * To + ot0[i]) * Ho + oh0[i]) * Wo + ow0[i]) * Co;
             } else {
-                ot0[i] = -(1 << 28); oh0[i] = 0; ow0[i] = 0; nbase[i] = 0;
+                ot0[i] = -(1 << 28); oh0[i] = 0; ow0[i] = 0; rowp[i] = A;
             }
         }
     }
-    __device__ __forceinline__ void fetch(int k0, int kend) {
-        const int k = k0 + this->kq * 4;
-        const bool kok = k < kend;
-        int tap = k / g.Co; const int co = k - tap * g.Co;
-        const int jw = tap % jW; tap /= jW;
-        const int jh = tap % jH; const int jt = tap / jH;
+    __device__ __forceinline__ void seek(int k0) {
+        kcur = k0 + this->kq * 4;
+        cur.seek(kcur, Co, jW, jH);
+    }
+    __device__ __forceinline__ void fetch(int kend) {
+        const bool kok = kcur < kend;
+        const int tapoff = cur.c - ((cur.t * Ho + cur.h) * Wo + cur.w) * Co;      // gathered position o = o0 - j
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i) {
-            const int ot = ot0[i] - jt, oh = oh0[i] - jh, ow = ow0[i] - jw;
-            const bool ok = kok && (unsigned)ot < (unsigned)g.To && (unsigned)oh < (unsigned)g.Ho &&
-                            (unsigned)ow < (unsigned)g.Wo;
-            const long long off = (nbase[i] + ((long long)ot * g.Ho + oh) * g.Wo + ow) * g.Co + co;
-            this->v[i] = ok ? ldg4(dy + off) : zero4();
+            const bool ok = kok && (unsigned)(ot0[i] - cur.t) < (unsigned)To && (unsigned)(oh0[i] - cur.h) < (unsigned)Ho &&
+                            (unsigned)(ow0[i] - cur.w) < (unsigned)Wo;
+            this->v[i] = ok ? ldg4(rowp[i] + tapoff) : zero4();
         }
+        kcur += BK;
+        cur.advance(BK, Co, jW, jH);
     }
 };
 
@@ -280,48 +312,56 @@ template <int BM, int MATH> struct AMLoaderBase {
 
 template <int BM, int MATH> struct ALoader<A_MPLAIN, BM, MATH> : AMLoaderBase<BM, MATH> {
     using Base = AMLoaderBase<BM, MATH>;
-    const float *colp; bool mok; long long lda;
+    const float *kp; bool mok; long long lda; int kcur;
     __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int) {
         this->kk0 = tid / Base::UPK; this->mq = tid % Base::UPK;
         const int m = m0 + this->mq * 4;
-        mok = m < p.M; colp = A + m; lda = p.lda;
+        mok = m < p.M; kp = A + m; lda = p.lda;
     }
-    __device__ __forceinline__ void fetch(int k0, int kend) {
+    __device__ __forceinline__ void seek(int k0) {
+        kcur = k0 + this->kk0 * Base::KMUL;
+        kp += (long long)kcur * lda;
+    }
+    __device__ __forceinline__ void fetch(int kend) {
 #pragma unroll
-        for (int i = 0; i < Base::ITERS; ++i) {
-            const int k = k0 + this->kk0 * Base::KMUL + Base::KSTEP * i;
-            this->v[i] = (mok && k < kend) ? ldg4(colp + (long long)k * lda) : zero4();
-        }
+        for (int i = 0; i < Base::ITERS; ++i)
+            this->v[i] = (mok && kcur + Base::KSTEP * i < kend) ? ldg4(kp + (long long)(Base::KSTEP * i) * lda) : zero4();
+        kcur += BK; kp += (long long)BK * lda;
     }
 };
 
 // backward-weight: GEMM row = (tap, ci), GEMM k = output pixel (n,to,ho,wo)
 template <int BM, int MATH> struct ALoader<A_CONV_M, BM, MATH> : AMLoaderBase<BM, MATH> {
     using Base = AMLoaderBase<BM, MATH>;
-    const float *x; lvt_conv_geom g; bool mok; int kt, kh, kw, ci;
+    const float *x; lvt_conv_geom g; bool mok; int kt, kh, kw, ci, kcur; long long sample;
+    Cursor4 cur;                              // output pixel of the lane's first k row: (wo, ho, to, n)
     __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int) {
         this->kk0 = tid / Base::UPK; this->mq = tid % Base::UPK;
         x = A; g = p.g;
+        sample = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
         const int m = m0 + this->mq * 4;
         mok = m < p.M;
         int tap = m / g.Ci; ci = m - tap * g.Ci;
         kw = tap % g.Kw; tap /= g.Kw;
         kh = tap % g.Kh; kt = tap / g.Kh;
     }
-    __device__ __forceinline__ void fetch(int k0, int kend) {
+    __device__ __forceinline__ void seek(int k0) {
+        kcur = k0 + this->kk0 * Base::KMUL;
+        cur.seek(kcur, g.Wo, g.Ho, g.To);
+    }
+    __device__ __forceinline__ void fetch(int kend) {
+        Cursor4 c = cur;
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i) {
-            int pix = k0 + this->kk0 * Base::KMUL + Base::KSTEP * i;
-            bool ok = mok && pix < kend;
-            const int wo = pix % g.Wo; pix /= g.Wo;
-            const int ho = pix % g.Ho; pix /= g.Ho;
-            const int to = pix % g.To; const int n = pix / g.To;
-            const int ti = to * g.st - g.pt + kt, hi = ho * g.sh - g.ph + kh, wi = wo * g.sw - g.pw + kw;
-            ok = ok && (unsigned)ti < (unsigned)g.Ti && (unsigned)hi < (unsigned)g.Hi &&
-                 (unsigned)wi < (unsigned)g.Wi;
-            const long long off = ((((long long)n * g.Ti + ti) * g.Hi + hi) * g.Wi + wi) * g.Ci + ci;
-            this->v[i] = ok ? ldg4(x + off) : zero4();
+            const int ti = c.h * g.st - g.pt + kt, hi = c.w * g.sh - g.ph + kh, wi = c.c * g.sw - g.pw + kw;
+            const bool ok = mok && kcur + Base::KSTEP * i < kend && (unsigned)ti < (unsigned)g.Ti &&
+                            (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
+            const int inner = ((ti * g.Hi + hi) * g.Wi + wi) * g.Ci + ci;            // within one sample: < 2^31
+            this->v[i] = ok ? ldg4(x + c.t * sample + inner) : zero4();
+            if (i + 1 < Base::ITERS) c.advance(Base::KSTEP, g.Wo, g.Ho, g.To);
         }
+        kcur += BK;
+        cur.advance(BK, g.Wo, g.Ho, g.To);
     }
 };
 
@@ -338,10 +378,14 @@ template <int BM, int MATH> struct ALoader<A_ONEHOT_M, BM, MATH> : AMLoaderBase<
         ip = p.oh_idx + p.oh_off[slot];
         bstride = p.oh_bstride; pstride = p.oh_pstride; P = p.oh_P;
     }
-    __device__ __forceinline__ void fetch(int k0, int kend) {
+    int kcur;
+    __device__ __forceinline__ void seek(int k0) { kcur = k0 + this->kk0 * Base::KMUL; }
+    __device__ __forceinline__ void fetch(int kend) {
+        const int kbase = kcur;
+        kcur += BK;
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i) {
-            const int row = k0 + this->kk0 * Base::KMUL + Base::KSTEP * i;
+            const int row = kbase + Base::KSTEP * i;
             float4 v = zero4();
             if (mok && row < kend) {
                 const int b = row / P, pos = row - b * P;
@@ -384,7 +428,7 @@ template <int BN> struct BKLoaderBase {
 
 template <int BN, int MATH> struct BLoader<B_KPLAIN, BN, MATH> : BKLoaderBase<BN> {
     using Base = BKLoaderBase<BN>;
-    const float *rowp[Base::ITERS]; bool rowok[Base::ITERS]; int kb; long long skb;
+    const float *rowp[Base::ITERS]; bool rowok[Base::ITERS]; int kb, kcur, kin; long long skb, kbase;
     __device__ __forceinline__ void init(const KParams &p, int tid, int n0, const float *B, int) {
         this->r0 = tid / QPR; this->kq = tid % QPR;
         kb = p.b_kb; skb = p.b_skb;
@@ -395,42 +439,52 @@ template <int BN, int MATH> struct BLoader<B_KPLAIN, BN, MATH> : BKLoaderBase<BN
             rowp[i] = B + (long long)n * p.ldb;
         }
     }
-    __device__ __forceinline__ void fetch(int k0, int kend) {
-        const int k = k0 + this->kq * 4;
-        const bool kok = k < kend;
-        const long long koff = (long long)(k / kb) * skb + (k % kb);
+    __device__ __forceinline__ void seek(int k0) {
+        kcur = k0 + this->kq * 4;
+        const int blk = kcur / kb;
+        kin = kcur - blk * kb; kbase = (long long)blk * skb;
+    }
+    __device__ __forceinline__ void fetch(int kend) {
+        const bool kok = kcur < kend;
+        const long long koff = kbase + kin;
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i)
             this->v[i] = (kok && rowok[i]) ? ldg4(rowp[i] + koff) : zero4();
+        kcur += BK; kin += BK;
+        while (kin >= kb) { kin -= kb; kbase += skb; }
     }
 };
 
 // packed conv weights wp[tap][ci][co] read as B(k=(phase tap j, co), n=ci) for one stride phase
 template <int BN, int MATH> struct BLoader<B_CONVT_W, BN, MATH> : BKLoaderBase<BN> {
     using Base = BKLoaderBase<BN>;
-    const float *wp; lvt_conv_geom g; int jH, jW, ft, fh, fw;
-    int nrow[Base::ITERS]; bool rowok[Base::ITERS];
+    const float *wp; lvt_conv_geom g; int jH, jW, ft, fh, fw, kcur;
+    int rowoff[Base::ITERS]; bool rowok[Base::ITERS];
+    Cursor4 cur;                              // (co, jw, jh, jt)
     __device__ __forceinline__ void init(const KParams &p, int tid, int n0, const float *B, int cls) {
         this->r0 = tid / QPR; this->kq = tid % QPR;
         wp = B; g = p.g; jH = p.jH; jW = p.jW;
         fw = cls % g.sw; fh = (cls / g.sw) % g.sh; ft = cls / (g.sw * g.sh);
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i) {
-            nrow[i] = n0 + this->r0 + RPP * i;
-            rowok[i] = nrow[i] < p.N && this->r0 < BN;
+            const int n = n0 + this->r0 + RPP * i;
+            rowok[i] = n < p.N && this->r0 < BN;
+            rowoff[i] = n * g.Co;                    // packed weights hold taps*Ci*Co < 2^31 elements
         }
     }
-    __device__ __forceinline__ void fetch(int k0, int kend) {
-        const int k = k0 + this->kq * 4;
-        const bool kok = k < kend;
-        int tap = k / g.Co; const int co = k - tap * g.Co;
-        const int jw = tap % jW; tap /= jW;
-        const int jh = tap % jH; const int jt = tap / jH;
-        const int kt = ft + g.st * jt, kh = fh + g.sh * jh, kw = fw + g.sw * jw;
-        const long long tapa = ((long long)kt * g.Kh + kh) * g.Kw + kw;
+    __device__ __forceinline__ void seek(int k0) {
+        kcur = k0 + this->kq * 4;
+        cur.seek(kcur, g.Co, jW, jH);
+    }
+    __device__ __forceinline__ void fetch(int kend) {
+        const bool kok = kcur < kend;
+        const int kt = ft + g.st * cur.t, kh = fh + g.sh * cur.h, kw = fw + g.sw * cur.w;
+        const int base = ((kt * g.Kh + kh) * g.Kw + kw) * g.Ci * g.Co + cur.c;
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i)
-            this->v[i] = (kok && rowok[i]) ? ldg4(wp + (tapa * g.Ci + nrow[i]) * g.Co + co) : zero4();
+            this->v[i] = (kok && rowok[i]) ? ldg4(wp + base + rowoff[i]) : zero4();
+        kcur += BK;
+        cur.advance(BK, g.Co, jW, jH);
     }
 };
 
@@ -441,20 +495,23 @@ template <int BN, int MATH> struct BLoader<B_NPLAIN, BN, MATH> {
     static constexpr int LD = BN + 4;
     static constexpr int KMUL = MATH ? ITERS : 1, KSTEP = MATH ? 1 : KPP;
     float4 v[ITERS];
-    int kk0, nq; bool active;
-    const float *colp; bool nok; long long ldb;
+    int kk0, nq, kcur; bool active;
+    const float *kp; bool nok; long long ldb;
     __device__ __forceinline__ void init(const KParams &p, int tid, int n0, const float *B, int) {
         kk0 = tid / UPK; nq = tid % UPK;
         active = kk0 < BK;
         const int n = n0 + nq * 4;
-        nok = active && n < p.N; colp = B + n; ldb = p.ldb;
+        nok = active && n < p.N; kp = B + n; ldb = p.ldb;
     }
-    __device__ __forceinline__ void fetch(int k0, int kend) {
+    __device__ __forceinline__ void seek(int k0) {
+        kcur = k0 + kk0 * KMUL;
+        kp += (long long)kcur * ldb;
+    }
+    __device__ __forceinline__ void fetch(int kend) {
 #pragma unroll
-        for (int i = 0; i < ITERS; ++i) {
-            const int k = k0 + kk0 * KMUL + KSTEP * i;
-            v[i] = (nok && k < kend) ? ldg4(colp + (long long)k * ldb) : zero4();
-        }
+        for (int i = 0; i < ITERS; ++i)
+            v[i] = (nok && kcur + KSTEP * i < kend) ? ldg4(kp + (long long)(KSTEP * i) * ldb) : zero4();
+        kcur += BK; kp += (long long)BK * ldb;
     }
     __device__ __forceinline__ void store(float *lds) const {
         if (!active) return;
@@ -545,7 +602,8 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (kbeg < kend) {
-        al.fetch(kbeg, kend); bl.fetch(kbeg, kend);
+        al.seek(kbeg); bl.seek(kbeg);
+        al.fetch(kend); bl.fetch(kend);
         if (MATH == 0) { al.store(As); bl.store(Bs); }
         else { al.store_split(Ah); bl.store_split(Bh); }
     }
@@ -556,7 +614,7 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
 
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool has_next = k0 + BK < kend;
-        if (has_next) { al.fetch(k0 + BK, kend); bl.fetch(k0 + BK, kend); }
+        if (has_next) { al.fetch(kend); bl.fetch(kend); }
         if (MATH == 0) {
             // operand fragments are double-buffered in registers: the ds_reads of step kk+2 are in flight
             // while the MFMAs of step kk issue, so the LDS latency is not exposed once per step
