@@ -356,7 +356,7 @@ def main():
                         "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in sorted(eng.items())}
         traffic = None
         try:      # HBM bytes per engine launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate runs)
-            with open(os.path.join(ROOT, "profiles", "r01_vqvae_pmc_hbm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_vqvae_pmc_hbm_traffic_bf16x3.json")) as f:
                 traffic = round(json.load(f)["hbm_bytes_per_launch"])
         except Exception:
             pass
@@ -372,7 +372,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(engine_peak(math_mode), 1),
                          "unit": "TFLOP/s", "frac": round(achieved / engine_peak(math_mode), 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, "
-                                         "profiles/r01_vqvae_pmc_hbm_traffic.txt); algorithmic flops per launch = %.3e" % (tot_fl / max(launches, 1)),
+                                         "profiles/r01_vqvae_pmc_hbm_traffic_bf16x3.txt); algorithmic flops per launch = %.3e" % (tot_fl / max(launches, 1)),
                          "kernel": "lvt_gemm_kernel<*> (implicit-GEMM engine: conv fwd / bwd-data / bwd-weight), %d "
                                    "launches per step; event-timed in a second pass of the same %d steps: %.2f ms of "
                                    "engine time in a %.2f ms instrumented step (unperturbed step: %.2f ms)"

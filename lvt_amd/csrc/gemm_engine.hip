@@ -532,6 +532,97 @@ template <int BN, int MATH> struct BLoader<B_NPLAIN, BN, MATH> {
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// ------------------------------------------------------------------------------------------------
+// epilogue shared by the kernels: alpha / bias / residual / ReLU / tanh / mask / accumulate, or split-K partials
+// ------------------------------------------------------------------------------------------------
+template <int AMODE, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void lvt_epilogue(const KParams &p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int m0, int n0,
+                                             int wm, int wn, int l31, int half, int cls, long long coff, int z, int split) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    // ConvTranspose phase: decode the phase-ordered row into the channels-last dx row.
+    int fw = 0, fh = 0, ft = 0, rt = 0, rh = 0, rw = 0;
+    if (AMODE == A_CONVT_K) {
+        const lvt_conv_geom &g = p.g;
+        fw = cls % g.sw; fh = (cls / g.sw) % g.sh; ft = cls / (g.sw * g.sh);
+        rt = ((ft - g.pt) % g.st + g.st) % g.st;
+        rh = ((fh - g.ph) % g.sh + g.sh) % g.sh;
+        rw = ((fw - g.pw) % g.sw + g.sw) % g.sw;
+    }
+    const int flags = p.flags;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row >= p.M) continue;
+            long long orow = row;
+            if (AMODE == A_CONVT_K) {
+                const lvt_conv_geom &g = p.g;
+                int m = row;
+                const int qw = m % p.Wq; m /= p.Wq;
+                const int qh = m % p.Hq; m /= p.Hq;
+                const int qt = m % p.Tq; const int n = m / p.Tq;
+                orow = (((long long)n * g.Ti + (g.st * qt + rt)) * g.Hi + (g.sh * qh + rh)) * g.Wi +
+                       (g.sw * qw + rw);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (TN * 32) + j * 32 + l31;
+                if (col >= p.N) continue;
+                float v = acc[i][j][r];
+                if (p.splits > 1) {
+                    p.partial[split * p.partial_stride + (long long)z * p.M * p.N + orow * p.N + col] = v;
+                    continue;
+                }
+                v *= p.alpha;
+                if (flags & LVT_EPI_BIAS) v += p.bias[col];
+                if (flags & LVT_EPI_RESIDUAL) v += p.res[coff + orow * p.ldr + col];
+                if (flags & LVT_EPI_RELU) v = fmaxf(v, 0.f);
+                if (flags & LVT_EPI_TANH) v = tanhf(v);
+                if (flags & LVT_EPI_MASK) v = (p.mask[coff + orow * p.ldm + col] > 0.f) ? v : 0.f;
+                float *cp = p.C + coff + orow * p.ldc + col;
+                if (flags & LVT_EPI_ACCUM) v += *cp;
+                *cp = v;
+            }
+        }
+    }
+}
+
+// blockIdx -> tile / batch / split coordinates (shared by the kernels)
+struct TileCtx { int m0, n0, z, split, cls, kbeg, kend; const float *A, *B; long long coff; };
+template <int AMODE, int BM, int BN>
+__device__ __forceinline__ TileCtx lvt_tile_ctx(const KParams &p) {
+    TileCtx t;
+    // Workgroup b is dispatched to XCD b % 8 and every XCD has a private L2, so the linear id is first remapped
+    // to give each XCD one CONTIGUOUS run of tiles (bijective for any grid size): the n tiles that share an A
+    // panel, and the neighbouring m tiles that share im2col halo rows / the same image, then hit the same L2.
+    const int ntn = (p.N + BN - 1) / BN;
+    int wg = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = wg & 7, slot = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    t.n0 = (wg % ntn) * BN; t.m0 = (wg / ntn) * BM;
+    t.z = blockIdx.y;                   // batch (or conv phase class)
+    t.split = blockIdx.z;
+    t.A = p.A; t.B = p.B; t.coff = 0; t.cls = 0;
+    if (AMODE == A_CONVT_K) {
+        t.cls = t.z;
+    } else {
+        const int zo = t.z / p.batch_inner, zi = t.z % p.batch_inner;
+        t.A += zo * p.sA_o + zi * p.sA_i;
+        t.B += zo * p.sB_o + zi * p.sB_i;
+        t.coff = zo * p.sC_o + zi * p.sC_i;
+    }
+    t.kbeg = 0; t.kend = p.K;
+    if (p.splits > 1) {
+        t.kbeg = t.split * p.k_per_split;
+        t.kend = min(p.K, t.kbeg + p.k_per_split);
+    }
+    return t;
+}
+
 // MATH == 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
 // MATH == 1: bf16x3 split -- every fp32 operand is staged as three bf16 planes and each 32x32x16 block is six
 //            v_mfma_f32_32x32x16_bf16 (a1b1, a1b2, a2b1, a1b3, a3b1, a2b2: all product terms above 2^-24 |ab|,
@@ -555,39 +646,10 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, half = lane >> 5;
 
-    // blockIdx.x -> (m tile, n tile).  Workgroup b is dispatched to XCD b % 8 and every XCD has a private
-    // L2, so the linear id is first remapped to give each XCD one CONTIGUOUS run of tiles (bijective for
-    // any grid size): the n tiles that share an A panel, and the neighbouring m tiles that share im2col
-    // halo rows / the same image, then hit the same L2 instead of each XCD fetching its own copy.
-    const int ntn = (p.N + BN - 1) / BN;
-    int wg = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
-        const int xcd = wg & 7, slot = wg >> 3;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    const int tile_n = wg % ntn, tile_m = wg / ntn;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    int z = blockIdx.y;                 // batch (or conv phase class)
-    const int split = blockIdx.z;
-
-    const float *A = p.A, *B = p.B;
-    long long coff = 0;
-    int cls = 0;
-    if (AMODE == A_CONVT_K) {
-        cls = z;
-    } else {
-        const int zo = z / p.batch_inner, zi = z % p.batch_inner;
-        A += zo * p.sA_o + zi * p.sA_i;
-        B += zo * p.sB_o + zi * p.sB_i;
-        coff = zo * p.sC_o + zi * p.sC_i;
-    }
-
-    int kbeg = 0, kend = p.K;
-    if (p.splits > 1) {
-        kbeg = split * p.k_per_split;
-        kend = min(p.K, kbeg + p.k_per_split);
-    }
+    const TileCtx tc = lvt_tile_ctx<AMODE, BM, BN>(p);
+    const int m0 = tc.m0, n0 = tc.n0, z = tc.z, split = tc.split, cls = tc.cls, kbeg = tc.kbeg, kend = tc.kend;
+    const float *A = tc.A, *B = tc.B;
+    const long long coff = tc.coff;
 
     AL al; BL bl;
     al.init(p, tid, m0, A, cls);
@@ -681,54 +743,7 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
         __syncthreads();
     }
 
-    // ---------------- epilogue ----------------
-    // ConvTranspose phase: decode the phase-ordered row into the channels-last dx row.
-    int fw = 0, fh = 0, ft = 0, rt = 0, rh = 0, rw = 0;
-    if (AMODE == A_CONVT_K) {
-        const lvt_conv_geom &g = p.g;
-        fw = cls % g.sw; fh = (cls / g.sw) % g.sh; ft = cls / (g.sw * g.sh);
-        rt = ((ft - g.pt) % g.st + g.st) % g.st;
-        rh = ((fh - g.ph) % g.sh + g.sh) % g.sh;
-        rw = ((fw - g.pw) % g.sw + g.sw) % g.sw;
-    }
-    const int flags = p.flags;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (row >= p.M) continue;
-            long long orow = row;
-            if (AMODE == A_CONVT_K) {
-                const lvt_conv_geom &g = p.g;
-                int m = row;
-                const int qw = m % p.Wq; m /= p.Wq;
-                const int qh = m % p.Hq; m /= p.Hq;
-                const int qt = m % p.Tq; const int n = m / p.Tq;
-                orow = (((long long)n * g.Ti + (g.st * qt + rt)) * g.Hi + (g.sh * qh + rh)) * g.Wi +
-                       (g.sw * qw + rw);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * (TN * 32) + j * 32 + l31;
-                if (col >= p.N) continue;
-                float v = acc[i][j][r];
-                if (p.splits > 1) {
-                    p.partial[split * p.partial_stride + (long long)z * p.M * p.N + orow * p.N + col] = v;
-                    continue;
-                }
-                v *= p.alpha;
-                if (flags & LVT_EPI_BIAS) v += p.bias[col];
-                if (flags & LVT_EPI_RESIDUAL) v += p.res[coff + orow * p.ldr + col];
-                if (flags & LVT_EPI_RELU) v = fmaxf(v, 0.f);
-                if (flags & LVT_EPI_TANH) v = tanhf(v);
-                if (flags & LVT_EPI_MASK) v = (p.mask[coff + orow * p.ldm + col] > 0.f) ? v : 0.f;
-                float *cp = p.C + coff + orow * p.ldc + col;
-                if (flags & LVT_EPI_ACCUM) v += *cp;
-                *cp = v;
-            }
-        }
-    }
+    lvt_epilogue<AMODE, BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, l31, half, cls, coff, z, split);
 }
 
 // deterministic split-K reduction: out[i] (+)= sum_s partial[s][i]
