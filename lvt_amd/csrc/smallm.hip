@@ -1,10 +1,18 @@
 // Small-M GEMM for incremental decoding: C[M<=64][N] = epi(alpha * A[M][K] . B), weights streamed once.
 // The 128x128 MFMA tile engine needs ~30 us for an M=16 problem (one workgroup per 128 columns walking the
-// whole K range); a decoding step is ~75 such GEMMs.  Here a workgroup owns 16 output columns for all rows,
-// stages A / B chunks of 128 k through LDS with 16-byte accesses, and the grid is N/16 (x heads) wide, so the
-// weight matrix is read by many CUs in parallel.  fp32 FMA, k ascending: same summation order as a per-thread
-// fmaf chain.
+// whole K range); a decoding step is ~60 such GEMMs.
+//
+// tb == 0 (B[n][k], k contiguous -- every Linear weight): matrix-core kernel.  A workgroup owns 32 output columns
+// for all rows; its 4 waves split the K range, each wave feeds the MFMA operands straight from global memory
+// (lane = row / column, 8 consecutive k: two 16-byte loads), splits them exactly into three bf16 terms in
+// registers and issues the six v_mfma_f32_32x32x16_bf16 of the fp32-accurate product (see gemm_engine.hip); the
+// four K partials are summed through LDS in a fixed order.  ~4 us for 64 x 512 x 512 against 36 us for the FMA
+// kernel below.
+// tb == 1 (B[k][n], n contiguous): LDS-staged fp32 FMA kernel, a workgroup owns 16 columns.
 #include "lvt_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct SmallParams {
     int M, N, K, tb;
@@ -81,6 +89,109 @@ __global__ __launch_bounds__(256) void lvt_gemm_smallm_kernel(const SmallParams 
     }
 }
 
+// ---- matrix-core path (tb == 0) -------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned sm_cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// 8 floats -> three planes of 8 bf16 (exact 3-way split, round-to-nearest-even at every level)
+__device__ __forceinline__ void sm_split8(const float4 lo, const float4 hi, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3) {
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    unsigned a[4], b[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = sm_cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
+        const float r0 = v[2 * i] - __uint_as_float(a[i] << 16), r1 = v[2 * i + 1] - __uint_as_float(a[i] & 0xffff0000u);
+        b[i] = sm_cvt_pk_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(b[i] << 16), s1 = r1 - __uint_as_float(b[i] & 0xffff0000u);
+        c[i] = sm_cvt_pk_bf16(s0, s1);
+    }
+    const uint4 ua = make_uint4(a[0], a[1], a[2], a[3]), ub = make_uint4(b[0], b[1], b[2], b[3]),
+                uc = make_uint4(c[0], c[1], c[2], c[3]);
+    p1 = *reinterpret_cast<const bf16x8 *>(&ua); p2 = *reinterpret_cast<const bf16x8 *>(&ub);
+    p3 = *reinterpret_cast<const bf16x8 *>(&uc);
+}
+__device__ __forceinline__ void sm_load8(const float *row, bool ok, int k, int K, float4 &lo, float4 &hi) {
+    lo = (ok && k < K) ? *reinterpret_cast<const float4 *>(row + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    hi = (ok && k + 4 < K) ? *reinterpret_cast<const float4 *>(row + k + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+#define SMM_WAVES 4
+template <int TM>      // TM = number of 32-row tiles (1: M <= 32, 2: M <= 64)
+__global__ __launch_bounds__(64 * SMM_WAVES) void lvt_gemm_smallm_mfma_kernel(const SmallParams p) {
+    __shared__ float red[SMM_WAVES][TM][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n0 = blockIdx.x * 32, z = blockIdx.y;
+    const float *B = p.B + z * p.sB;
+    // K range of this wave, in units of the 16-wide MFMA step
+    const int steps = (p.K + 15) / 16, per = (steps + SMM_WAVES - 1) / SMM_WAVES;
+    const int kbeg = wave * per * 16, kend = min(p.K, (wave + 1) * per * 16);
+    const int col = n0 + l31;
+    const float *brow = B + (long long)col * p.ldb;
+    const bool bok = col < p.N;
+    const float *arow[TM]; bool aok[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int m = 32 * t + l31;
+        aok[t] = m < p.M; arow[t] = p.A + (long long)m * p.lda;
+    }
+    f32x16 acc[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // operands of step s+1 are fetched while the MFMAs of step s run
+    float4 blo, bhi, alo[TM], ahi[TM];
+    int k = kbeg + 8 * half;
+    if (kbeg < kend) {
+        sm_load8(brow, bok, k, kend, blo, bhi);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) sm_load8(arow[t], aok[t], k, kend, alo[t], ahi[t]);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        bf16x8 b[3], a[TM][3];
+        sm_split8(blo, bhi, b[0], b[1], b[2]);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) sm_split8(alo[t], ahi[t], a[t][0], a[t][1], a[t][2]);
+        k += 16;
+        if (k0 + 16 < kend) {
+            sm_load8(brow, bok, k, kend, blo, bhi);
+#pragma unroll
+            for (int t = 0; t < TM; ++t) sm_load8(arow[t], aok[t], k, kend, alo[t], ahi[t]);
+        }
+        constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};     // smallest terms first
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][TA[q]], b[TB[q]], acc[t], 0, 0, 0);
+    }
+    // fixed-order sum of the K partials: wave w finalises accumulator registers 4w .. 4w+3 of every tile
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][t][r][lane] = acc[t][r];
+    __syncthreads();
+    if (!bok) return;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * wave + rr;
+            const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m >= p.M) continue;
+            float v = ((red[0][t][r][lane] + red[1][t][r][lane]) + red[2][t][r][lane]) + red[3][t][r][lane];
+            v *= p.alpha;
+            if (p.flags & LVT_EPI_BIAS) v += p.bias[col];
+            if (p.flags & LVT_EPI_RESIDUAL) v += p.res[(long long)m * p.ldr + col];
+            if (p.flags & LVT_EPI_RELU) v = fmaxf(v, 0.f);
+            p.C[z * p.sC + (long long)m * p.ldc + col] = v;
+        }
+}
+
 extern "C" int lvt_gemm_smallm_f32(int M, int N, int K, int tb, const float *A, long long lda, const float *B,
                                    long long ldb, float *C, long long ldc, int batch, long long sB, long long sC,
                                    float alpha, int flags, const float *bias, const float *res, long long ldr,
@@ -94,6 +205,13 @@ extern "C" int lvt_gemm_smallm_f32(int M, int N, int K, int tb, const float *A, 
     SmallParams p;
     p.M = M; p.N = N; p.K = K; p.tb = tb; p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
     p.sB = sB; p.sC = sC; p.alpha = alpha; p.flags = flags; p.bias = bias; p.res = res; p.ldr = ldr;
+    if (tb == 0 && K % 8 == 0) {
+        dim3 grid((unsigned)lvt_cdiv(N, 32), (unsigned)batch);
+        if (M <= 32) hipLaunchKernelGGL(lvt_gemm_smallm_mfma_kernel<1>, grid, dim3(64 * SMM_WAVES), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(lvt_gemm_smallm_mfma_kernel<2>, grid, dim3(64 * SMM_WAVES), 0, (hipStream_t)stream, p);
+        LVT_CHECK_LAUNCH("lvt_gemm_smallm_mfma_kernel");
+        return LVT_OK;
+    }
     dim3 grid((unsigned)lvt_cdiv(N, 16), (unsigned)batch);
     if (tb == 0) hipLaunchKernelGGL(lvt_gemm_smallm_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(lvt_gemm_smallm_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);

@@ -25,56 +25,92 @@ class IncrementalDecoder:
         d = decoder.linear_projector.weight.shape[0]
         self.d = d
         self.base = torch.empty(rows, d, dtype=torch.float32, device=dev)
-        self.begin_slice(zl_tok)
-        decoder.conv.rezero_()
         cw = decoder.conv.conv.weight
         self.de = cw.shape[1]
+        self.nc = len(decoder.ch_embedder)
+        # codes of the slice being decoded, with one extra always-padded position that out-of-range causal
+        # neighbours point at; `self.sl` is the (b, nc, t, h, w) view callers write drawn codes into
+        self.sl_ext = torch.full((b, self.nc, self.S + 1), -1, dtype=torch.int64, device=dev)
+        self.sl = self.sl_ext[:, :, :self.S].view(b, self.nc, t, h, w)
+        # single-position causal conv: x_i = sum over the taps that can see data of W_tap . emb[neighbour_tap(i)]
         kt, kh, kw = cw.shape[2:]
-        self.geom = G.conv_geom(b, t, h, w, self.de, d, (kt, kh, kw), (1, 1, 1), (kt - 1, kh - 1, kw // 2), out=(t, h, w))
-        self.wp = G.pack_weight(self.geom, cw, self.de, d)
-        self.tables = torch.cat([e.weight for e in decoder.ch_embedder], dim=0).contiguous()
+        self.taps = [(jt, jh, jw) for jt in range(kt) for jh in range(kh) for jw in range(kw)
+                     if not (jt == kt - 1 and jh == kh - 1 and jw >= kw // 2 and kw // 2 > 0)      # zeroed (non-causal) taps
+                     and kt - 1 - jt < t and kh - 1 - jh < h and abs(jw - kw // 2) < w]            # never inside the volume
+        nb = torch.full((self.S, len(self.taps)), self.S, dtype=torch.int64)
+        for ti in range(t):
+            for hi in range(h):
+                for wi in range(w):
+                    for j, (jt, jh, jw) in enumerate(self.taps):
+                        tt, hh, ww = ti + jt - (kt - 1), hi + jh - (kh - 1), wi + jw - kw // 2
+                        if tt >= 0 and hh >= 0 and 0 <= ww < w:
+                            nb[(ti * h + hi) * w + wi, j] = (tt * h + hh) * w + ww
+        self.nb = nb.to(dev)
+        self.wfront = torch.empty(d, len(self.taps) * self.de, dtype=torch.float32, device=dev)
+        self.tables = torch.empty(self.nc * decoder.ch_embedder[0].weight.shape[0], self.de, dtype=torch.float32, device=dev)
         self.layers = list(decoder.block_local_attention)
         m0 = self.layers[0].mha
         self.na, self.da = m0.na, m0.da
         hd = self.na * self.da
         self.kc = [torch.zeros(b, self.S, hd, dtype=torch.float32, device=dev) for _ in self.layers]
         self.vc = [torch.zeros(b, self.S, hd, dtype=torch.float32, device=dev) for _ in self.layers]
+        # per-head projection weights (na, d, da) re-laid out as one k-contiguous (na*da, d) matrix per projection,
+        # the layout the matrix-core small-M GEMM streams; refreshed at every begin_slice (weights may have been
+        # trained in between), in place so that captured graphs keep reading the same buffers
+        self.wqkv = [tuple(torch.empty(hd, d, dtype=torch.float32, device=dev) for _ in range(3)) for _ in self.layers]
+        self.begin_slice(zl_tok)
+
+    def _refresh_weights(self):
+        self.dec.conv.rezero_()
+        cw = self.dec.conv.conv.weight.detach()
+        for j, (jt, jh, jw) in enumerate(self.taps):
+            self.wfront[:, j * self.de:(j + 1) * self.de].copy_(cw[:, :, jt, jh, jw])
+        torch.cat([e.weight.detach() for e in self.dec.ch_embedder], dim=0, out=self.tables)
+        for layer, bufs in zip(self.layers, self.wqkv):
+            m = layer.mha
+            for w, buf in zip((m.w_q, m.w_k, m.w_v), bufs):
+                buf.view(self.na, self.da, self.d).copy_(w.detach().transpose(1, 2))
 
     def begin_slice(self, zl_tok):
         """position signal + projection of the encoder output: fixed for the whole slice (written in place so
         that captured graphs keep seeing the same buffer).  Stale cache rows need no reset: step(i) only reads
         keys 0..i, all of which are rewritten while the new slice is decoded."""
         t, h, w = self.thw
+        self._refresh_weights()
         G.gemm(zl_tok, self.dec.linear_projector.weight, self.base, self.b * self.S, self.d, self.d)
         self.dec.positional_encoder.add_tokens_(self.base, t, h, w)
 
-    def _front_row(self, sl, i):
-        """x_i = causal_conv(sum_k Emb_k(slice))[i] + pos[i] + proj(zl)[i]  -> (b, d)."""
-        b, nc = sl.shape[:2]
-        S, nv = self.S, self.tables.shape[0] // nc
-        emb = tx.embbag_fwd(sl, nc * S, S, b * S, [k * S for k in range(nc)], [k * nv for k in range(nc)],
-                            self.tables, self.de)
-        t, h, w = self.thw
-        x = G.conv_fwd(self.geom, emb.view(b, t, h, w, self.de), self.wp, bias=self.dec.conv.conv.bias,
-                       res=self.base.view(b, t, h, w, self.d))
-        return x.view(b, S, self.d)[:, i].contiguous()
+    def _front_row(self, i):
+        """x_i = causal_conv(sum_k Emb_k(slice))[i] + pos[i] + proj(zl)[i]  -> (b, d): the codes of the causal
+        neighbours of position i are gathered (integer plumbing), embedded and contracted with the packed taps."""
+        b, nc, nt = self.b, self.nc, len(self.taps)
+        nv = self.tables.shape[0] // nc
+        codes = self.sl_ext.index_select(2, self.nb[i])                              # (b, nc, taps), -1 = outside
+        a = tx.embbag_fwd(codes, nc * nt, nt, b * nt, [k * nt for k in range(nc)], [k * nv for k in range(nc)],
+                          self.tables, self.de)                                      # (b*taps, de) == (b, taps*de)
+        x = torch.empty(b, self.d, dtype=torch.float32, device=a.device)
+        G.gemm_small(a, self.wfront, x, b, self.d, nt * self.de, flags=L.EPI_BIAS | L.EPI_RESIDUAL,
+                     bias=self.dec.conv.conv.bias, res=self.base.view(-1)[i * self.d:], ldr=self.S * self.d)
+        return x
 
     def step(self, sl, i):
         """Hidden state y_i (b, d) of token i given the codes of tokens < i in `sl`; fills the caches at i."""
         b, d, S = self.b, self.d, self.S
         na, da = self.na, self.da
         hd = na * da
-        x = self._front_row(sl.contiguous(), i)
+        if sl.data_ptr() != self.sl.data_ptr():
+            self.sl.copy_(sl)
+        x = self._front_row(i)
         dev = x.device
         for li, layer in enumerate(self.layers):
             m, f = layer.mha, layer.ffn
             xn, _, _ = ew.layernorm_fwd(x, m.layer_norm.weight, m.layer_norm.bias, save_stats=False)
             q = torch.empty(b, hd, dtype=torch.float32, device=dev)
-            G.gemm_small(xn, m.w_q, q, b, da, d, tb=1, lda=d, ldb=da, ldc=hd, batch=na, sB=d * da, sC=da)
-            for w_, cache in ((m.w_k, self.kc[li]), (m.w_v, self.vc[li])):
+            wq, wk, wv = self.wqkv[li]
+            G.gemm_small(xn, wq, q, b, hd, d)
+            for w_, cache in ((wk, self.kc[li]), (wv, self.vc[li])):
                 # write row i of every sample straight into the cache: C = cache[0, i], row stride S*hd
-                G.gemm_small(xn, w_, cache.view(-1)[i * hd:], b, da, d, tb=1, lda=d, ldb=da, ldc=S * hd, batch=na,
-                             sB=d * da, sC=da)
+                G.gemm_small(xn, w_, cache.view(-1)[i * hd:], b, hd, d, ldc=S * hd)
             o = tx.attn_decode(q, self.kc[li], self.vc[li], na, i, math.sqrt(da), layer.dt_bank, layer.dh_bank,
                                layer.dw_bank, layer.block_size)
             y1 = torch.empty(b, d, dtype=torch.float32, device=dev)
@@ -106,10 +142,10 @@ class GraphedSliceSampler:
     def begin_slice(self, zl_tok, sl):
         if self.dec is None:
             self.dec = IncrementalDecoder(self.vt.decoder, zl_tok, self.b, self.thw)
-            self.sl = sl.clone()
+            self.sl = self.dec.sl                          # drawn codes go straight into the decoder's buffer
         else:
             self.dec.begin_slice(zl_tok)
-            self.sl.copy_(sl)
+        self.sl.copy_(sl)
 
     def _body(self, pos, sample):
         y = self.dec.step(self.sl, pos)

@@ -225,3 +225,19 @@ def test_math_modes_accuracy(math_mode):
         assert err["bf16x3"][0] <= 1.25 * err["f32"][0], (name, err)
         assert err["bf16x3"][1] <= 1.5 * err["f32"][1] + 1e-7, (name, err)
         assert err["bf16x3"][1] < 1e-5, (name, err)
+
+
+@pytest.mark.parametrize("M,N,K,tb", [(64, 512, 512, 0), (3, 512, 1024, 0), (33, 100, 136, 0), (64, 2048, 512, 0),
+                                      (16, 128, 512, 1), (64, 512, 2560, 0)])
+def test_gemm_small_m(M, N, K, tb):
+    """Decode-time GEMM (M <= 64): matrix-core kernel for k-contiguous weights, FMA kernel for n-contiguous ones;
+    bias + residual + ReLU epilogue; ragged M / N / K tails."""
+    from lvt_amd.hip import gemm as G, binding as L
+    a, b, r = _rand(M, K), _rand(N, seed=2), _rand(M, N, seed=3)
+    w = _rand(N, K, seed=1) if tb == 0 else _rand(K, N, seed=1)
+    ref = torch.relu((a.double() @ (w.double().t() if tb == 0 else w.double())) * 0.5 + b + r).float()
+    d = _dev()
+    out = torch.full((M, N), float("nan"), device=d)
+    G.gemm_small(a.to(d), w.to(d), out, M, N, K, tb=tb, alpha=0.5, flags=L.EPI_BIAS | L.EPI_RESIDUAL | L.EPI_RELU,
+                 bias=b.to(d), res=r.to(d))
+    assert rel_err(out, ref) < TOL
