@@ -199,6 +199,12 @@ int lvt_attn_decode(const float *q, const float *Kc, const float *Vc, int B, int
                     float temper, const float *dt, const float *dh, const float *dw, int bt, int bh, int bw,
                     float *o, void *stream);
 
+/* categorical draw per row from logits / temp with caller-supplied uniforms u[row] in [0,1) (the reference draws
+ * with torch.multinomial on softmax(logit / temp), videotransformer.py:176-181): code = #{ j : cdf_j <= u * total },
+ * clamped to V-1, written as int64 at out[row * out_stride]; `probs` (rows, V) is optional.  V <= 1024.   */
+int lvt_sample_categorical(const float *logits, long long rows, int V, float temp, const float *u,
+                           long long *out, long long out_stride, float *probs, void *stream);
+
 /* ---- embedding bags: the one-hot Conv3d / Embedding sums / one-hot Linear inputs as gathers (K13,K15,K25)
  * out[b*P+pos][:] = bias + btable[bindex[b]] + sum_s table[tab_row[s] + idx[b*bstride + off[s] + pos]][:]
  * (negative indices, i.e. PAD_VALUE, contribute nothing).                                             */

@@ -378,27 +378,32 @@ extern "C" int lvt_xent_bwd(const float *logits, const long long *target, long l
 // ------------------------------------------------------------------------------------------------
 // single-query attention against a K/V cache (incremental sampling):
 //   o[b][h][:] = softmax_j<=i( q.K_j / temper + bias(i, j) ) V_j     for the one query position i.
-// One wave per (b, h).  q (B, H*DA), caches (B, S, H*DA) token-major, o (B, H*DA).  DA == 128.
+// One workgroup of 4 waves per (b, h).  q (B, H*DA), caches (B, S, H*DA) token-major, o (B, H*DA).  DA == 128.
 // Same arithmetic as row i of the full causal layer (the masked columns j > i carry exp(-1e4 - m) == 0).
+// Scores: one key per thread (a 512-byte row each).  P.V: the keys are dealt to the 4 waves (j = w mod 4), every
+// lane owns 2 of the 128 output dims, and the 4 partial sums are added in wave order through LDS.
 // ------------------------------------------------------------------------------------------------
 #define DEC_DA 128
-__global__ __launch_bounds__(64) void lvt_attn_decode_kernel(const float *__restrict__ q, const float *__restrict__ Kc,
+#define DEC_WAVES 4
+__global__ __launch_bounds__(64 * DEC_WAVES) void lvt_attn_decode_kernel(const float *__restrict__ q, const float *__restrict__ Kc,
                                                              const float *__restrict__ Vc, int H, int S, int qi,
                                                              float temper, const float *__restrict__ dt,
                                                              const float *__restrict__ dh, const float *__restrict__ dw,
                                                              BiasGeom g, float *__restrict__ o) {
     __shared__ float qs[DEC_DA];
     __shared__ float ps[1024];
-    const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+    __shared__ float redm[DEC_WAVES], reds[DEC_WAVES];
+    __shared__ float acc[DEC_WAVES][DEC_DA];
+    const int b = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hd = H * DEC_DA;
     const float *qp = q + (long long)b * hd + h * DEC_DA;
-    qs[lane] = qp[lane]; qs[lane + 64] = qp[lane + 64];
+    if (tid < DEC_DA) qs[tid] = qp[tid];
     __syncthreads();
     const int nk = qi + 1;
     const int wi = qi % g.bw, hi = (qi / g.bw) % g.bh, ti = qi / (g.bw * g.bh);
     const float *bt = dt + h * (2 * g.bt - 1), *bhp = dh + h * (2 * g.bh - 1), *bwp = dw + h * (2 * g.bw - 1);
     float m = -3.4e38f;
-    for (int j = lane; j < nk; j += 64) {
+    for (int j = tid; j < nk; j += 64 * DEC_WAVES) {
         const float4 *kp = reinterpret_cast<const float4 *>(Kc + ((long long)b * S + j) * hd + h * DEC_DA);
         float s = 0.f;
 #pragma unroll 8
@@ -413,19 +418,75 @@ __global__ __launch_bounds__(64) void lvt_attn_decode_kernel(const float *__rest
         m = fmaxf(m, x);
     }
     m = wmax(m);
-    float sum = 0.f;
-    for (int j = lane; j < nk; j += 64) { const float e = expf(ps[j] - m); ps[j] = e; sum += e; }
-    sum = wsum(sum);
+    if (lane == 0) redm[wave] = m;
     __syncthreads();
+    m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    float sum = 0.f;
+    for (int j = tid; j < nk; j += 64 * DEC_WAVES) { const float e = expf(ps[j] - m); ps[j] = e; sum += e; }
+    sum = wsum(sum);
+    if (lane == 0) reds[wave] = sum;
+    __syncthreads();
+    sum = ((reds[0] + reds[1]) + reds[2]) + reds[3];
     float a0 = 0.f, a1 = 0.f;
     const float *vp = Vc + (long long)b * S * hd + h * DEC_DA;
-    for (int j = 0; j < nk; ++j) {
+    for (int j = wave; j < nk; j += DEC_WAVES) {
         const float p = ps[j];
         a0 = fmaf(p, vp[(long long)j * hd + lane], a0);
         a1 = fmaf(p, vp[(long long)j * hd + lane + 64], a1);
     }
-    float *op = o + (long long)b * hd + h * DEC_DA;
-    op[lane] = a0 / sum; op[lane + 64] = a1 / sum;
+    acc[wave][lane] = a0; acc[wave][lane + 64] = a1;
+    __syncthreads();
+    if (tid < DEC_DA)
+        o[(long long)b * hd + h * DEC_DA + tid] = (((acc[0][tid] + acc[1][tid]) + acc[2][tid]) + acc[3][tid]) / sum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// categorical draw from logits with a caller-supplied uniform (videotransformer.py:176-181: softmax(logit / temp)
+// followed by torch.multinomial; here the inverse-CDF rule of oracle.multinomial_from_uniform so that a draw is a
+// pure function of (logits, u)): code = #{ j : cdf_j <= u * total }, clamped to V-1.  One wave per row, V <= 1024.
+// The code is written as int64 at out[row * out_stride]; probabilities (row, V) are optional.
+// ------------------------------------------------------------------------------------------------
+#define SMP_MAXPER 16
+__global__ __launch_bounds__(64) void lvt_sample_categorical_kernel(const float *__restrict__ logits, int V, float inv_temp,
+                                                                    const float *__restrict__ u, long long *__restrict__ out,
+                                                                    long long out_stride, float *__restrict__ probs) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const float *x = logits + (long long)row * V;
+    const int per = (V + 63) / 64;                      // consecutive elements per lane: cdf order == memory order
+    const int j0 = lane * per;
+    float e[SMP_MAXPER];
+    float m = -3.4e38f;
+#pragma unroll
+    for (int i = 0; i < SMP_MAXPER; ++i) { e[i] = (i < per && j0 + i < V) ? x[j0 + i] * inv_temp : -3.4e38f; m = fmaxf(m, e[i]); }
+    m = wmax(m);
+    float loc = 0.f;
+#pragma unroll
+    for (int i = 0; i < SMP_MAXPER; ++i) { e[i] = (i < per && j0 + i < V) ? expf(e[i] - m) : 0.f; loc += e[i]; }
+    // exclusive scan of the lane sums
+    float incl = loc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const float t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    const float total = __shfl(incl, 63, 64);
+    const float thr = u[row] * total;
+    float c = incl - loc;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < SMP_MAXPER; ++i) { c += e[i]; if (i < per && j0 + i < V && c <= thr) ++cnt; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+    if (lane == 0) out[row * out_stride] = cnt < V - 1 ? cnt : V - 1;
+    if (probs)
+#pragma unroll
+        for (int i = 0; i < SMP_MAXPER; ++i) if (i < per && j0 + i < V) probs[(long long)row * V + j0 + i] = e[i] / total;
+}
+
+extern "C" int lvt_sample_categorical(const float *logits, long long rows, int V, float temp, const float *u,
+                                      long long *out, long long out_stride, float *probs, void *stream) {
+    LVT_REQUIRE(logits && u && out && rows > 0 && V > 0 && V <= 64 * SMP_MAXPER && temp > 0.f, "sample_categorical: bad args");
+    hipLaunchKernelGGL(lvt_sample_categorical_kernel, dim3((unsigned)rows), dim3(64), 0, (hipStream_t)stream, logits, V,
+                       1.f / temp, u, out, out_stride, probs);
+    LVT_CHECK_LAUNCH("lvt_sample_categorical_kernel");
+    return LVT_OK;
 }
 
 extern "C" int lvt_attn_decode(const float *q, const float *Kc, const float *Vc, int B, int H, int S, int da, int qi,
@@ -434,7 +495,7 @@ extern "C" int lvt_attn_decode(const float *q, const float *Kc, const float *Vc,
     LVT_REQUIRE(q && Kc && Vc && dt && dh && dw && o && B > 0 && H > 0, "attn_decode: bad args");
     LVT_REQUIRE(da == DEC_DA && S == bt * bh * bw && S <= 1024 && qi >= 0 && qi < S, "attn_decode: unsupported shape");
     BiasGeom g = {bt, bh, bw};
-    hipLaunchKernelGGL(lvt_attn_decode_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, q, Kc, Vc, H, S, qi,
+    hipLaunchKernelGGL(lvt_attn_decode_kernel, dim3(B * H), dim3(64 * DEC_WAVES), 0, (hipStream_t)stream, q, Kc, Vc, H, S, qi,
                        temper, dt, dh, dw, g, o);
     LVT_CHECK_LAUNCH("lvt_attn_decode_kernel");
     return LVT_OK;

@@ -126,3 +126,14 @@ def attn_decode(q, Kc, Vc, H, qi, temper, dt, dh, dw, block):
                                     L.ptr(dw), block[0], block[1], block[2], L.ptr(o), L.stream_ptr()),
             "lvt_attn_decode")
     return o
+
+
+def sample_categorical(logits, temp, u, out, out_stride=1, want_probs=False):
+    """Draw one code per row of `logits` (rows, V) with the uniforms `u` (rows,); the int64 codes go to
+    out.data_ptr() + row * out_stride (elements).  Returns the probabilities when asked for."""
+    L.require(logits, u)
+    rows, V = logits.shape
+    probs = torch.empty(rows, V, dtype=torch.float32, device=logits.device) if want_probs else None
+    L.check(L.lib().lvt_sample_categorical(L.ptr(logits), rows, V, float(temp), L.ptr(u), C.c_void_p(out.data_ptr()),
+                                           out_stride, L.ptr(probs), L.stream_ptr()), "lvt_sample_categorical")
+    return probs

@@ -145,6 +145,7 @@ class GraphedSliceSampler:
             self.sl = self.dec.sl                          # drawn codes go straight into the decoder's buffer
         else:
             self.dec.begin_slice(zl_tok)
+        self.vt.ch_predictor.prepare_decode()
         self.sl.copy_(sl)
 
     def _body(self, pos, sample):

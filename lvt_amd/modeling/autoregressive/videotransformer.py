@@ -344,27 +344,44 @@ class ChannelPredictor(nn.Module):
         rows = yl_tok.view(b, P, d)[:, pos].contiguous()                      # (b, d)
         return self.sample_from_rows(rows, temp, forced_codes, return_probs)
 
+    def prepare_decode(self):
+        """Transposed copies of the one-hot columns of U_k ((k*nv, d) gather tables), refreshed IN PLACE so that
+        captured decode graphs keep reading the same buffers; call once per slice before sample_from_rows."""
+        d = self.layer_norm.weight.shape[0]
+        if getattr(self, "_ut", None) is None:
+            self._ut = [None] + [torch.empty(k * self.nv, d, dtype=torch.float32, device=self.U[k].weight.device)
+                                 for k in range(1, self.nc)]
+        for k in range(1, self.nc):
+            self._ut[k].copy_(self.U[k].weight.detach()[:, d:d + k * self.nv].t())
+
     def sample_from_rows(self, rows, temp=1.0, forced_codes=None, return_probs=False):
         """rows (b, d): decoder hidden state of ONE position per sample -> codes (b, nc)."""
         b, d = rows.shape
+        cached = getattr(self, "_ut", None)
         y, _, _ = ew.layernorm_fwd(rows, self.layer_norm.weight, self.layer_norm.bias, save_stats=False)
         codes = torch.zeros(b, self.nc, 1, dtype=torch.int64, device=rows.device)
         probs = []
+        # one uniform per (sample, channel); a draw is then a pure function of (logits, u) -- lvt_sample_categorical
+        u = torch.rand(self.nc, b, device=rows.device) if forced_codes is None else None
         for k in range(self.nc):
             uw, pw = self.U[k].weight, self.P[k].weight
             res = None
             if k > 0:
-                ut = _permute_cols(uw, d, k * self.nv)
+                ut = cached[k] if cached is not None else _permute_cols(uw, d, k * self.nv)
                 res = tx.embbag_fwd(codes, self.nc, 1, b, list(range(k)), [c * self.nv for c in range(k)], ut, d)
-            u = torch.empty(b, d, dtype=torch.float32, device=y.device)
-            G.gemm_small(y, uw, u, b, d, d, ldb=uw.shape[1], flags=L.EPI_BIAS | L.EPI_RELU | (L.EPI_RESIDUAL if k else 0),
+            u_ = torch.empty(b, d, dtype=torch.float32, device=y.device)
+            G.gemm_small(y, uw, u_, b, d, d, ldb=uw.shape[1], flags=L.EPI_BIAS | L.EPI_RELU | (L.EPI_RESIDUAL if k else 0),
                          bias=self.U[k].bias, res=res)
             o = torch.empty(b, self.nv, dtype=torch.float32, device=y.device)
-            G.gemm_small(u, pw, o, b, self.nv, d, flags=L.EPI_BIAS, bias=self.P[k].bias)
-            prob = torch.softmax(o / temp, 1)
-            probs.append(prob)
-            codes[:, k, 0] = (torch.multinomial(prob, 1).squeeze(-1) if forced_codes is None
-                              else forced_codes[:, k].to(codes.device))
+            G.gemm_small(u_, pw, o, b, self.nv, d, flags=L.EPI_BIAS, bias=self.P[k].bias)
+            if forced_codes is None:
+                # writes codes[:, k, 0] (element stride nc between samples)
+                pr = tx.sample_categorical(o, temp, u[k], codes.view(-1)[k:], self.nc, want_probs=return_probs)
+                if return_probs:
+                    probs.append(pr)
+            else:
+                probs.append(torch.softmax(o / temp, 1))
+                codes[:, k, 0] = forced_codes[:, k].to(codes.device)
         if return_probs:
             return codes[:, :, 0], torch.stack(probs, 1)
         return codes[:, :, 0]

@@ -77,3 +77,27 @@ def test_sample_videos_contract_and_priming(vt):
     with torch.no_grad():
         res = vt([{"image_sequence": codes[0]}], mode="inference")
     assert len(res) == 1 and len(res[0]["samples"]) == 1 and tuple(res[0]["samples"][0].shape) == (4, 16, 16, 16)
+
+
+def test_sample_categorical_matches_oracle_rule():
+    """lvt_sample_categorical == oracle.multinomial_from_uniform on softmax(logits / temp) (rows whose threshold
+    is not within rounding of a cdf step), and its probabilities == softmax."""
+    from lvt_amd.hip import tx
+    g = torch.Generator().manual_seed(11)
+    logits = torch.randn(300, 512, generator=g) * 3
+    u = torch.rand(300, generator=g)
+    u[0], u[1] = 0.0, 0.999999
+    temp = 0.9
+    prob = torch.softmax(logits.double() / temp, 1)
+    want = O.multinomial_from_uniform(prob, u.double())
+    cdf = torch.cumsum(prob, 1)
+    margin = (cdf - (u.double() * cdf[:, -1]).unsqueeze(1)).abs().min(1).values
+    out = torch.full((300, 4), -1, dtype=torch.int64, device=DEV)
+    pr = tx.sample_categorical(logits.to(DEV), temp, u.to(DEV), out.view(-1)[2:], 4, want_probs=True)
+    got = out[:, 2].cpu()
+    safe = margin > 1e-5
+    assert int(safe.sum()) > 280
+    assert torch.equal(got[safe], want[safe])
+    assert bool(((got - want).abs() <= 1).all())
+    assert bool((out[:, [0, 1, 3]] == -1).all())
+    assert rel_err(pr, prob.float()) < 1e-5
