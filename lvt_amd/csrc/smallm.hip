@@ -3,11 +3,9 @@
 // whole K range); a decoding step is ~60 such GEMMs.
 //
 // tb == 0 (B[n][k], k contiguous -- every Linear weight): matrix-core kernel.  A workgroup owns 32 output columns
-// for all rows; its 4 waves split the K range, each wave feeds the MFMA operands straight from global memory
-// (lane = row / column, 8 consecutive k: two 16-byte loads), splits them exactly into three bf16 terms in
-// registers and issues the six v_mfma_f32_32x32x16_bf16 of the fp32-accurate product (see gemm_engine.hip); the
-// four K partials are summed through LDS in a fixed order.  ~4 us for 64 x 512 x 512 against 36 us for the FMA
-// kernel below.
+// for all rows; operands are staged through LDS with coalesced loads, split exactly into three bf16 terms in
+// registers and multiplied with the six v_mfma_f32_32x32x16_bf16 of the fp32-accurate product (see
+// gemm_engine.hip); the waves' K partials are summed through LDS in a fixed order.
 // tb == 1 (B[k][n], n contiguous): LDS-staged fp32 FMA kernel, a workgroup owns 16 columns.
 #include "lvt_common.h"
 
@@ -112,78 +110,112 @@ __device__ __forceinline__ void sm_split8(const float4 lo, const float4 hi, bf16
     p1 = *reinterpret_cast<const bf16x8 *>(&ua); p2 = *reinterpret_cast<const bf16x8 *>(&ub);
     p3 = *reinterpret_cast<const bf16x8 *>(&uc);
 }
-__device__ __forceinline__ void sm_load8(const float *row, bool ok, int k, int K, float4 &lo, float4 &hi) {
-    lo = (ok && k < K) ? *reinterpret_cast<const float4 *>(row + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    hi = (ok && k + 4 < K) ? *reinterpret_cast<const float4 *>(row + k + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-#define SMM_WAVES 4
+#define SMM_WAVES 8
+#define SMM_KC 128                    // k per staged chunk: 8 MFMA steps, one per wave
+#define SMM_LDK (SMM_KC + 4)          // LDS row stride (floats): 16-byte fragment reads of 16 rows hit 16 bank groups
+// Direct per-lane fragment loads (lane = row) give the texture addresser one 16-byte request per lane -- measured
+// ~1 lane per cycle per CU, 5.6 us for 64x512x512.  Instead the 256 threads fetch every 128-k chunk of A (64 rows)
+// and B (32 rows) with fully coalesced 16-byte loads (a wave covers one 512-byte row segment), park it in LDS as
+// fp32, and the waves read their MFMA fragments from there (conflict-free ds_read_b128).  Chunk c+1 is in flight
+// in registers while chunk c is multiplied; each of the 8 waves takes one of the 8 k-steps (the split / MFMA chains
+// of two waves share a SIMD and overlap) and the partial tiles are added in wave order through LDS.
 template <int TM>      // TM = number of 32-row tiles (1: M <= 32, 2: M <= 64)
 __global__ __launch_bounds__(64 * SMM_WAVES) void lvt_gemm_smallm_mfma_kernel(const SmallParams p) {
-    __shared__ float red[SMM_WAVES][TM][16][64];
+    constexpr int AR = 32 * TM;                                   // staged A rows
+    constexpr int NA = AR * (SMM_KC / 4) / (64 * SMM_WAVES);      // float4 per thread per chunk (A)
+    constexpr int NB = 32 * (SMM_KC / 4) / (64 * SMM_WAVES);      // (B)
+    constexpr int STAGE = 2 * (AR + 32) * SMM_LDK, REDN = SMM_WAVES * TM * 16 * 64;
+    __shared__ __attribute__((aligned(16))) float smem[STAGE > REDN ? STAGE : REDN];     // staging, then the reduction
+    float (*As)[AR][SMM_LDK] = reinterpret_cast<float (*)[AR][SMM_LDK]>(smem);
+    float (*Bs)[32][SMM_LDK] = reinterpret_cast<float (*)[32][SMM_LDK]>(smem + 2 * AR * SMM_LDK);
+    float (*red)[TM][16][64] = reinterpret_cast<float (*)[TM][16][64]>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int n0 = blockIdx.x * 32, z = blockIdx.y;
     const float *B = p.B + z * p.sB;
-    // K range of this wave, in units of the 16-wide MFMA step
-    const int steps = (p.K + 15) / 16, per = (steps + SMM_WAVES - 1) / SMM_WAVES;
-    const int kbeg = wave * per * 16, kend = min(p.K, (wave + 1) * per * 16);
-    const int col = n0 + l31;
-    const float *brow = B + (long long)col * p.ldb;
-    const bool bok = col < p.N;
-    const float *arow[TM]; bool aok[TM];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-        const int m = 32 * t + l31;
-        aok[t] = m < p.M; arow[t] = p.A + (long long)m * p.lda;
-    }
+    const int nchunks = (p.K + SMM_KC - 1) / SMM_KC;
+    constexpr int RP = 64 * SMM_WAVES / 32;                       // rows covered per pass of the workgroup
+    const int q4 = (tid & 31) * 4, r0 = tid >> 5;                 // this thread's float4 column and first row
+
     f32x16 acc[TM];
 #pragma unroll
     for (int t = 0; t < TM; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // operands of step s+1 are fetched while the MFMAs of step s run
-    float4 blo, bhi, alo[TM], ahi[TM];
-    int k = kbeg + 8 * half;
-    if (kbeg < kend) {
-        sm_load8(brow, bok, k, kend, blo, bhi);
+    float4 ra[NA], rb[NB];
+    auto fetch = [&](int c) {
+        const int k = c * SMM_KC + q4;
 #pragma unroll
-        for (int t = 0; t < TM; ++t) sm_load8(arow[t], aok[t], k, kend, alo[t], ahi[t]);
-    }
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        bf16x8 b[3], a[TM][3];
-        sm_split8(blo, bhi, b[0], b[1], b[2]);
-#pragma unroll
-        for (int t = 0; t < TM; ++t) sm_split8(alo[t], ahi[t], a[t][0], a[t][1], a[t][2]);
-        k += 16;
-        if (k0 + 16 < kend) {
-            sm_load8(brow, bok, k, kend, blo, bhi);
-#pragma unroll
-            for (int t = 0; t < TM; ++t) sm_load8(arow[t], aok[t], k, kend, alo[t], ahi[t]);
+        for (int i = 0; i < NA; ++i) {
+            const int m = r0 + RP * i;
+            ra[i] = (m < p.M && k < p.K) ? *reinterpret_cast<const float4 *>(p.A + (long long)m * p.lda + k)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};     // smallest terms first
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int i = 0; i < NB; ++i) {
+            const int n = n0 + r0 + RP * i;
+            rb[i] = (n < p.N && k < p.K) ? *reinterpret_cast<const float4 *>(B + (long long)n * p.ldb + k)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<float4 *>(&As[buf][r0 + RP * i][q4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<float4 *>(&Bs[buf][r0 + RP * i][q4]) = rb[i];
+    };
+
+    fetch(0);
+    park(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) fetch(c + 1);
+        {
+            const int kk = 16 * wave;                             // k offset of this wave's step inside the chunk
+            const int ko = kk + 8 * half;
+            if (c * SMM_KC + kk < p.K) {
+            bf16x8 b[3], a[TM][3];
+            sm_split8(*reinterpret_cast<const float4 *>(&Bs[buf][l31][ko]), *reinterpret_cast<const float4 *>(&Bs[buf][l31][ko + 4]),
+                      b[0], b[1], b[2]);
 #pragma unroll
             for (int t = 0; t < TM; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][TA[q]], b[TB[q]], acc[t], 0, 0, 0);
+                sm_split8(*reinterpret_cast<const float4 *>(&As[buf][32 * t + l31][ko]),
+                          *reinterpret_cast<const float4 *>(&As[buf][32 * t + l31][ko + 4]), a[t][0], a[t][1], a[t][2]);
+            constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};     // smallest terms first
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][TA[q]], b[TB[q]], acc[t], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) {
+            park(buf ^ 1);            // the other buffer was last read before the barrier that ended chunk c-1
+            __syncthreads();
+        }
     }
-    // fixed-order sum of the K partials: wave w finalises accumulator registers 4w .. 4w+3 of every tile
+    // fixed-order sum of the waves' partial tiles (the staging memory is reused): wave w finalises accumulator
+    // registers 2w, 2w+1
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < TM; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave][t][r][lane] = acc[t][r];
     __syncthreads();
-    if (!bok) return;
+    const int col = n0 + l31;
+    if (col >= p.N) return;
 #pragma unroll
     for (int t = 0; t < TM; ++t)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = 4 * wave + rr;
+        for (int rr = 0; rr < 16 / SMM_WAVES; ++rr) {
+            const int r = (16 / SMM_WAVES) * wave + rr;
             const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (m >= p.M) continue;
-            float v = ((red[0][t][r][lane] + red[1][t][r][lane]) + red[2][t][r][lane]) + red[3][t][r][lane];
+            float v = red[0][t][r][lane];
+#pragma unroll
+            for (int w = 1; w < SMM_WAVES; ++w) v += red[w][t][r][lane];
             v *= p.alpha;
             if (p.flags & LVT_EPI_BIAS) v += p.bias[col];
             if (p.flags & LVT_EPI_RESIDUAL) v += p.res[(long long)m * p.ldr + col];
