@@ -97,7 +97,7 @@ def vqvae_step(model, optimizers, data, storage_iter):
     return losses
 
 
-def bench_dsfvt(device, world, rank, steps, warmup, batch):
+def bench_dsfvt(device, world, rank, steps, warmup, batch, strict_f32=True):
     """Secondary figure: DSFVT train step (fwd + bwd + RMSprop) on synthetic code clips, one random
     subscale slice per clip (BASELINE.json configs[2]); reported under `extra.dsfvt`."""
     from lvt_amd.config import get_cfg
@@ -156,12 +156,35 @@ def bench_dsfvt(device, world, rank, steps, warmup, batch):
     summ = timer.summary()
     eng_ms = sum(v_["ms"] for v_ in summ.values())
     eng_fl = sum(v_["flops"] for v_ in summ.values())
-    return {"samples_per_s": round(batch * world * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 2),
-            "batch_per_gpu": batch, "loss": round(float(loss.detach()), 5),
-            "engine_tflops": round(eng_fl / (eng_ms * 1e-3) / 1e12, 2) if eng_ms else None,
-            "engine_ms_per_step": round(eng_ms / steps, 2),
-            "note": "one subscale slice (256 tokens x 4 code channels) of one 16-frame clip per sample; "
-                    "fp32 data; 49.87M parameters; engine_tflops counts algorithmic fp32 GEMM FLOPs of the engine launches (event-timed in a second pass)"}
+    out = {"samples_per_s": round(batch * world * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 2),
+           "batch_per_gpu": batch, "loss": round(float(loss.detach()), 5),
+           "engine_tflops": round(eng_fl / (eng_ms * 1e-3) / 1e12, 2) if eng_ms else None,
+           "engine_ms_per_step": round(eng_ms / steps, 2),
+           "engine_frac_of_peak": round(eng_fl / (eng_ms * 1e-3) / 1e12 / engine_peak(L.get_math_mode()), 4) if eng_ms else None,
+           "note": "one subscale slice (256 tokens x 4 code channels) of one 16-frame clip per sample; fp32 data; 49.87M "
+                   "parameters; engine_tflops counts algorithmic fp32 GEMM FLOPs of the engine launches (event-timed "
+                   "in a second pass)"}
+    if L.get_math_mode() != "f32" and strict_f32:
+        # MFMA utilisation of the attention / MLP GEMMs on the plain fp32 instruction (target: >= 50 %)
+        mode = L.get_math_mode()
+        L.set_math_mode("f32")
+        for i in range(2):
+            step(i)
+        torch.cuda.synchronize()
+        L.TIMER = L.KernelTimer()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        timer, L.TIMER = L.TIMER, None
+        L.set_math_mode(mode)
+        s2 = timer.summary()
+        ms2 = sum(v_["ms"] for v_ in s2.values())
+        fl2 = sum(v_["flops"] for v_ in s2.values())
+        out["strict_f32_mfma"] = {"engine_tflops": round(fl2 / (ms2 * 1e-3) / 1e12, 2),
+                                  "mfma_utilisation": round(fl2 / (ms2 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                  "note": "LVT_MATH=f32: the same GEMM launches on v_mfma_f32_32x32x2_f32, fraction of "
+                                          "the 157.3 TFLOP/s fp32 MFMA peak"}
+    return out
 
 
 def bench_generate(device, batch):
@@ -338,7 +361,8 @@ def main():
     if not args.no_dsfvt:
         del model, optimizers, clips, data
         torch.cuda.empty_cache()
-        extra["dsfvt"] = bench_dsfvt(device, world, rank, max(3, args.steps // 4), 2, args.dsfvt_batch)
+        extra["dsfvt"] = bench_dsfvt(device, world, rank, max(3, args.steps // 4), 2, args.dsfvt_batch,
+                                     strict_f32=not args.no_strict_f32)
     if not args.no_generate and rank == 0 and world == 1:
         torch.cuda.empty_cache()
         extra["generate"] = bench_generate(device, args.generate_batch)
