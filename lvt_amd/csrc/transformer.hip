@@ -36,21 +36,24 @@ __global__ void lvt_attn_softmax_fwd_kernel(float *__restrict__ scores, int B, i
         float *p = scores + row * S;
         float v[SM_MAXC][4];
         float m = -3.4e38f;
+        const float inv_temper = 1.f / temper;
 #pragma unroll
         for (int c = 0; c < SM_MAXC; ++c) {
             if (c < nc) {
                 const int j0 = c * 256 + lane * 4;
                 const float4 x4 = *reinterpret_cast<const float4 *>(p + j0);
                 const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+                // key coordinates of j0, then stepped with carries (no division per element)
+                int wj = j0 % g.bw, q = j0 / g.bw;
+                int hj = q % g.bh, tj = q / g.bh;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int j = j0 + e;
-                    const int wj = j % g.bw, hj = (j / g.bw) % g.bh, tj = j / (g.bw * g.bh);
                     const float bias = (bt[ti - tj + g.bt - 1] + bhp[hi - hj + g.bh - 1]) + bwp[wi - wj + g.bw - 1];
-                    float x = xs[e] / temper + bias;
-                    if (masked && j > i) x = fill;
+                    float x = xs[e] * inv_temper + bias;
+                    if (masked && j0 + e > i) x = fill;
                     v[c][e] = x;
                     m = fmaxf(m, x);
+                    if (++wj == g.bw) { wj = 0; if (++hj == g.bh) { hj = 0; ++tj; } }
                 }
             }
         }
@@ -62,12 +65,12 @@ __global__ void lvt_attn_softmax_fwd_kernel(float *__restrict__ scores, int B, i
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[c][e] = expf(v[c][e] - m); s += v[c][e]; }
             }
-        s = wsum(s);
+        s = 1.f / wsum(s);
 #pragma unroll
         for (int c = 0; c < SM_MAXC; ++c)
             if (c < nc)
                 *reinterpret_cast<float4 *>(p + c * 256 + lane * 4) =
-                    make_float4(v[c][0] / s, v[c][1] / s, v[c][2] / s, v[c][3] / s);
+                    make_float4(v[c][0] * s, v[c][1] * s, v[c][2] * s, v[c][3] * s);
     }
 }
 
@@ -114,37 +117,86 @@ __global__ void lvt_attn_softmax_bwd_kernel(const float *__restrict__ P, float *
     }
 }
 
-// d bank[h][entry] = sum over (i, j) whose coordinate difference selects `entry`; one workgroup per
-// (h, bank, entry), fixed-order tree reduction.
-__global__ __launch_bounds__(256) void lvt_attn_bank_grad_kernel(const float *__restrict__ G, int H, int S,
-                                                                 BiasGeom g, float *__restrict__ ddt,
-                                                                 float *__restrict__ ddh, float *__restrict__ ddw) {
-    __shared__ float red[256];
+// d bank[h][entry] = sum over (i, j) whose coordinate difference selects `entry`.  One workgroup of 16 waves per
+// head; a wave stages one row G[h][i][:] in LDS at a time, lane e owns bank entry e (dt entries, then dh, then dw;
+// at most 64 of them) and adds the row's elements that select it -- a strided walk over the row, no divisions in
+// the inner loop, every element of G visited by exactly the lanes that need it.  The 16 wave partials are added
+// in wave order: bit-reproducible, no atomics.
+#define BG_WAVES 16
+__global__ __launch_bounds__(64 * BG_WAVES) void lvt_attn_bank_grad_kernel(const float *__restrict__ G, int H, int S,
+                                                                           BiasGeom g, float *__restrict__ ddt,
+                                                                           float *__restrict__ ddh, float *__restrict__ ddw) {
+    __shared__ __attribute__((aligned(16))) float rowbuf[BG_WAVES][1024];
+    __shared__ float red[BG_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nt = 2 * g.bt - 1, nh = 2 * g.bh - 1, nw = 2 * g.bw - 1;
-    const int per_h = nt + nh + nw;
-    const int h = blockIdx.x / per_h;
-    int e = blockIdx.x % per_h;
-    int which = 0;
-    if (e >= nt) { e -= nt; which = 1; if (e >= nh) { e -= nh; which = 2; } }
+    const int h = blockIdx.x;
     const float *Gh = G + (long long)h * S * S;
-    float s = 0.f;
-    for (int idx = threadIdx.x; idx < S * S; idx += 256) {
-        const int i = idx / S, j = idx % S;
-        int di;
-        if (which == 0) di = i / (g.bw * g.bh) - j / (g.bw * g.bh) + g.bt - 1;
-        else if (which == 1) di = (i / g.bw) % g.bh - (j / g.bw) % g.bh + g.bh - 1;
-        else di = i % g.bw - j % g.bw + g.bw - 1;
-        if (di == e) s += Gh[idx];
+    // which bank / which difference this lane accumulates
+    int which = -1, e = lane;
+    if (e < nt) which = 0;
+    else if ((e -= nt) < nh) which = 1;
+    else if ((e -= nh) < nw) which = 2;
+    float acc = 0.f;
+    float *rb = rowbuf[wave];
+    // the next row is in flight in registers while the current one is reduced (S <= 1024: 4 float4 per lane)
+    float4 nxt[4];
+    auto fetch = [&](int i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (lane * 4 + 256 * u < S) nxt[u] = *reinterpret_cast<const float4 *>(Gh + (long long)i * S + lane * 4 + 256 * u);
+    };
+    if (wave < S) fetch(wave);
+    for (int i = wave; i < S; i += BG_WAVES) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (lane * 4 + 256 * u < S) *reinterpret_cast<float4 *>(rb + lane * 4 + 256 * u) = nxt[u];
+        if (i + BG_WAVES < S) fetch(i + BG_WAVES);
+        __builtin_amdgcn_wave_barrier();
+        const int wi = i % g.bw, hi = (i / g.bw) % g.bh, ti = i / (g.bw * g.bh);
+        // four running sums per lane keep the adds independent; they are combined in a fixed order
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        // dt entries: a whole (h, w) plane each -- summed by the wave together (lane c holds elements 4c..4c+3 of
+        // every 256-chunk), the owning lane keeps the total
+        for (int tj = 0; tj < g.bt; ++tj) {
+            const int lo = tj * g.bh * g.bw, hi_ = lo + g.bh * g.bw;
+            float part = 0.f;
+            for (int c = lane * 4; c < S; c += 256)
+                if (c >= lo && c < hi_) { const float4 v = *reinterpret_cast<const float4 *>(rb + c); part += (v.x + v.y) + (v.z + v.w); }
+            part = wsum(part);
+            if (which == 0 && e == ti + g.bt - 1 - tj) a0 += part;
+        }
+        if (which == 0) {
+        } else if (which == 1) {
+            const int hj = hi + g.bh - 1 - e;
+            if (hj >= 0 && hj < g.bh)
+                for (int tj = 0; tj < g.bt; ++tj) {
+                    const float *q = rb + (tj * g.bh + hj) * g.bw;
+#pragma unroll 4
+                    for (int k = 0; k + 3 < g.bw; k += 4) { a0 += q[k]; a1 += q[k + 1]; a2 += q[k + 2]; a3 += q[k + 3]; }
+                    for (int k = g.bw & ~3; k < g.bw; ++k) a0 += q[k];
+                }
+        } else if (which == 2) {
+            const int wj = wi + g.bw - 1 - e;
+            if (wj >= 0 && wj < g.bw) {
+                const int n = g.bt * g.bh;
+#pragma unroll 4
+                for (int k = 0; k + 3 < n; k += 4) {
+                    a0 += rb[k * g.bw + wj]; a1 += rb[(k + 1) * g.bw + wj]; a2 += rb[(k + 2) * g.bw + wj]; a3 += rb[(k + 3) * g.bw + wj];
+                }
+                for (int k = n & ~3; k < n; ++k) a0 += rb[k * g.bw + wj];
+            }
+        }
+        acc += (a0 + a1) + (a2 + a3);
+        __builtin_amdgcn_wave_barrier();
     }
-    red[threadIdx.x] = s;
+    red[wave][lane] = acc;
     __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
-        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
+    if (wave == 0 && which >= 0) {
+        float v = red[0][lane];
+        for (int w = 1; w < BG_WAVES; ++w) v += red[w][lane];
         float *dst = which == 0 ? ddt + h * nt : (which == 1 ? ddh + h * nh : ddw + h * nw);
-        dst[e] = red[0];
+        dst[e] = v;
     }
 }
 
@@ -174,7 +226,8 @@ extern "C" int lvt_attn_softmax_bwd(const float *P, float *dP, int B, int H, int
     LVT_CHECK_LAUNCH("lvt_attn_softmax_bwd_kernel");
     BiasGeom g = {bt, bh, bw};
     const int per_h = (2 * bt - 1) + (2 * bh - 1) + (2 * bw - 1);
-    hipLaunchKernelGGL(lvt_attn_bank_grad_kernel, dim3(H * per_h), dim3(256), 0, s, G, H, S, g, ddt, ddh, ddw);
+    LVT_REQUIRE(per_h <= 64 && S <= 1024 && (bh * bw) % 4 == 0, "attn_softmax_bwd: %d bank entries per head (max 64)", per_h);
+    hipLaunchKernelGGL(lvt_attn_bank_grad_kernel, dim3(H), dim3(64 * BG_WAVES), 0, s, G, H, S, g, ddt, ddh, ddw);
     LVT_CHECK_LAUNCH("lvt_attn_bank_grad_kernel");
     return LVT_OK;
 }
