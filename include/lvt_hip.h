@@ -108,9 +108,11 @@ int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, cons
  * Requires Kt % st == 0 etc. and To*st == Ti-ish geometries produced by lvt_conv geometry helpers.  */
 int lvt_conv3d_bwd_data(const lvt_conv_geom *g, const float *dy, const float *wp, const float *bias,
                         const float *res, const float *mask, float *dx, int flags, void *stream);
-/* dw[Co_real][Ci_real][Kt][Kh][Kw] = sum_pixels x (*) dy, deterministic split-K through workspace.  */
+/* dw[Co_real][Ci_real][Kt][Kh][Kw] = sum_pixels x (*) dy, deterministic split-K through workspace.
+ * db (nullable, Co_real floats) = sum_pixels dy: the bias gradient, accumulated from the dy tiles the kernel streams
+ * anyway (no second pass over dy).                                                                         */
 size_t lvt_conv3d_bwd_weight_workspace_bytes(const lvt_conv_geom *g);
-int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, const float *dy, float *dw,
+int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, float *db,
                           int Ci_real, int Co_real, void *workspace, size_t workspace_bytes,
                           void *stream);
 /* Image-side layers (3 channels carried as 4): LDS-tiled fp32 FMA kernels that read the 128-channel activation

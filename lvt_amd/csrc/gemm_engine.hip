@@ -44,6 +44,7 @@ struct KParams {
     float alpha; int flags;
     const float *bias; const float *res; long long ldr; const float *mask; long long ldm;
     int splits; int k_per_split; float *partial; long long partial_stride;
+    float *colsum_partial;   // bwd-weight: [splits][N] column sums of B (= bias gradient), written by the m0 == 0 tiles
     lvt_conv_geom g;
     int Tq, Hq, Wq;          // A_CONVT_K: per-phase output extents
     int jT, jH, jW;          // A_CONVT_K: taps per phase and dimension
@@ -497,11 +498,13 @@ template <int BN, int MATH> struct BLoader<B_NPLAIN, BN, MATH> {
     float4 v[ITERS];
     int kk0, nq, kcur; bool active;
     const float *kp; bool nok; long long ldb;
+    bool sum_on; float4 colacc;      // bwd-weight: running column sums of the fetched B tiles (bias gradient)
     __device__ __forceinline__ void init(const KParams &p, int tid, int n0, const float *B, int) {
         kk0 = tid / UPK; nq = tid % UPK;
         active = kk0 < BK;
         const int n = n0 + nq * 4;
         nok = active && n < p.N; kp = B + n; ldb = p.ldb;
+        sum_on = false; colacc = zero4();
     }
     __device__ __forceinline__ void seek(int k0) {
         kcur = k0 + kk0 * KMUL;
@@ -512,6 +515,21 @@ template <int BN, int MATH> struct BLoader<B_NPLAIN, BN, MATH> {
         for (int i = 0; i < ITERS; ++i)
             v[i] = (nok && kcur + KSTEP * i < kend) ? ldg4(kp + (long long)(KSTEP * i) * ldb) : zero4();
         kcur += BK; kp += (long long)BK * ldb;
+        if (sum_on) {
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i) { colacc.x += v[i].x; colacc.y += v[i].y; colacc.z += v[i].z; colacc.w += v[i].w; }
+        }
+    }
+    // column sums of everything this workgroup fetched: lanes with the same column quad (nq) are added in kk0 order
+    __device__ __forceinline__ void write_colsum(float *scratch, float *dst, int n0, int N, int tid) const {
+        constexpr int KROWS = (NTHREADS / UPK) > BK ? BK : (NTHREADS / UPK);
+        if (active) *reinterpret_cast<float4 *>(&scratch[(kk0 * UPK + nq) * 4]) = colacc;
+        __syncthreads();
+        if (tid < BN) {
+            float s_ = 0.f;
+            for (int r = 0; r < KROWS; ++r) s_ += scratch[(r * UPK + tid / 4) * 4 + (tid & 3)];
+            if (n0 + tid < N) dst[n0 + tid] = s_;
+        }
     }
     __device__ __forceinline__ void store(float *lds) const {
         if (!active) return;
@@ -663,6 +681,8 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    constexpr bool COLSUM = (AMODE == A_CONV_M && BMODE == B_NPLAIN);
+    if constexpr (COLSUM) bl.sum_on = p.colsum_partial != nullptr && m0 == 0;
     if (kbeg < kend) {
         al.seek(kbeg); bl.seek(kbeg);
         al.fetch(kend); bl.fetch(kend);
@@ -743,6 +763,9 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
         __syncthreads();
     }
 
+    if constexpr (COLSUM) {
+        if (bl.sum_on) bl.write_colsum(lds, p.colsum_partial + (long long)split * p.N, n0, p.N, tid);   // staging LDS is free now
+    }
     lvt_epilogue<AMODE, BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, l31, half, cls, coff, z, split);
 }
 
@@ -782,7 +805,18 @@ __global__ void lvt_pack_weight_kernel(const float *__restrict__ w, float *__res
 // the one scattered write per element is the cheap side.
 __global__ void lvt_unpack_wgrad_kernel(const float *__restrict__ partial, long long stride, int splits,
                                         float *__restrict__ dw, int taps, int Ci, int Co, int Ci_real,
-                                        int Co_real) {
+                                        int Co_real, const float *__restrict__ colsum_partial, float *__restrict__ db) {
+    if (db) {
+        // bias gradient: one wave per output channel, lanes over the splits, butterfly sum (a fixed tree)
+        const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+        if (wave < Co_real) {
+            float s = 0.f;
+            for (int k = lane; k < splits; k += 64) s += colsum_partial[(long long)k * Co + wave];
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+            if (lane == 0) db[wave] = s;
+        }
+    }
     const long long total = (long long)taps * Ci * Co;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -1021,7 +1055,7 @@ int lvt_unpack_wgrad(const void *partial, long long stride, int splits, float *d
     const long long total = (long long)taps * Ci * Co;
     const int blocks = (int)(lvt_cdiv(total, 256) < 4096 ? lvt_cdiv(total, 256) : 4096);
     hipLaunchKernelGGL(lvt_unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)partial,
-                       stride, splits, dw, taps, Ci, Co, Ci_real, Co_real);
+                       stride, splits, dw, taps, Ci, Co, Ci_real, Co_real, (const float *)nullptr, (float *)nullptr);
     LVT_CHECK_LAUNCH("lvt_unpack_wgrad_kernel");
     return LVT_OK;
 }
@@ -1029,10 +1063,10 @@ int lvt_unpack_wgrad(const void *partial, long long stride, int splits, float *d
 extern "C" size_t lvt_conv3d_bwd_weight_workspace_bytes(const lvt_conv_geom *g) {
     if (!g) return 0;
     const long long Mg = (long long)g->Kt * g->Kh * g->Kw * g->Ci;
-    return (size_t)bwd_weight_splits(g) * Mg * g->Co * sizeof(float);
+    return (size_t)bwd_weight_splits(g) * (Mg + 1) * g->Co * sizeof(float);      // + one row per split: column sums
 }
 
-extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, const float *dy, float *dw,
+extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, float *db,
                                      int Ci_real, int Co_real, void *workspace, size_t workspace_bytes,
                                      void *stream) {
     int rc = check_geom(g, "conv3d_bwd_weight"); if (rc) return rc;
@@ -1052,13 +1086,15 @@ extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, con
     p.k_per_split = (int)(lvt_cdiv(lvt_cdiv(p.K, p.splits), BK) * BK);
     p.partial = (float *)workspace;
     p.partial_stride = (long long)p.M * p.N;
+    p.colsum_partial = db ? p.partial + (long long)p.splits * p.partial_stride : nullptr;
     hipStream_t s = (hipStream_t)stream;
     rc = launch_tile<A_CONV_M, B_NPLAIN, 128, 128, 2, 2>(p, 1, s);
     if (rc) return rc;
     const long long total = (long long)Co_real * Ci_real * taps;
-    const int blocks = (int)(lvt_cdiv(total, 256) < 4096 ? lvt_cdiv(total, 256) : 4096);
+    int blocks = (int)(lvt_cdiv(total, 256) < 4096 ? lvt_cdiv(total, 256) : 4096);
+    if (db && blocks < (int)lvt_cdiv(Co_real, 4)) blocks = (int)lvt_cdiv(Co_real, 4);      // one wave per bias entry
     hipLaunchKernelGGL(lvt_unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, s, p.partial, p.partial_stride,
-                       p.splits, dw, taps, g->Ci, g->Co, Ci_real, Co_real);
+                       p.splits, dw, taps, g->Ci, g->Co, Ci_real, Co_real, (const float *)p.colsum_partial, db);
     LVT_CHECK_LAUNCH("lvt_unpack_wgrad_kernel");
     return LVT_OK;
 }

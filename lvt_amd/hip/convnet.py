@@ -105,11 +105,13 @@ def stack_backward(layers, x, outs, saved, grad_out, need_input_grad=False):
         gp = gpres[i]
         # parameter gradients
         co = Layer.pad4(ly.cout)
+        db = None
         if ly.kind == "conv":
-            dw = G.conv_bwd_weight(g, inp, gp, ly.cin, ly.cout)
+            dw, db = G.conv_bwd_weight(g, inp, gp, ly.cin, ly.cout, want_bias=True)     # db rides on the dy stream
         else:
             dw = G.conv_bwd_weight(g, gp, inp, ly.cout, ly.cin)
-        db = G.colsum(gp, gp.numel() // co, co)[:ly.cout]
+        if db is None:
+            db = G.colsum(gp, gp.numel() // co, co)[:ly.cout]
         grads[i] = (dw, db)      # dw is (Co, Ci, Kt, Kh, Kw); callers view it as the parameter shape
         # gradient w.r.t. the layer input == g_pre of layer i-1 (mask / residual folded in)
         if i == 0 and not need_input_grad:

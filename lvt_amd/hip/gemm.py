@@ -135,7 +135,9 @@ def thin_wgrad_ok(g):
             and g.Wo % 32 == 0)
 
 
-def conv_bwd_weight(g, x, dy, Ci_real, Co_real):
+def conv_bwd_weight(g, x, dy, Ci_real, Co_real, want_bias=False):
+    """-> dw, or (dw, db) with want_bias: db = column sums of dy (the bias gradient of a forward conv), produced by
+    the same launch; db is None when this geometry takes the image-side kernel (the caller falls back to colsum)."""
     L.require(x, dy)
     lib = L.lib()
     dw = torch.empty(Co_real, Ci_real, g.Kt, g.Kh, g.Kw, dtype=torch.float32, device=x.device)
@@ -147,15 +149,16 @@ def conv_bwd_weight(g, x, dy, Ci_real, Co_real):
                                          L.stream_ptr()), "lvt_conv4_bwd_weight")
         if t0 is not None:
             L.TIMER.end("thin_bwd_weight", conv_flops(g), t0)
-        return dw
+        return (dw, None) if want_bias else dw
     nws = lib.lvt_conv3d_bwd_weight_workspace_bytes(C.byref(g))
     ws = L.workspace(nws, x.device, "wgrad")
+    db = torch.empty(Co_real, dtype=torch.float32, device=x.device) if want_bias else None
     t0 = L.TIMER.begin() if L.TIMER is not None else None
-    L.check(lib.lvt_conv3d_bwd_weight(C.byref(g), L.ptr(x), L.ptr(dy), L.ptr(dw), Ci_real, Co_real, L.ptr(ws),
+    L.check(lib.lvt_conv3d_bwd_weight(C.byref(g), L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), Ci_real, Co_real, L.ptr(ws),
                                       nws, L.stream_ptr()), "lvt_conv3d_bwd_weight")
     if t0 is not None:
         L.TIMER.end("conv_bwd_weight", conv_flops(g), t0)
-    return dw
+    return (dw, db) if want_bias else dw
 
 
 def colsum(gmat, M, N, ld=None):

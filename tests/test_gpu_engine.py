@@ -130,10 +130,12 @@ def test_conv_fwd_bwd(Ci, Co, k, s, p, H):
     gd = _nhwc(gmask).to(dev)
     dx = G.conv_bwd_data(g, gd, wp)
     assert rel_err(_nchw(dx), x.grad) < TOL
-    dw = G.conv_bwd_weight(g, xd, gd, Ci, Co)
+    dw, db_fused = G.conv_bwd_weight(g, xd, gd, Ci, Co, want_bias=True)
     assert rel_err(dw.squeeze(2), w.grad) < 5e-5
     db = G.colsum(gd.view(-1, Co), gd.numel() // Co, Co)
     assert rel_err(db, gmask.sum((0, 2, 3))) < 5e-5
+    if db_fused is not None:          # bias gradient accumulated inside the weight-gradient launch
+        assert rel_err(db_fused, gmask.sum((0, 2, 3))) < 5e-5
 
 
 @pytest.mark.parametrize("Cin,Cout,H", [(256, 128, 16), (128, 4, 32)])
