@@ -195,9 +195,9 @@ int lvt_attn_softmax_bwd(const float *P, float *dP, int B, int H, int S, float t
                          int bw, float *G, float *ddt, float *ddh, float *ddw, void *stream);
 
 /* single-query attention against a token-major K/V cache (incremental sampling: the reference re-runs the
- * whole causal decoder for every generated pixel, vt.py:121-131).  q/o (B, H*da), caches (B, S, H*da);
+ * whole causal decoder for every generated pixel, vt.py:121-131).  q (B rows of H*da, row stride ldq), o (B, H*da), caches (B, S, H*da);
  * attends keys 0..qi with the same scale / bias-bank rule as lvt_attn_softmax_fwd.  da == 128.        */
-int lvt_attn_decode(const float *q, const float *Kc, const float *Vc, int B, int H, int S, int da, int qi,
+int lvt_attn_decode(const float *q, long long ldq, const float *Kc, const float *Vc, int B, int H, int S, int da, int qi,
                     float temper, const float *dt, const float *dh, const float *dw, int bt, int bh, int bw,
                     float *o, void *stream);
 

@@ -433,12 +433,13 @@ extern "C" int lvt_xent_bwd(const float *logits, const long long *target, long l
 //   o[b][h][:] = softmax_j<=i( q.K_j / temper + bias(i, j) ) V_j     for the one query position i.
 // One workgroup of 4 waves per (b, h).  q (B, H*DA), caches (B, S, H*DA) token-major, o (B, H*DA).  DA == 128.
 // Same arithmetic as row i of the full causal layer (the masked columns j > i carry exp(-1e4 - m) == 0).
-// Scores: one key per thread (a 512-byte row each).  P.V: the keys are dealt to the 4 waves (j = w mod 4), every
+// Scores: 16 lanes per key (coalesced rows).  P.V: the keys are dealt to the 4 waves (j = w mod 4), every
 // lane owns 2 of the 128 output dims, and the 4 partial sums are added in wave order through LDS.
 // ------------------------------------------------------------------------------------------------
 #define DEC_DA 128
 #define DEC_WAVES 4
-__global__ __launch_bounds__(64 * DEC_WAVES) void lvt_attn_decode_kernel(const float *__restrict__ q, const float *__restrict__ Kc,
+__global__ __launch_bounds__(64 * DEC_WAVES) void lvt_attn_decode_kernel(const float *__restrict__ q, long long ldq,
+                                                             const float *__restrict__ Kc,
                                                              const float *__restrict__ Vc, int H, int S, int qi,
                                                              float temper, const float *__restrict__ dt,
                                                              const float *__restrict__ dh, const float *__restrict__ dw,
@@ -449,26 +450,38 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void lvt_attn_decode_kernel(const f
     __shared__ float acc[DEC_WAVES][DEC_DA];
     const int b = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hd = H * DEC_DA;
-    const float *qp = q + (long long)b * hd + h * DEC_DA;
+    const float *qp = q + (long long)b * ldq + h * DEC_DA;
     if (tid < DEC_DA) qs[tid] = qp[tid];
     __syncthreads();
     const int nk = qi + 1;
     const int wi = qi % g.bw, hi = (qi / g.bw) % g.bh, ti = qi / (g.bw * g.bh);
     const float *bt = dt + h * (2 * g.bt - 1), *bhp = dh + h * (2 * g.bh - 1), *bwp = dw + h * (2 * g.bw - 1);
     float m = -3.4e38f;
-    for (int j = tid; j < nk; j += 64 * DEC_WAVES) {
-        const float4 *kp = reinterpret_cast<const float4 *>(Kc + ((long long)b * S + j) * hd + h * DEC_DA);
-        float s = 0.f;
-#pragma unroll 8
-        for (int d4 = 0; d4 < DEC_DA / 4; ++d4) {
-            const float4 kv = kp[d4];
-            s = fmaf(qs[d4 * 4 + 0], kv.x, s); s = fmaf(qs[d4 * 4 + 1], kv.y, s);
-            s = fmaf(qs[d4 * 4 + 2], kv.z, s); s = fmaf(qs[d4 * 4 + 3], kv.w, s);
+    // scores: 16 lanes share one key (a coalesced 512-byte row: 8 dims = two float4 per lane), 16 keys per pass of
+    // the workgroup; the 16 partial dot products are combined with a butterfly inside the lane group
+    {
+        const int sub = tid & 15, grp = tid >> 4;                       // 16 groups of 16 lanes
+        float qv[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) qv[d] = qs[sub * 8 + d];
+        for (int j0 = 0; j0 < nk; j0 += 16) {
+            const int j = j0 + grp;
+            float sc = 0.f;
+            if (j < nk) {
+                const float4 *kp = reinterpret_cast<const float4 *>(Kc + ((long long)b * S + j) * hd + h * DEC_DA + sub * 8);
+                const float4 k0 = kp[0], k1 = kp[1];
+                sc = fmaf(qv[0], k0.x, sc); sc = fmaf(qv[1], k0.y, sc); sc = fmaf(qv[2], k0.z, sc); sc = fmaf(qv[3], k0.w, sc);
+                sc = fmaf(qv[4], k1.x, sc); sc = fmaf(qv[5], k1.y, sc); sc = fmaf(qv[6], k1.z, sc); sc = fmaf(qv[7], k1.w, sc);
+            }
+#pragma unroll
+            for (int d = 8; d > 0; d >>= 1) sc += __shfl_xor(sc, d, 64);
+            if (sub == 0 && j < nk) {
+                const int wj = j % g.bw, hj = (j / g.bw) % g.bh, tj = j / (g.bw * g.bh);
+                const float x = sc / temper + ((bt[ti - tj + g.bt - 1] + bhp[hi - hj + g.bh - 1]) + bwp[wi - wj + g.bw - 1]);
+                ps[j] = x;
+                m = fmaxf(m, x);
+            }
         }
-        const int wj = j % g.bw, hj = (j / g.bw) % g.bh, tj = j / (g.bw * g.bh);
-        const float x = s / temper + ((bt[ti - tj + g.bt - 1] + bhp[hi - hj + g.bh - 1]) + bwp[wi - wj + g.bw - 1]);
-        ps[j] = x;
-        m = fmaxf(m, x);
     }
     m = wmax(m);
     if (lane == 0) redm[wave] = m;
@@ -542,13 +555,14 @@ extern "C" int lvt_sample_categorical(const float *logits, long long rows, int V
     return LVT_OK;
 }
 
-extern "C" int lvt_attn_decode(const float *q, const float *Kc, const float *Vc, int B, int H, int S, int da, int qi,
+extern "C" int lvt_attn_decode(const float *q, long long ldq, const float *Kc, const float *Vc, int B, int H, int S, int da, int qi,
                                float temper, const float *dt, const float *dh, const float *dw, int bt, int bh, int bw,
                                float *o, void *stream) {
     LVT_REQUIRE(q && Kc && Vc && dt && dh && dw && o && B > 0 && H > 0, "attn_decode: bad args");
     LVT_REQUIRE(da == DEC_DA && S == bt * bh * bw && S <= 1024 && qi >= 0 && qi < S, "attn_decode: unsupported shape");
     BiasGeom g = {bt, bh, bw};
-    hipLaunchKernelGGL(lvt_attn_decode_kernel, dim3(B * H), dim3(64 * DEC_WAVES), 0, (hipStream_t)stream, q, Kc, Vc, H, S, qi,
+    LVT_REQUIRE(ldq >= (long long)H * da, "attn_decode: ldq");
+    hipLaunchKernelGGL(lvt_attn_decode_kernel, dim3(B * H), dim3(64 * DEC_WAVES), 0, (hipStream_t)stream, q, ldq, Kc, Vc, H, S, qi,
                        temper, dt, dh, dw, g, o);
     LVT_CHECK_LAUNCH("lvt_attn_decode_kernel");
     return LVT_OK;

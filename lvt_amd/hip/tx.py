@@ -117,12 +117,13 @@ def xent_bwd(logits, target, tstride_b, tstride_pos, P, ignore, lse, count, gout
     return dl
 
 
-def attn_decode(q, Kc, Vc, H, qi, temper, dt, dh, dw, block):
-    """q (B, H*da); Kc/Vc (B, S, H*da) caches -> o (B, H*da) for query position qi over keys 0..qi."""
-    L.require(q, Kc, Vc, dt, dh, dw)
+def attn_decode(q, Kc, Vc, H, qi, temper, dt, dh, dw, block, ldq=None):
+    """q: B rows of H*da floats (row stride ldq, default contiguous); Kc/Vc (B, S, H*da) caches -> o (B, H*da) for
+    query position qi over keys 0..qi."""
+    L.require(Kc, Vc, dt, dh, dw)
     B, S, hd = Kc.shape
-    o = torch.empty_like(q)
-    L.check(L.lib().lvt_attn_decode(L.ptr(q), L.ptr(Kc), L.ptr(Vc), B, H, S, hd // H, qi, temper, L.ptr(dt), L.ptr(dh),
+    o = torch.empty(B, hd, dtype=torch.float32, device=Kc.device)
+    L.check(L.lib().lvt_attn_decode(C.c_void_p(q.data_ptr()), ldq if ldq is not None else hd, L.ptr(Kc), L.ptr(Vc), B, H, S, hd // H, qi, temper, L.ptr(dt), L.ptr(dh),
                                     L.ptr(dw), block[0], block[1], block[2], L.ptr(o), L.stream_ptr()),
             "lvt_attn_decode")
     return o

@@ -52,12 +52,15 @@ class IncrementalDecoder:
         m0 = self.layers[0].mha
         self.na, self.da = m0.na, m0.da
         hd = self.na * self.da
-        self.kc = [torch.zeros(b, self.S, hd, dtype=torch.float32, device=dev) for _ in self.layers]
-        self.vc = [torch.zeros(b, self.S, hd, dtype=torch.float32, device=dev) for _ in self.layers]
+        # per layer one (3, b, S, hd) tensor: slot 0 holds the queries, 1 the key cache, 2 the value cache, so that one
+        # batched small-M GEMM (batch 3, uniform weight / output strides) writes q_i, k_i and v_i of every sample
+        self.qkv = [torch.zeros(3, b, self.S, hd, dtype=torch.float32, device=dev) for _ in self.layers]
+        self.kc = [t[1] for t in self.qkv]
+        self.vc = [t[2] for t in self.qkv]
         # per-head projection weights (na, d, da) re-laid out as one k-contiguous (na*da, d) matrix per projection,
         # the layout the matrix-core small-M GEMM streams; refreshed at every begin_slice (weights may have been
         # trained in between), in place so that captured graphs keep reading the same buffers
-        self.wqkv = [tuple(torch.empty(hd, d, dtype=torch.float32, device=dev) for _ in range(3)) for _ in self.layers]
+        self.wqkv = [torch.empty(3, hd, d, dtype=torch.float32, device=dev) for _ in self.layers]
         self.begin_slice(zl_tok)
 
     def _refresh_weights(self):
@@ -105,14 +108,11 @@ class IncrementalDecoder:
         for li, layer in enumerate(self.layers):
             m, f = layer.mha, layer.ffn
             xn, _, _ = ew.layernorm_fwd(x, m.layer_norm.weight, m.layer_norm.bias, save_stats=False)
-            q = torch.empty(b, hd, dtype=torch.float32, device=dev)
-            wq, wk, wv = self.wqkv[li]
-            G.gemm_small(xn, wq, q, b, hd, d)
-            for w_, cache in ((wk, self.kc[li]), (wv, self.vc[li])):
-                # write row i of every sample straight into the cache: C = cache[0, i], row stride S*hd
-                G.gemm_small(xn, w_, cache.view(-1)[i * hd:], b, hd, d, ldc=S * hd)
-            o = tx.attn_decode(q, self.kc[li], self.vc[li], na, i, math.sqrt(da), layer.dt_bank, layer.dh_bank,
-                               layer.dw_bank, layer.block_size)
+            # q_i / k_i / v_i of every sample in one launch: output row i of slot z, row stride S*hd, slot stride b*S*hd
+            qkv = self.qkv[li]
+            G.gemm_small(xn, self.wqkv[li], qkv.view(-1)[i * hd:], b, hd, d, ldc=S * hd, batch=3, sB=hd * d, sC=b * S * hd)
+            o = tx.attn_decode(qkv.view(-1)[i * hd:], self.kc[li], self.vc[li], na, i, math.sqrt(da), layer.dt_bank,
+                               layer.dh_bank, layer.dw_bank, layer.block_size, ldq=S * hd)
             y1 = torch.empty(b, d, dtype=torch.float32, device=dev)
             G.gemm_small(o, m.proj.weight, y1, b, d, hd, flags=L.EPI_RESIDUAL, res=x)
             fn, _, _ = ew.layernorm_fwd(y1, f[0].weight, f[0].bias, save_stats=False)
