@@ -318,3 +318,36 @@ def test_oracle_live_batch5(vt):
         a, r32, r64 = named[n].grad.double().cpu(), g32[n], g64[n]
         e_mine, e_cpu = float((a - r64).norm() / r64.norm()), float((r32 - r64).norm() / r64.norm())
         assert e_mine < max(4 * e_cpu, 2e-5) or e_mine < 3e-3, (n, e_mine, e_cpu)
+
+
+def test_dsfvt_full_batch_properties(vt):
+    """BASELINE-size DSFVT batch (64 slices): properties that do not need an oracle run at this size.
+    (a) causality: codes at positions >= p cannot change the logits of positions < p (bit for bit: masked scores
+        carry exactly zero probability, masked conv taps are exactly zero);
+    (b) batch independence: a sample's logits do not depend on which batch it is computed in;
+    (c) the batch loss is the mean of the per-sample losses (equal numbers of trained positions)."""
+    from lvt_amd.data.dataset_mapper import prepare_slices_batch
+    model, _ = vt
+    model.eval()
+    b = 64
+    g = torch.Generator().manual_seed(123)
+    codes = torch.randint(0, 512, (b, 16, 4, 16, 16), generator=g)
+    abcs = [(int(a), 0, 0) for a in torch.randint(1, 16, (b,), generator=g)]
+    ctx, sl, sidx, ign = (t.to(DEV) for t in prepare_slices_batch(codes, abcs, (16, 1, 1), (7, 1, 1), 1, -1))
+    with torch.no_grad():
+        base = model.model.logits_tokens(ctx, sl, sidx)                       # nc x (b*256, 512)
+        p = 128
+        sl2 = sl.clone()
+        sl2.view(b, 4, 256)[:, :, p:] = torch.randint(0, 512, (b, 4, 256 - p), generator=g).to(DEV)
+        pert = model.model.logits_tokens(ctx, sl2, sidx)
+        for k in range(4):
+            assert torch.equal(base[k].view(b, 256, 512)[:, :p], pert[k].view(b, 256, 512)[:, :p]), k
+            assert not torch.equal(base[k].view(b, 256, 512)[:, p:], pert[k].view(b, 256, 512)[:, p:])
+        one = model.model.logits_tokens(ctx[5:6].contiguous(), sl[5:6].contiguous(), sidx[5:6].contiguous())
+        for k in range(4):
+            assert rel_err(one[k], base[k].view(b, 256, 512)[5]) < 1e-6
+        full = float(model.compute_supervised_loss(ctx, sl, sidx, ign)["loss_cross_entropy"])
+        parts = [float(model.compute_supervised_loss(ctx[i:i + 16].contiguous(), sl[i:i + 16].contiguous(),
+                                                     sidx[i:i + 16].contiguous(), ign[i:i + 16].contiguous())["loss_cross_entropy"])
+                 for i in range(0, b, 16)]
+        assert abs(full - sum(parts) / len(parts)) < 1e-5 * abs(full)
