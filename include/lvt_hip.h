@@ -194,6 +194,13 @@ int lvt_attn_softmax_fwd(float *scores, int B, int H, int S, float temper, const
 int lvt_attn_softmax_bwd(const float *P, float *dP, int B, int H, int S, float temper, int bt, int bh,
                          int bw, float *G, float *ddt, float *ddh, float *ddw, void *stream);
 
+/* fused attention of one 256-token block (ScaledDotProductAttention, vt_attention.py:52-81):
+ * P = lvt_attn_softmax_fwd(q k^T) and o = P v in one launch; q/k/v/o token-major (B*S rows, H*da columns, head h in
+ * columns h*da..), P (B,H,S,S) is written for the backward pass.  S == 256, da == 128.                    */
+int lvt_attn_fwd(const float *q, const float *k, const float *v, int B, int H, int S, int da, float temper,
+                 const float *dt, const float *dh, const float *dw, int bt, int bh, int bw, int masked, float fill,
+                 float *P, float *o, void *stream);
+
 /* single-query attention against a token-major K/V cache (incremental sampling: the reference re-runs the
  * whole causal decoder for every generated pixel, vt.py:121-131).  q (B rows of H*da, row stride ldq), o (B, H*da), caches (B, S, H*da);
  * attends keys 0..qi with the same scale / bias-bank rule as lvt_attn_softmax_fwd.  da == 128.        */

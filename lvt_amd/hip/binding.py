@@ -91,6 +91,7 @@ def _declare(lib):
         "lvt_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, cll, ci, vp, vp, vp, vp, vp, sz, vp]),
         "lvt_attn_softmax_fwd": (ci, [vp, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp]),
         "lvt_attn_softmax_bwd": (ci, [vp, vp, ci, ci, ci, cf, ci, ci, ci, vp, vp, vp, vp, vp]),
+        "lvt_attn_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp]),
         "lvt_attn_decode": (ci, [vp, cll, vp, vp, ci, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, vp, vp]),
         "lvt_sample_categorical": (ci, [vp, cll, ci, cf, vp, vp, cll, vp, vp]),
         "lvt_embbag_fwd": (ci, [vp, cll, ci, cll, ci, P(ci), P(ci), vp, ci, vp, vp, vp, vp, vp]),

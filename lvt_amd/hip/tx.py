@@ -20,6 +20,24 @@ def attn_softmax_fwd_(scores, temper, dt, dh, dw, block, masked, fill=-1e4):
     return scores
 
 
+def attn_fwd_supported(S, da):
+    return S == 256 and da == 128
+
+
+def attn_fwd(q, k, v, B, H, S, da, temper, dt, dh, dw, block, masked, fill=-1e4):
+    """Fused scores + bias + mask + softmax + P.V for one 256-token block -> (P (B,H,S,S), o (B*S, H*da))."""
+    L.require(q, k, v, dt, dh, dw)
+    P = torch.empty(B, H, S, S, dtype=torch.float32, device=q.device)
+    o = torch.empty(B * S, H * da, dtype=torch.float32, device=q.device)
+    t0 = L.TIMER.begin() if L.TIMER is not None else None
+    L.check(L.lib().lvt_attn_fwd(L.ptr(q), L.ptr(k), L.ptr(v), B, H, S, da, temper, L.ptr(dt), L.ptr(dh), L.ptr(dw),
+                                 block[0], block[1], block[2], 1 if masked else 0, fill, L.ptr(P), L.ptr(o),
+                                 L.stream_ptr()), "lvt_attn_fwd")
+    if t0 is not None:
+        L.TIMER.end("attn_fwd", 4.0 * B * H * S * S * da, t0)
+    return P, o
+
+
 def attn_softmax_bwd_(P, dP, temper, block):
     """dP is overwritten with dS.  Returns (ddt, ddh, ddw)."""
     L.require(P, dP)

@@ -94,6 +94,9 @@ def linear_wgrad(dy, x, n_out, k_in, rows):
     return dw
 
 
+FUSED_ATTENTION = True      # scores + bias + mask + softmax + P.V in one launch when the block is 256 tokens x 128 dims
+
+
 class _BlockLocalAttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, block, masked, dt, dh, dw, ln_w, ln_b, w_q, w_k, w_v, proj_w, f0w, f0b, f1w, f1b, f3w, f3b):
@@ -112,13 +115,16 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
             G.gemm(xn, w, out, M, da, d, ta=0, tb=1, lda=d, ldb=da, ldc=hd, batch_inner=na, sB=(0, d * da), sC=(0, da))
             qkv.append(out)
         q, k, v = qkv
-        P = torch.empty(b, na, S, S, dtype=torch.float32, device=dev)
-        G.gemm(q, k, P, S, S, da, ta=0, tb=0, lda=hd, ldb=hd, ldc=S, batch_outer=b, batch_inner=na,
-               sA=(S * hd, da), sB=(S * hd, da), sC=(na * S * S, S * S))
-        tx.attn_softmax_fwd_(P, temper, dt, dh, dw, block, masked)
-        o = torch.empty(M, hd, dtype=torch.float32, device=dev)
-        G.gemm(P, v, o, S, da, S, ta=0, tb=1, lda=S, ldb=hd, ldc=hd, batch_outer=b, batch_inner=na,
-               sA=(na * S * S, S * S), sB=(S * hd, da), sC=(S * hd, da))
+        if FUSED_ATTENTION and tx.attn_fwd_supported(S, da):
+            P, o = tx.attn_fwd(q, k, v, b, na, S, da, temper, dt, dh, dw, block, masked)
+        else:
+            P = torch.empty(b, na, S, S, dtype=torch.float32, device=dev)
+            G.gemm(q, k, P, S, S, da, ta=0, tb=0, lda=hd, ldb=hd, ldc=S, batch_outer=b, batch_inner=na,
+                   sA=(S * hd, da), sB=(S * hd, da), sC=(na * S * S, S * S))
+            tx.attn_softmax_fwd_(P, temper, dt, dh, dw, block, masked)
+            o = torch.empty(M, hd, dtype=torch.float32, device=dev)
+            G.gemm(P, v, o, S, da, S, ta=0, tb=1, lda=S, ldb=hd, ldc=hd, batch_outer=b, batch_inner=na,
+                   sA=(na * S * S, S * S), sB=(S * hd, da), sC=(S * hd, da))
         y1 = torch.empty(M, d, dtype=torch.float32, device=dev)
         G.gemm(o, proj_w, y1, M, d, hd, flags=L.EPI_RESIDUAL, res=x)
         fn, mean2, rstd2 = ew.layernorm_fwd(y1, f0w, f0b)

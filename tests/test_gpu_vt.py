@@ -351,3 +351,38 @@ def test_dsfvt_full_batch_properties(vt):
                                                      sidx[i:i + 16].contiguous(), ign[i:i + 16].contiguous())["loss_cross_entropy"])
                  for i in range(0, b, 16)]
         assert abs(full - sum(parts) / len(parts)) < 1e-5 * abs(full)
+
+
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("blk", [(1, 16, 16), (4, 8, 8)])
+def test_fused_attention_forward(masked, blk):
+    """lvt_attn_fwd (scores + bias + mask + softmax + P.V in one launch) against the plain torch formula and the
+    three-launch path (QK^T GEMM, softmax kernel, PV GEMM)."""
+    from lvt_amd.hip import gemm as G, tx
+    B, H, S, da = 3, 8, 256, 128
+    hd = H * da
+    q, k, v = _rand(B * S, hd, seed=1), _rand(B * S, hd, seed=2), _rand(B * S, hd, seed=3)
+    banks = [_rand(H, 2 * n - 1, seed=5 + i) * 0.5 for i, n in enumerate(blk)]
+    temper = math.sqrt(da)
+    # reference in fp64
+    qh = q.double().view(B, S, H, da).permute(0, 2, 1, 3); kh = k.double().view(B, S, H, da).permute(0, 2, 1, 3)
+    vh = v.double().view(B, S, H, da).permute(0, 2, 1, 3)
+    bias = O.rel_position_bias(*[x.double() for x in banks], blk).transpose(0, 1)        # (1, H, S, S)
+    sc = qh @ kh.transpose(2, 3) / temper + bias
+    if masked:
+        sc = sc.masked_fill(torch.triu(torch.ones(S, S), 1).bool(), -1e4)
+    Pref = torch.softmax(sc, -1)
+    oref = (Pref @ vh).permute(0, 2, 1, 3).reshape(B * S, hd)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    bd = [x.to(DEV).contiguous() for x in banks]
+    P, o = tx.attn_fwd(qd, kd, vd, B, H, S, da, temper, bd[0], bd[1], bd[2], blk, masked)
+    assert rel_err(P, Pref.float()) < 2e-5
+    assert rel_err(o, oref.float()) < 2e-5
+    if masked:
+        assert float(P[:, :, 0, 1:].abs().max()) == 0.0 and float(P[:, :, 100, 101:].abs().max()) == 0.0
+    # three-launch path
+    P2 = torch.empty(B, H, S, S, device=DEV)
+    G.gemm(qd, kd, P2, S, S, da, ta=0, tb=0, lda=hd, ldb=hd, ldc=S, batch_outer=B, batch_inner=H,
+           sA=(S * hd, da), sB=(S * hd, da), sC=(H * S * S, S * S))
+    tx.attn_softmax_fwd_(P2, temper, bd[0], bd[1], bd[2], blk, masked)
+    assert rel_err(P, P2) < 2e-5
