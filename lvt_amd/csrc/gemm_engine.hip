@@ -895,9 +895,11 @@ static int launch_tile(const KParams &p, int zcount, hipStream_t s) {
 
 static int choose_splits(long long tiles, int K, int min_k) {
     // Two workgroups are resident per CU (176 registers/lane), i.e. 512 slots on the chip: aim for the
-    // largest split count whose grid still fits in two full waves of workgroups (tiles * splits <= 1024),
-    // so that no partially filled tail wave is paid; never less than min_k of reduction per split.
-    int s = (int)((4 * LVT_NUM_CU) / (tiles > 0 ? tiles : 1));
+    // largest split count whose grid still fits in ONE full wave of workgroups (tiles * splits <= 512), so that no
+    // partially filled tail wave is paid; never less than min_k of reduction per split.  (Two waves, 1024, are no
+    // faster on the conv weight gradients, 12-14 % slower on the 16384-row linear ones, and double the
+    // partial-sum traffic; 1.5 waves is 20 % slower.)
+    int s = (int)((2 * LVT_NUM_CU) / (tiles > 0 ? tiles : 1));
     const int maxs = K / min_k > 0 ? K / min_k : 1;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
