@@ -139,39 +139,52 @@ __global__ __launch_bounds__(EMA_THREADS) void lvt_vq_ema_partial_kernel(
     const long long *__restrict__ idx, const float *__restrict__ z, long long rows, int ldz, int num, int P,
     long long rows_per_chunk, int nchunks, float *__restrict__ partial) {
     constexpr int LDS_LD = VQ_D + 1;
-    extern __shared__ __attribute__((aligned(16))) float acc[];      // [KC][65]
+    extern __shared__ __attribute__((aligned(16))) float acc[];      // [KC][65], then a 64-row staging tile
+    float *tile = acc + ((KC * LDS_LD + 3) & ~3);                   // [64 rows][VQ_D]
     const int g = blockIdx.x / nchunks, c = blockIdx.x % nchunks;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < KC * LDS_LD; i += EMA_THREADS) acc[i] = 0.f;
-    __syncthreads();
     const long long r0 = (long long)c * rows_per_chunk;
     const long long r1 = min(rows, r0 + rows_per_chunk);
+    // 64 rows at a time: the workgroup fetches them coalesced (16 lanes per 256-byte row slice, the next tile is in
+    // flight in registers), then the waves reduce them from LDS -- no wave waits on a global load per row any more.
+    const int trow = tid >> 4, tq = (tid & 15) * 4;                  // staging: rows trow and trow + 32
+    float4 pre[2];
+    auto fetch = [&](long long base) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long r = base + trow + 32 * u;
+            pre[u] = r < r1 ? *reinterpret_cast<const float4 *>(z + r * (long long)ldz + g * VQ_D + tq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (r0 < r1) fetch(r0);
+    __syncthreads();
     for (long long base = r0; base < r1; base += 64) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<float4 *>(&tile[(trow + 32 * u) * VQ_D + tq]) = pre[u];
         const long long r = base + lane;
         int code = -1;
         if (r < r1) code = (int)idx[((r / P) * num + g) * (long long)P + r % P];
-        unsigned long long m = __ballot(code >= 0 && (code & 7) == wave);
-        while (m) {
-            // gather up to 4 pending rows first (independent 256-byte loads), then apply them in order
-            int js[4], cs[4]; float vs[4]; int cnt = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (m) {
-                    const int j = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    js[q] = j; cs[q] = __shfl(code, j);
-                    vs[q] = z[(base + j) * (long long)ldz + g * VQ_D + lane];
-                    cnt = q + 1;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q < cnt) {
-                    acc[cs[q] * LDS_LD + lane] += vs[q];
-                    if (lane == 0) acc[cs[q] * LDS_LD + VQ_D] += 1.0f;
-                }
-            }
+        __syncthreads();
+        if (base + 64 < r1) fetch(base + 64);
+        // Rows of the tile that share a code are summed in registers first and hit the LDS accumulator once, by
+        // the wave that owns the code's FIRST row in the tile (row j belongs to wave j & 7): no two waves ever touch
+        // the same accumulator row inside a tile, the work is spread by rows (a skewed code histogram no longer
+        // serialises on one wave), and the order -- rows ascending inside a tile, tiles ascending -- is fixed.
+        unsigned long long todo = __ballot(code >= 0);
+        while (todo) {
+            const int j = __ffsll((long long)todo) - 1;                // leader: first unprocessed row
+            const int cj = __shfl(code, j);
+            const unsigned long long same = __ballot(code == cj);
+            todo &= ~same;
+            if ((j & 7) != wave) continue;
+            float sum = 0.f; int cnt = 0;
+            unsigned long long mm = same;
+            while (mm) { const int r_ = __ffsll((long long)mm) - 1; mm &= mm - 1; sum += tile[r_ * VQ_D + lane]; ++cnt; }
+            acc[cj * LDS_LD + lane] += sum;
+            if (lane == 0) acc[cj * LDS_LD + VQ_D] += (float)cnt;
         }
+        __syncthreads();
     }
     __syncthreads();
     float *dst = partial + ((long long)g * nchunks + c) * (KC * LDS_LD);
@@ -296,7 +309,7 @@ extern "C" int lvt_vq_ema_accumulate(const long long *idx, const float *z, long 
         return LVT_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    const int smem = KC * (VQ_D + 1) * (int)sizeof(float);
+    const int smem = (((KC * (VQ_D + 1) + 3) & ~3) + 64 * VQ_D) * (int)sizeof(float);
     hipError_t e;
 #define EMA_LAUNCH(KCV)                                                                                          \
     e = hipFuncSetAttribute((const void *)lvt_vq_ema_partial_kernel<KCV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
