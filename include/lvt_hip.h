@@ -133,9 +133,14 @@ int lvt_colsum(const float *g, long long M, int N, long long ld, float *out, voi
 /* ---- product vector quantiser (vidgen/modeling/vq/vq_utils.py:5-65, vq_embedding.py:9-99; K7-K9) ----
  * z: [rows][ldz] channels-last activations, group g owns columns [g*D, (g+1)*D).  codebooks: [num][KC][D].
  * idx: int64 [rows/P][num][P]  (== the reference's (N, num, H, W) layout with P = H*W).
- * lvt_vq_nearest: idx = argmin_k |e_k|^2 + |x|^2 - 2 x.e_k in fp32, lowest k on ties (torch.min).     */
+ * lvt_vq_nearest: idx = argmin_k |e_k|^2 + |x|^2 - 2 x.e_k in fp32, lowest k on ties (torch.min).  In the default
+ * (bf16x3) math mode the product runs on the bf16 matrix cores, one workgroup per codebook half, and the per-half
+ * (distance, index) candidates go through `workspace`; without a workspace, or in f32 mode, the fp32-MFMA kernel
+ * with the whole codebook LDS-resident is used.                                                           */
+size_t lvt_vq_nearest_workspace_bytes(long long rows, int num, int KC);
 int lvt_vq_nearest(const float *z, long long rows, int ldz, int num, int D, int KC,
-                   const float *codebooks, long long *idx, int P, void *stream);
+                   const float *codebooks, long long *idx, int P, void *workspace, size_t workspace_bytes,
+                   void *stream);
 /* out[row][g*D+d] = codebooks[g][idx][d]   (index_select / embedding: z_q_st, z_q_bar, mode "emb")   */
 int lvt_vq_gather(const long long *idx, const float *codebooks, long long rows, int num, int D, int KC,
                   int P, float *out, int ldo, void *stream);

@@ -115,6 +115,152 @@ __global__ __launch_bounds__(VQ_THREADS) void lvt_vq_nearest_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// vq_nearest, default arithmetic (bf16x3, see gemm_engine.hip): the distance product runs on the bf16 matrix cores
+// with the exact 3-way split of both operands (six MFMAs per 16-wide step, fp32 accumulation) -- 384 MFMAs of 32
+// cycles per 32 rows instead of 512 of 64.  The three bf16 planes of a 512 x 64 codebook (221 KB) do not fit in
+// LDS, so a workgroup holds HALF a codebook (256 codes, 108 KB) and writes the (distance, index) of its best code
+// per row; a merge pass picks the winner (ties -> lower index = lower half first, torch.min semantics).
+// The product is computed transposed, D^T[code][row] = E X^T: a lane then owns one activation row (lane & 31) and
+// sees codes in ascending order in its accumulator registers, so the running arg-min needs no cross-lane traffic
+// until one exchange with the other half-wave at the end.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define VQH_CODES 256
+#define VQH_LD (VQ_D + 8)              // plane row stride (bf16): 144 B, conflict-free 16-byte fragment reads
+
+__device__ __forceinline__ unsigned vq_cvt_pk(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ void vq_split4(const float4 v, uint2 &p1, uint2 &p2, uint2 &p3) {
+    p1.x = vq_cvt_pk(v.x, v.y); p1.y = vq_cvt_pk(v.z, v.w);
+    const float r0 = v.x - __uint_as_float(p1.x << 16), r1 = v.y - __uint_as_float(p1.x & 0xffff0000u);
+    const float r2 = v.z - __uint_as_float(p1.y << 16), r3 = v.w - __uint_as_float(p1.y & 0xffff0000u);
+    p2.x = vq_cvt_pk(r0, r1); p2.y = vq_cvt_pk(r2, r3);
+    const float s0 = r0 - __uint_as_float(p2.x << 16), s1 = r1 - __uint_as_float(p2.x & 0xffff0000u);
+    const float s2 = r2 - __uint_as_float(p2.y << 16), s3 = r3 - __uint_as_float(p2.y & 0xffff0000u);
+    p3.x = vq_cvt_pk(s0, s1); p3.y = vq_cvt_pk(s2, s3);
+}
+
+__global__ __launch_bounds__(VQ_THREADS) void lvt_vq_nearest_half_kernel(
+    const float *__restrict__ z, long long rows, int ldz, int KC, const float *__restrict__ codebooks,
+    float *__restrict__ pbest, int *__restrict__ pidx) {
+    __shared__ __attribute__((aligned(16))) unsigned short planes[3 * VQH_CODES * VQH_LD];
+    __shared__ float cbsq[VQH_CODES];
+    constexpr int PL = VQH_CODES * VQH_LD;
+    const int g = blockIdx.z, part = blockIdx.y, nparts = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int code0 = part * VQH_CODES;
+    const float *E = codebooks + ((long long)g * KC + code0) * VQ_D;
+
+    // stage this half of the codebook as three bf16 planes [code][dim]; thread (code = tid >> 1, dims 32*(tid&1)..)
+    {
+        const int code = tid >> 1, d0 = 32 * (tid & 1);
+        float sq = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 v = *reinterpret_cast<const float4 *>(E + (long long)code * VQ_D + d0 + 4 * u);
+            sq = fmaf(v.x, v.x, sq); sq = fmaf(v.y, v.y, sq); sq = fmaf(v.z, v.z, sq); sq = fmaf(v.w, v.w, sq);
+            uint2 p1, p2, p3;
+            vq_split4(v, p1, p2, p3);
+            unsigned short *dst = planes + code * VQH_LD + d0 + 4 * u;
+            *reinterpret_cast<uint2 *>(dst) = p1;
+            *reinterpret_cast<uint2 *>(dst + PL) = p2;
+            *reinterpret_cast<uint2 *>(dst + 2 * PL) = p3;
+        }
+        sq += __shfl_xor(sq, 1);
+        if ((tid & 1) == 0) cbsq[code] = sq;
+    }
+    __syncthreads();
+
+    const long long ntiles = (rows + 31) / 32;
+    const int wpb = VQ_THREADS / 64;
+    for (long long tile = (long long)blockIdx.x * wpb + wave; tile < ntiles; tile += (long long)gridDim.x * wpb) {
+        const long long row = tile * 32 + l31;
+        const bool rok = row < rows;
+        // B operand: the lane's row, dims 16s + 8*half .. +7 for the four 16-wide steps, as three planes
+        bf16x8 zb[4][3];
+        float xs = 0.f;
+        {
+            const float *zp = z + (rok ? row : 0) * (long long)ldz + g * VQ_D + 8 * half;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float4 lo = rok ? *reinterpret_cast<const float4 *>(zp + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 hi = rok ? *reinterpret_cast<const float4 *>(zp + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xs = fmaf(lo.x, lo.x, xs); xs = fmaf(lo.y, lo.y, xs); xs = fmaf(lo.z, lo.z, xs); xs = fmaf(lo.w, lo.w, xs);
+                xs = fmaf(hi.x, hi.x, xs); xs = fmaf(hi.y, hi.y, xs); xs = fmaf(hi.z, hi.z, xs); xs = fmaf(hi.w, hi.w, xs);
+                uint2 a1, a2, a3, b1, b2, b3;
+                vq_split4(lo, a1, a2, a3); vq_split4(hi, b1, b2, b3);
+                const uint4 u1 = make_uint4(a1.x, a1.y, b1.x, b1.y), u2 = make_uint4(a2.x, a2.y, b2.x, b2.y),
+                            u3 = make_uint4(a3.x, a3.y, b3.x, b3.y);
+                zb[s][0] = *reinterpret_cast<const bf16x8 *>(&u1); zb[s][1] = *reinterpret_cast<const bf16x8 *>(&u2);
+                zb[s][2] = *reinterpret_cast<const bf16x8 *>(&u3);
+            }
+            xs += __shfl_xor(xs, 32);
+        }
+        float best = 3.4e38f; int bidx = 0;
+        // two code tiles advance together, term by term (independent accumulators)
+        for (int ct = 0; ct < VQH_CODES / 32; ct += 2) {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 a0[3], a1[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a0[pl] = *reinterpret_cast<const bf16x8 *>(planes + pl * PL + (ct * 32 + l31) * VQH_LD + 16 * s + 8 * half);
+                    a1[pl] = *reinterpret_cast<const bf16x8 *>(planes + pl * PL + (ct * 32 + 32 + l31) * VQH_LD + 16 * s + 8 * half);
+                }
+                constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};     // smallest terms first
+#pragma unroll
+                for (int tm = 0; tm < 6; ++tm) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[TA[tm]], zb[s][TB[tm]], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[TA[tm]], zb[s][TB[tm]], acc1, 0, 0, 0);
+                }
+            }
+            // codes ascend with (tile, r): a strict < keeps the lowest index among equal distances
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                // (|e|^2 + |x|^2) + (-2) * (x.e): same algebraic form as torch.addmm(beta=1, alpha=-2)
+                const float dist = fmaf(-2.0f, acc0[r], cbsq[cl] + xs);
+                if (dist < best) { best = dist; bidx = code0 + cl; }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = ct * 32 + 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float dist = fmaf(-2.0f, acc1[r], cbsq[cl] + xs);
+                if (dist < best) { best = dist; bidx = code0 + cl; }
+            }
+        }
+        // the other half-wave saw the other codes of every tile
+        const float ob = __shfl_xor(best, 32);
+        const int oi = __shfl_xor(bidx, 32);
+        if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        if (half == 0 && rok) {
+            const long long o = ((long long)g * nparts + part) * rows + row;
+            pbest[o] = best; pidx[o] = bidx;
+        }
+    }
+}
+
+__global__ void lvt_vq_nearest_merge_kernel(const float *__restrict__ pbest, const int *__restrict__ pidx, long long rows,
+                                            int num, int nparts, int P, long long *__restrict__ idx_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * num) return;
+    const int g = (int)(i / rows); const long long row = i % rows;
+    float best = pbest[((long long)g * nparts) * rows + row]; int bi = pidx[((long long)g * nparts) * rows + row];
+    for (int p = 1; p < nparts; ++p) {
+        const float b = pbest[((long long)g * nparts + p) * rows + row];
+        if (b < best) { best = b; bi = pidx[((long long)g * nparts + p) * rows + row]; }      // strict: lower half wins ties
+    }
+    idx_out[((row / P) * num + g) * (long long)P + row % P] = bi;
+}
+
 // out[row][g*D + d] = E[g][idx[n][g][p]][d]; one wave per (row, g) pair, d = lane (D == 64)
 __global__ void lvt_vq_gather_kernel(const long long *__restrict__ idx, const float *__restrict__ codebooks,
                                      long long rows, int num, int KC, int P, float *__restrict__ out, int ldo) {
@@ -243,14 +389,39 @@ __global__ __launch_bounds__(512) void lvt_vq_ema_finalize_kernel(const float *_
 // ------------------------------------------------------------------------------------------------
 static int vq_smem_bytes(int KC) { return (VQ_D * (KC + 1) + KC) * (int)sizeof(float); }
 
+extern "C" int lvt_get_math_mode(void);
+
+extern "C" size_t lvt_vq_nearest_workspace_bytes(long long rows, int num, int KC) {
+    const int nparts = KC / VQH_CODES > 0 ? KC / VQH_CODES : 1;
+    return (size_t)rows * num * nparts * (sizeof(float) + sizeof(int));
+}
+
 extern "C" int lvt_vq_nearest(const float *z, long long rows, int ldz, int num, int D, int KC,
-                              const float *codebooks, long long *idx_out, int P, void *stream) {
+                              const float *codebooks, long long *idx_out, int P, void *workspace,
+                              size_t workspace_bytes, void *stream) {
     LVT_REQUIRE(z && codebooks && idx_out, "vq_nearest: null pointer");
     LVT_REQUIRE(D == VQ_D, "vq_nearest: only D=%d per codebook is instantiated (got %d)", VQ_D, D);
     LVT_REQUIRE(KC == 512 || KC == 256 || KC == 128, "vq_nearest: codebook size %d not instantiated", KC);
     LVT_REQUIRE(rows > 0 && num > 0 && P > 0 && rows % P == 0, "vq_nearest: bad rows/P");
     LVT_REQUIRE(ldz % 4 == 0 && ldz >= num * D && lvt_aligned16(z) && lvt_aligned16(codebooks),
                 "vq_nearest: alignment / ldz");
+    if (lvt_get_math_mode() == 1 && KC % VQH_CODES == 0 && workspace &&
+        workspace_bytes >= lvt_vq_nearest_workspace_bytes(rows, num, KC)) {
+        const int nparts = KC / VQH_CODES;
+        float *pbest = (float *)workspace;
+        int *pidx = (int *)(pbest + rows * num * nparts);
+        int bpp = LVT_NUM_CU / (num * nparts);        // one workgroup per CU (LDS-bound)
+        const long long need_ = lvt_cdiv((rows + 31) / 32, VQ_THREADS / 64);
+        if (bpp > need_) bpp = (int)need_;
+        if (bpp < 1) bpp = 1;
+        hipLaunchKernelGGL(lvt_vq_nearest_half_kernel, dim3(bpp, nparts, num), dim3(VQ_THREADS), 0, (hipStream_t)stream, z,
+                           rows, ldz, KC, codebooks, pbest, pidx);
+        LVT_CHECK_LAUNCH("lvt_vq_nearest_half_kernel");
+        hipLaunchKernelGGL(lvt_vq_nearest_merge_kernel, dim3((unsigned)lvt_cdiv(rows * num, 256)), dim3(256), 0,
+                           (hipStream_t)stream, (const float *)pbest, (const int *)pidx, rows, num, nparts, P, idx_out);
+        LVT_CHECK_LAUNCH("lvt_vq_nearest_merge_kernel");
+        return LVT_OK;
+    }
     const long long ntiles = (rows + 31) / 32;
     int bpg = LVT_NUM_CU / num;                       // one workgroup per CU (LDS-bound)
     const long long need = lvt_cdiv(ntiles, VQ_THREADS / 64);

@@ -73,7 +73,8 @@ def _declare(lib):
         "lvt_conv4_bwd_weight": (ci, [P(ConvGeom), vp, vp, vp, ci, ci, vp, sz, vp]),
         "lvt_colsum_workspace_bytes": (sz, [cll, ci]),
         "lvt_colsum": (ci, [vp, cll, ci, cll, vp, vp, sz, vp]),
-        "lvt_vq_nearest": (ci, [vp, cll, ci, ci, ci, ci, vp, vp, ci, vp]),
+        "lvt_vq_nearest_workspace_bytes": (sz, [cll, ci, ci]),
+        "lvt_vq_nearest": (ci, [vp, cll, ci, ci, ci, ci, vp, vp, ci, vp, sz, vp]),
         "lvt_vq_gather": (ci, [vp, vp, cll, ci, ci, ci, ci, vp, ci, vp]),
         "lvt_vq_ema_workspace_bytes": (sz, [cll, ci, ci, ci]),
         "lvt_vq_ema_accumulate": (ci, [vp, vp, cll, ci, ci, ci, ci, ci, vp, vp, sz, vp]),

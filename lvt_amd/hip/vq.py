@@ -10,8 +10,11 @@ def nearest(z, codebooks, P):
     rows, ldz = z.shape
     num, K, D = codebooks.shape
     idx = torch.empty(rows // P, num, P, dtype=torch.int64, device=z.device)
-    L.check(L.lib().lvt_vq_nearest(L.ptr(z), rows, ldz, num, D, K, L.ptr(codebooks), L.ptr(idx), P, L.stream_ptr()),
-            "lvt_vq_nearest")
+    lib = L.lib()
+    nws = lib.lvt_vq_nearest_workspace_bytes(rows, num, K)
+    ws = L.workspace(nws, z.device, "vq_nearest")
+    L.check(lib.lvt_vq_nearest(L.ptr(z), rows, ldz, num, D, K, L.ptr(codebooks), L.ptr(idx), P, L.ptr(ws), nws,
+                               L.stream_ptr()), "lvt_vq_nearest")
     return idx
 
 
