@@ -279,7 +279,7 @@ extern "C" int lvt_layernorm_fwd(const float *x, long long rows, int d, float ep
 }
 
 // dx = rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat)) (+ add);  partial dw/db per workgroup
-#define LN_BWD_BLOCKS 256
+#define LN_BWD_BLOCKS 1024
 __global__ __launch_bounds__(256) void lvt_layernorm_bwd_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ mean,
     const float *__restrict__ rstd, const float *__restrict__ w, long long rows, int d, const float *__restrict__ add,
@@ -344,17 +344,27 @@ __global__ __launch_bounds__(256) void lvt_layernorm_bwd_kernel(
         pdb[(long long)blockIdx.x * d + c] = ((sdb[0][c] + sdb[1][c]) + sdb[2][c]) + sdb[3][c];
     }
 }
-// out[c] = sum_b partial[b][c] with the partial rows split over RL row-lanes per column group
-// (fixed order: lane-local sequential sums, then lanes combined in lane order).
-__global__ __launch_bounds__(256) void lvt_rowsum_partials_kernel(const float *__restrict__ partial, int nblk, int n,
-                                                                  float *__restrict__ out) {
+// out[c] = sum_b partial[b][c]: 8 columns per workgroup, 32 row-lanes per column, four independent running sums per
+// lane (the loads of a lane do not wait on each other); lanes are combined in lane order -> fixed summation order.
+// blockIdx.y selects the (partial, out) pair, so dw and db of a LayerNorm share one launch.
+__global__ __launch_bounds__(256) void lvt_rowsum_partials_kernel(const float *__restrict__ partial0, const float *__restrict__ partial1,
+                                                                  int nblk, int n, float *__restrict__ out0, float *__restrict__ out1) {
     __shared__ float red[256];
-    const int cols = 32;                       // columns per workgroup
+    const float *partial = blockIdx.y ? partial1 : partial0;
+    float *out = blockIdx.y ? out1 : out0;
+    constexpr int cols = 8, RL = 256 / cols;
     const int c = blockIdx.x * cols + (threadIdx.x % cols);
-    const int rl = threadIdx.x / cols, RL = 256 / cols;
-    float s = 0.f;
-    if (c < n)
-        for (int b = rl; b < nblk; b += RL) s += partial[(long long)b * n + c];
+    const int rl = threadIdx.x / cols;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < n) {
+        int b = rl;
+        for (; b + 3 * RL < nblk; b += 4 * RL) {
+            s0 += partial[(long long)b * n + c]; s1 += partial[(long long)(b + RL) * n + c];
+            s2 += partial[(long long)(b + 2 * RL) * n + c]; s3 += partial[(long long)(b + 3 * RL) * n + c];
+        }
+        for (; b < nblk; b += RL) s0 += partial[(long long)b * n + c];
+    }
+    float s = (s0 + s1) + (s2 + s3);
     red[threadIdx.x] = s;
     __syncthreads();
     if (rl == 0 && c < n) {
@@ -377,8 +387,8 @@ extern "C" int lvt_layernorm_bwd(const float *dy, const float *x, const float *m
     hipLaunchKernelGGL(lvt_layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, s, dy, x, mean, rstd, w, rows, d, add,
                        dx, pdw, pdb);
     LVT_CHECK_LAUNCH("lvt_layernorm_bwd_kernel");
-    hipLaunchKernelGGL(lvt_rowsum_partials_kernel, dim3((d + 31) / 32), dim3(256), 0, s, pdw, blocks, d, dw);
-    hipLaunchKernelGGL(lvt_rowsum_partials_kernel, dim3((d + 31) / 32), dim3(256), 0, s, pdb, blocks, d, db);
+    hipLaunchKernelGGL(lvt_rowsum_partials_kernel, dim3((d + 7) / 8, 2), dim3(256), 0, s, (const float *)pdw, (const float *)pdb,
+                       blocks, d, dw, db);
     LVT_CHECK_LAUNCH("lvt_rowsum_partials_kernel");
     return LVT_OK;
 }
