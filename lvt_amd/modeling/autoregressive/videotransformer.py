@@ -183,14 +183,18 @@ class _DecoderFrontFn(torch.autograd.Function):
         off = [k * P for k in range(nc)]
         emb = tx.embbag_fwd(sl, nc * P, P, rows, off, [k * nv for k in range(nc)], tables, de)
         kt, kh, kw = conv_w.shape[2:]
-        g = G.conv_geom(b, t, h, w, de, d, (kt, kh, kw), (1, 1, 1), (kt - 1, kh - 1, kw // 2), out=(t, h, w))
-        wp = G.pack_weight(g, conv_w, de, d)
+        # the causal conv pads kt-1 frames in front: with t frames only the last min(kt, t) temporal taps ever see
+        # data (DSFVT: t == 1 -> 9 of the 27 taps); the others multiply zero padding and are skipped exactly
+        kt_eff = min(kt, t)
+        w_eff = conv_w if kt_eff == kt else conv_w[:, :, kt - kt_eff:].contiguous()
+        g = G.conv_geom(b, t, h, w, de, d, (kt_eff, kh, kw), (1, 1, 1), (kt_eff - 1, kh - 1, kw // 2), out=(t, h, w))
+        wp = G.pack_weight(g, w_eff, de, d)
         x = G.conv_fwd(g, emb.view(b, t, h, w, de), wp, bias=conv_b).view(rows, d)
         ew.add_periodic_(x, pos_table, P)
         y = torch.empty(rows, d, dtype=torch.float32, device=x.device)
         G.gemm(zl, proj_w, y, rows, d, d, flags=L.EPI_RESIDUAL, res=x)
         ctx.save_for_backward(sl, zl, emb, wp, proj_w)
-        ctx.g, ctx.geo = g, (b, nc, P, nv, de, d, off)
+        ctx.g, ctx.geo, ctx.kt = g, (b, nc, P, nv, de, d, off), kt
         return y
 
     @staticmethod
@@ -205,8 +209,13 @@ class _DecoderFrontFn(torch.autograd.Function):
         dproj = linear_wgrad(dy, zl, d, d, rows).view(d, d, 1, 1, 1)
         dy5 = dy.view(g.N, g.To, g.Ho, g.Wo, d)
         demb = G.conv_bwd_data(g, dy5, wp).view(rows, de)
-        dconv = G.conv_bwd_weight(g, emb.view(g.N, g.Ti, g.Hi, g.Wi, de), dy5, de, d)
-        dbias = G.colsum(dy, rows, d)
+        dconv, dbias = G.conv_bwd_weight(g, emb.view(g.N, g.Ti, g.Hi, g.Wi, de), dy5, de, d, want_bias=True)
+        if dbias is None:
+            dbias = G.colsum(dy, rows, d)
+        if g.Kt < ctx.kt:               # taps that only ever saw zero padding: gradient exactly 0
+            full = torch.zeros(d, de, ctx.kt, g.Kh, g.Kw, dtype=torch.float32, device=dy.device)
+            full[:, :, ctx.kt - g.Kt:] = dconv
+            dconv = full
         dtab = tx.onehot_tn_gemm(sl, nv, off, nc * P, 1, P, rows, demb, de)
         return None, dzl, dtab, dconv, dbias, dproj, None, None
 
