@@ -159,12 +159,18 @@ __global__ __launch_bounds__(256, 1) void lvt_attn_fwd_kernel(const float *__res
         }
     };
 
+    // causal layers: key j > query i carries exactly zero probability (exp(fill - max) underflows to 0), so key
+    // chunks beyond the workgroup's last query are never staged and key tiles beyond a wave's last query are
+    // never multiplied; their accumulators stay 0 and are overwritten with `fill` / 0 below.
+    const int iw_last = qhalf * 128 + wave * 32 + 31;                     // last query of this wave
+    const int nchunks = masked ? (qhalf * 128 + 127) / AT_KC + 1 : AT_S / AT_KC;
     load_k(0);
 #pragma unroll
     for (int c = 0; c < AT_S / AT_KC; ++c) {
+        if (c >= nchunks) break;
         park_k();
         __syncthreads();
-        if (c + 1 < AT_S / AT_KC) load_k(c + 1); else load_v(0);          // in flight during the MFMAs (and the softmax)
+        if (c + 1 < nchunks) load_k(c + 1); else load_v(0);               // in flight during the MFMAs (and the softmax)
         // the two key tiles of the chunk advance together, term by term: consecutive MFMAs never hit the same accumulator
 #pragma unroll
         for (int s = 0; s < AT_D / 16; ++s) {
@@ -179,8 +185,9 @@ __global__ __launch_bounds__(256, 1) void lvt_attn_fwd_kernel(const float *__res
             for (int tm = 0; tm < 6; ++tm)
 #pragma unroll
                 for (int kt = 0; kt < AT_KC / 32; ++kt)
-                    st[c * (AT_KC / 32) + kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kt][TA[tm]], qb[s][TB[tm]],
-                                                                                         st[c * (AT_KC / 32) + kt], 0, 0, 0);
+                    if (!masked || 32 * (c * (AT_KC / 32) + kt) <= iw_last)
+                        st[c * (AT_KC / 32) + kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kt][TA[tm]], qb[s][TB[tm]],
+                                                                                             st[c * (AT_KC / 32) + kt], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -255,12 +262,14 @@ __global__ __launch_bounds__(256, 1) void lvt_attn_fwd_kernel(const float *__res
 
 #pragma unroll
     for (int c = 0; c < AT_S / AT_KC; ++c) {
+        if (c >= nchunks) break;
         park_v();
         __syncthreads();
-        if (c + 1 < AT_S / AT_KC) load_v(c + 1);
+        if (c + 1 < nchunks) load_v(c + 1);
 #pragma unroll
         for (int kt = 0; kt < AT_KC / 32; ++kt) {
             const int T = c * (AT_KC / 32) + kt;
+            if (masked && 32 * T > iw_last) continue;                     // P is exactly 0 on this key tile
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 // B operand: P^T, registers 8s .. 8s+7 of tile T = keys {0-3, 8-11} + 16s + 4*half of the tile
