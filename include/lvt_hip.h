@@ -74,6 +74,9 @@ typedef struct {
     const float *res;  long long ldr;   /* batch strides of res / mask follow C's */
     const float *mask; long long ldm;
     int splits;
+    /* ta == 1 with splits > 1 only (weight gradient dW = dY^T X): when non-NULL receives the M column sums of A
+     * (= sum over the K rows of dY: the bias gradient), accumulated from the A tiles the kernel streams anyway. */
+    float *a_colsum;
 } lvt_gemm_desc;
 size_t lvt_gemm_workspace_bytes(const lvt_gemm_desc *d);
 int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t workspace_bytes, void *stream);

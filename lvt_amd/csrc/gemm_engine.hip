@@ -314,10 +314,22 @@ template <int BM, int MATH> struct AMLoaderBase {
 template <int BM, int MATH> struct ALoader<A_MPLAIN, BM, MATH> : AMLoaderBase<BM, MATH> {
     using Base = AMLoaderBase<BM, MATH>;
     const float *kp; bool mok; long long lda; int kcur;
+    bool sum_on; float4 colacc;      // weight gradients: running sums over k of the fetched A tiles (bias gradient)
     __device__ __forceinline__ void init(const KParams &p, int tid, int m0, const float *A, int) {
         this->kk0 = tid / Base::UPK; this->mq = tid % Base::UPK;
         const int m = m0 + this->mq * 4;
         mok = m < p.M; kp = A + m; lda = p.lda;
+        sum_on = false; colacc = zero4();
+    }
+    // sums of everything this workgroup fetched, per m: lanes with the same m quad are added in kk0 order
+    __device__ __forceinline__ void write_colsum(float *scratch, float *dst, int m0, int M, int tid) const {
+        *reinterpret_cast<float4 *>(&scratch[(this->kk0 * Base::UPK + this->mq) * 4]) = colacc;
+        __syncthreads();
+        if (tid < BM) {
+            float s_ = 0.f;
+            for (int r = 0; r < Base::KPP; ++r) s_ += scratch[(r * Base::UPK + tid / 4) * 4 + (tid & 3)];
+            if (m0 + tid < M) dst[m0 + tid] = s_;
+        }
     }
     __device__ __forceinline__ void seek(int k0) {
         kcur = k0 + this->kk0 * Base::KMUL;
@@ -328,6 +340,12 @@ template <int BM, int MATH> struct ALoader<A_MPLAIN, BM, MATH> : AMLoaderBase<BM
         for (int i = 0; i < Base::ITERS; ++i)
             this->v[i] = (mok && kcur + Base::KSTEP * i < kend) ? ldg4(kp + (long long)(Base::KSTEP * i) * lda) : zero4();
         kcur += BK; kp += (long long)BK * lda;
+        if (sum_on) {
+#pragma unroll
+            for (int i = 0; i < Base::ITERS; ++i) {
+                colacc.x += this->v[i].x; colacc.y += this->v[i].y; colacc.z += this->v[i].z; colacc.w += this->v[i].w;
+            }
+        }
     }
 };
 
@@ -682,7 +700,9 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     constexpr bool COLSUM = (AMODE == A_CONV_M && BMODE == B_NPLAIN);
+    constexpr bool COLSUM_A = (AMODE == A_MPLAIN);
     if constexpr (COLSUM) bl.sum_on = p.colsum_partial != nullptr && m0 == 0;
+    if constexpr (COLSUM_A) al.sum_on = p.colsum_partial != nullptr && n0 == 0 && z == 0;
     if (kbeg < kend) {
         al.seek(kbeg); bl.seek(kbeg);
         al.fetch(kend); bl.fetch(kend);
@@ -765,6 +785,9 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
 
     if constexpr (COLSUM) {
         if (bl.sum_on) bl.write_colsum(lds, p.colsum_partial + (long long)split * p.N, n0, p.N, tid);   // staging LDS is free now
+    }
+    if constexpr (COLSUM_A) {
+        if (al.sum_on) al.write_colsum(lds, p.colsum_partial + (long long)split * p.M, m0, p.M, tid);
     }
     lvt_epilogue<AMODE, BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, l31, half, cls, coff, z, split);
 }
@@ -925,7 +948,7 @@ static int gemm_batch(const lvt_gemm_desc *d) {
 
 extern "C" size_t lvt_gemm_workspace_bytes(const lvt_gemm_desc *d) {
     if (!d || d->splits <= 1) return 0;
-    return (size_t)d->splits * gemm_batch(d) * (size_t)d->M * d->N * sizeof(float);
+    return (size_t)d->splits * (gemm_batch(d) * (size_t)d->M * d->N + (d->a_colsum ? (size_t)d->M : 0)) * sizeof(float);
 }
 
 extern "C" int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t workspace_bytes, void *stream) {
@@ -958,6 +981,12 @@ extern "C" int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t work
         p.k_per_split = (int)(lvt_cdiv(lvt_cdiv(p.K, p.splits), BK) * BK);
         p.partial = (float *)workspace;
         p.partial_stride = (long long)zc * d->M * d->N;
+        if (d->a_colsum) {
+            LVT_REQUIRE(d->ta == 1 && zc == 1 && d->M % 4 == 0, "gemm: a_colsum needs ta == 1, no batch, M %% 4 == 0");
+            p.colsum_partial = p.partial + (long long)p.splits * p.partial_stride;
+        }
+    } else {
+        LVT_REQUIRE(!d->a_colsum, "gemm: a_colsum needs splits > 1");
     }
     int rc;
     if (d->ta == 0 && d->tb == 0) rc = launch_tile<A_KPLAIN, B_KPLAIN, 128, 128, 2, 2>(p, zc, s);
@@ -971,6 +1000,11 @@ extern "C" int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t work
         hipLaunchKernelGGL(lvt_reduce_splits_kernel, dim3(blocks), dim3(256), 0, s, p.partial, n4,
                            p.partial_stride, p.splits, d->C, (d->flags & LVT_EPI_ACCUM) ? 1 : 0);
         LVT_CHECK_LAUNCH("lvt_reduce_splits_kernel");
+        if (p.colsum_partial) {
+            hipLaunchKernelGGL(lvt_reduce_splits_kernel, dim3((unsigned)lvt_cdiv(d->M / 4, 256)), dim3(256), 0, s,
+                               (const float *)p.colsum_partial, (long long)(d->M / 4), (long long)d->M, p.splits, d->a_colsum, 0);
+            LVT_CHECK_LAUNCH("lvt_reduce_splits_kernel");
+        }
     }
     return LVT_OK;
 }

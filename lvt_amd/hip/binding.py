@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("alpha", C.c_float), ("flags", C.c_int),
         ("bias", C.c_void_p), ("res", C.c_void_p), ("ldr", C.c_longlong),
         ("mask", C.c_void_p), ("ldm", C.c_longlong), ("splits", C.c_int),
+        ("a_colsum", C.c_void_p),
     ]
 
 

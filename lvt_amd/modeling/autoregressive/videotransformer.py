@@ -298,15 +298,14 @@ class _ChannelPredictorFn(torch.autograd.Function):
             fin = uw.shape[1]
             du = torch.empty(rows, d, dtype=torch.float32, device=dev)
             G.gemm(do, pw, du, rows, d, nvk, ta=0, tb=1, ldb=d, flags=L.EPI_MASK, mask=us[k])
-            dpw = linear_wgrad(do, us[k], nvk, d, rows)
-            dpb = G.colsum(do, rows, nvk)
+            dpw, dpb = linear_wgrad(do, us[k], nvk, d, rows, want_bias=True)
             G.gemm(du, uw, dy, rows, d, d, ta=0, tb=1, ldb=fin, flags=L.EPI_ACCUM if k else 0)
             duw = torch.empty(d, fin, dtype=torch.float32, device=dev)
-            duw[:, :d] = linear_wgrad(du, y, d, d, rows)
+            duw_d, dub = linear_wgrad(du, y, d, d, rows, want_bias=True)
+            duw[:, :d] = duw_d
             if k > 0:
                 dut = tx.onehot_tn_gemm(sl, nv, [c * P for c in range(k)], nc * P, 1, P, rows, du, d)   # (k*nv, d)
                 duw[:, d:] = dut.t()
-            dub = G.colsum(du, rows, d)
             grads += [duw, dub, dpw, dpb]
         dyl, dlnw, dlnb = ew.layernorm_bwd(dy, yl, mean, rstd, ln_w)
         return (dyl, None, dlnw, dlnb, None) + tuple(grads)

@@ -87,12 +87,21 @@ def _splits(tiles, k):
     return max(1, min(s, k // 512 if k >= 1024 else 1))
 
 
-def linear_wgrad(dy, x, n_out, k_in, rows):
-    """dW (n_out, k_in) = dy^T x with deterministic split-K."""
+def linear_wgrad(dy, x, n_out, k_in, rows, want_bias=False):
+    """dW (n_out, k_in) = dy^T x with deterministic split-K; want_bias additionally returns db = column sums of dy,
+    accumulated by the same launch from the dy tiles it streams."""
     dw = torch.empty(n_out, k_in, dtype=torch.float32, device=dy.device)
     tiles = -(-n_out // 128) * -(-k_in // 128)
-    G.gemm(dy, x, dw, n_out, k_in, rows, ta=1, tb=1, lda=dy.shape[-1], ldb=x.shape[-1], splits=_splits(tiles, rows))
-    return dw
+    splits = _splits(tiles, rows)
+    if not want_bias:
+        G.gemm(dy, x, dw, n_out, k_in, rows, ta=1, tb=1, lda=dy.shape[-1], ldb=x.shape[-1], splits=splits)
+        return dw
+    if splits < 2:
+        G.gemm(dy, x, dw, n_out, k_in, rows, ta=1, tb=1, lda=dy.shape[-1], ldb=x.shape[-1], splits=splits)
+        return dw, G.colsum(dy, rows, n_out)
+    db = torch.empty(n_out, dtype=torch.float32, device=dy.device)
+    G.gemm(dy, x, dw, n_out, k_in, rows, ta=1, tb=1, lda=dy.shape[-1], ldb=x.shape[-1], splits=splits, a_colsum=db)
+    return dw, db
 
 
 FUSED_ATTENTION = True      # scores + bias + mask + softmax + P.V in one launch when the block is 256 tokens x 128 dims
@@ -151,12 +160,10 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         # FFN: y2 = h1 W3^T + b3 + y1 ; h1 = relu(fn W1^T + b1)
         dh1 = torch.empty(M, dff, dtype=torch.float32, device=dev)
         G.gemm(dy2, f3w, dh1, M, dff, d, ta=0, tb=1, ldb=dff, flags=L.EPI_MASK, mask=h1)
-        df3w = linear_wgrad(dy2, h1, d, dff, M)
-        df3b = G.colsum(dy2, M, d)
+        df3w, df3b = linear_wgrad(dy2, h1, d, dff, M, want_bias=True)
         dfn = torch.empty(M, d, dtype=torch.float32, device=dev)
         G.gemm(dh1, f1w, dfn, M, d, dff, ta=0, tb=1, ldb=d)
-        df1w = linear_wgrad(dh1, fn, dff, d, M)
-        df1b = G.colsum(dh1, M, dff)
+        df1w, df1b = linear_wgrad(dh1, fn, dff, d, M, want_bias=True)
         dy1, df0w, df0b = ew.layernorm_bwd(dfn, y1, mean2, rstd2, f0w, add=dy2)
         # proj: y1 = o proj^T + x
         do = torch.empty(M, hd, dtype=torch.float32, device=dev)

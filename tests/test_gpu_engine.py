@@ -243,3 +243,15 @@ def test_gemm_small_m(M, N, K, tb):
     G.gemm_small(a.to(d), w.to(d), out, M, N, K, tb=tb, alpha=0.5, flags=L.EPI_BIAS | L.EPI_RESIDUAL | L.EPI_RELU,
                  bias=b.to(d), res=r.to(d))
     assert rel_err(out, ref) < TOL
+
+
+def test_gemm_tn_splitk_with_a_colsum():
+    """Weight-gradient GEMM dW = dY^T X with the bias gradient (column sums of dY) from the same launch."""
+    from lvt_amd.hip import gemm as G
+    rows, n_out, k_in = 4096, 384, 256
+    dy, x = _rand(rows, n_out), _rand(rows, k_in, seed=1)
+    d = _dev()
+    dw = torch.empty(n_out, k_in, device=d); db = torch.full((n_out,), float("nan"), device=d)
+    G.gemm(dy.to(d), x.to(d), dw, n_out, k_in, rows, ta=1, tb=1, lda=n_out, ldb=k_in, splits=8, a_colsum=db)
+    assert rel_err(dw, dy.t() @ x) < 5e-5
+    assert rel_err(db, dy.double().sum(0).float()) < 1e-5
