@@ -19,6 +19,7 @@
 //     weight gradients are bit-reproducible run to run (no float atomics).
 #include "lvt_common.h"
 #include <string.h>
+#include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -44,6 +45,7 @@ struct KParams {
     float alpha; int flags;
     const float *bias; const float *res; long long ldr; const float *mask; long long ldm;
     int splits; int k_per_split; float *partial; long long partial_stride;
+    int vec_epi;             // C / res / mask / partial rows are 16-byte aligned and N % 4 == 0: float4 epilogue
     float *colsum_partial;   // bwd-weight: [splits][N] column sums of B (= bias gradient), written by the m0 == 0 tiles
     lvt_conv_geom g;
     int Tq, Hq, Wq;          // A_CONVT_K: per-phase output extents
@@ -659,6 +661,76 @@ __device__ __forceinline__ TileCtx lvt_tile_ctx(const KParams &p) {
     return t;
 }
 
+// The accumulator layout gives a lane ONE column and 16 rows per 32x32 tile, i.e. 4-byte stores and 4-byte residual /
+// mask loads, 64 of them per thread, each with its own address arithmetic -- for the K = 512 GEMMs of the transformer
+// this epilogue cost about as much as a third of the main loop.  Here every wave turns its sub-tile through LDS
+// (32 rows at a time, wave-private region of the staging memory, which is free after the main loop): a lane then owns
+// 4 consecutive columns of a row, the residual / mask / accumulate reads and the store are 16-byte accesses, a wave
+// instruction covers whole 256-byte row segments, and the row decode (ConvTranspose phases) runs once per float4.
+template <int AMODE, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void lvt_epilogue_vec(const KParams &p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float *lds,
+                                                 int m0, int n0, int wm, int wn, int lane, int cls, long long coff, int z,
+                                                 int split) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int SW = TN * 32;                    // sub-tile width (floats), row stride of the LDS turn-table
+    constexpr int C4 = SW / 4;                     // float4 per row
+    const int l31 = lane & 31, half = lane >> 5;
+    float *tile = lds + (wm * WN + wn) * (32 * SW);
+    int rt = 0, rh = 0, rw = 0;
+    if (AMODE == A_CONVT_K) {
+        const lvt_conv_geom &g = p.g;
+        const int fw = cls % g.sw, fh = (cls / g.sw) % g.sh, ft = cls / (g.sw * g.sh);
+        rt = ((ft - g.pt) % g.st + g.st) % g.st;
+        rh = ((fh - g.ph) % g.sh + g.sh) % g.sh;
+        rw = ((fw - g.pw) % g.sw + g.sw) % g.sw;
+    }
+    const int flags = p.flags;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * SW + 32 * j + l31] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 32 * C4 / 64; ++u) {
+            const int idx = lane + 64 * u;
+            const int rowl = idx / C4, c4 = idx % C4;
+            const int row = m0 + wm * (TM * 32) + i * 32 + rowl;
+            const int col = n0 + wn * SW + 4 * c4;
+            if (row < p.M && col < p.N) {
+                float4 v = *reinterpret_cast<const float4 *>(&tile[rowl * SW + 4 * c4]);
+                long long orow = row;
+                if (AMODE == A_CONVT_K) {
+                    const lvt_conv_geom &g = p.g;
+                    int m = row;
+                    const int qw = m % p.Wq; m /= p.Wq;
+                    const int qh = m % p.Hq; m /= p.Hq;
+                    const int qt = m % p.Tq; const int n = m / p.Tq;
+                    orow = (((long long)n * g.Ti + (g.st * qt + rt)) * g.Hi + (g.sh * qh + rh)) * g.Wi + (g.sw * qw + rw);
+                }
+                if (p.splits > 1) {
+                    *reinterpret_cast<float4 *>(p.partial + split * p.partial_stride + (long long)z * p.M * p.N + orow * p.N + col) = v;
+                } else {
+                    v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+                    if (flags & LVT_EPI_BIAS) { const float4 b = ldg4(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                    if (flags & LVT_EPI_RESIDUAL) { const float4 b = ldg4(p.res + coff + orow * p.ldr + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                    if (flags & LVT_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (flags & LVT_EPI_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+                    if (flags & LVT_EPI_MASK) {
+                        const float4 mk = ldg4(p.mask + coff + orow * p.ldm + col);
+                        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                    }
+                    float4 *cp = reinterpret_cast<float4 *>(p.C + coff + orow * p.ldc + col);
+                    if (flags & LVT_EPI_ACCUM) { const float4 c = *cp; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+                    *cp = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // MATH == 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
 // MATH == 1: bf16x3 split -- every fp32 operand is staged as three bf16 planes and each 32x32x16 block is six
 //            v_mfma_f32_32x32x16_bf16 (a1b1, a1b2, a2b1, a1b3, a3b1, a2b2: all product terms above 2^-24 |ab|,
@@ -789,7 +861,8 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
     if constexpr (COLSUM_A) {
         if (al.sum_on) al.write_colsum(lds, p.colsum_partial + (long long)split * p.M, m0, p.M, tid);
     }
-    lvt_epilogue<AMODE, BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, l31, half, cls, coff, z, split);
+    if (p.vec_epi) lvt_epilogue_vec<AMODE, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, cls, coff, z, split);
+    else lvt_epilogue<AMODE, BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, l31, half, cls, coff, z, split);
 }
 
 // deterministic split-K reduction: out[i] (+)= sum_s partial[s][i]
@@ -908,10 +981,23 @@ static int launch_tile(const KParams &p, int zcount, hipStream_t s) {
         return LVT_EINVAL;
     }
     dim3 grid((unsigned)(ntm * ntn), (unsigned)zcount, (unsigned)(p.splits > 1 ? p.splits : 1));
+    KParams pv = p;
+    {
+        auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
+        bool ok = p.N % 4 == 0;
+        if (p.splits > 1) ok = ok && al16(p.partial) && p.partial_stride % 4 == 0 && ((long long)p.M * p.N) % 4 == 0;
+        else {
+            ok = ok && al16(p.C) && p.ldc % 4 == 0 && p.sC_o % 4 == 0 && p.sC_i % 4 == 0;
+            if (p.flags & LVT_EPI_BIAS) ok = ok && al16(p.bias);
+            if (p.flags & LVT_EPI_RESIDUAL) ok = ok && al16(p.res) && p.ldr % 4 == 0;
+            if (p.flags & LVT_EPI_MASK) ok = ok && al16(p.mask) && p.ldm % 4 == 0;
+        }
+        pv.vec_epi = ok ? 1 : 0;
+    }
     if (g_math_mode == 1 && BK == 32)
-        hipLaunchKernelGGL((lvt_gemm_kernel<AMODE, BMODE, BM, BN, WM, WN, 1>), grid, dim3(NTHREADS), 0, s, p);
+        hipLaunchKernelGGL((lvt_gemm_kernel<AMODE, BMODE, BM, BN, WM, WN, 1>), grid, dim3(NTHREADS), 0, s, pv);
     else
-        hipLaunchKernelGGL((lvt_gemm_kernel<AMODE, BMODE, BM, BN, WM, WN, 0>), grid, dim3(NTHREADS), 0, s, p);
+        hipLaunchKernelGGL((lvt_gemm_kernel<AMODE, BMODE, BM, BN, WM, WN, 0>), grid, dim3(NTHREADS), 0, s, pv);
     LVT_CHECK_LAUNCH("lvt_gemm_kernel");
     return LVT_OK;
 }
