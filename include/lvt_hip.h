@@ -118,16 +118,12 @@ size_t lvt_conv3d_bwd_weight_workspace_bytes(const lvt_conv_geom *g);
 int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, float *db,
                           int Ci_real, int Co_real, void *workspace, size_t workspace_bytes,
                           void *stream);
-/* Image-side layers (3 channels carried as 4): LDS-tiled fp32 FMA kernels that read the 128-channel activation
- * exactly once instead of spending MFMA tiles on padding columns.
+/* Image-side layer (3 channels carried as 4): LDS-tiled fp32 FMA kernel that reads the 128-channel activation exactly
+ * once instead of spending MFMA tiles on padding columns.
  * lvt_convt4_fwd: ConvTranspose2d(Ci -> Cr<=3, k4 s2 p1) forward, x (N,Hi,Wi,Ci) -> y (N,2Hi,2Wi,4) (+tanh);
- *                 w in torch layout (Ci, Cr, 4, 4), bias (Cr).   (K6 of resdecoder.py:56,68)
- * lvt_conv4_bwd_weight: weight gradient of a 2-D conv whose input has 4 (padded) channels (K1 / K6 bwd-W).   */
+ *                 w in torch layout (Ci, Cr, 4, 4), bias (Cr).   (K6 of resdecoder.py:56,68)                   */
 int lvt_convt4_fwd(const float *x, const float *w, const float *bias, int N, int Hi, int Wi, int Ci, int Cr,
                    int act_tanh, float *y, void *stream);
-size_t lvt_conv4_bwd_weight_workspace_bytes(const lvt_conv_geom *g);
-int lvt_conv4_bwd_weight(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, int Ci_real,
-                         int Co_real, void *workspace, size_t workspace_bytes, void *stream);
 /* out[n] (+)= sum_m g[m*ld + n]  (bias gradients).  workspace >= lvt_colsum_workspace_bytes.        */
 size_t lvt_colsum_workspace_bytes(long long M, int N);
 int lvt_colsum(const float *g, long long M, int N, long long ld, float *out, void *workspace,

@@ -742,7 +742,9 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
     using BL = BLoader<BMODE, BN, MATH>;
     constexpr int LDA = AL::LD, LDB = BL::LD;
     constexpr int PSA = HPlane<BM>::SIZE, PSB = HPlane<BN>::SIZE;                       // bf16 plane strides (MATH == 1)
-    constexpr int LDS_FLOATS = MATH == 0 ? (BK * LDA + BK * LDB + 8) : (3 * (PSA + PSB) / 2 + 8);
+    constexpr int STAGE_FLOATS = MATH == 0 ? (BK * LDA + BK * LDB + 8) : (3 * (PSA + PSB) / 2 + 8);
+    constexpr int TURN_FLOATS = WM * WN * 32 * (TN * 32);             // epilogue turn-table: 32 rows of every wave's sub-tile
+    constexpr int LDS_FLOATS = STAGE_FLOATS > TURN_FLOATS ? STAGE_FLOATS : TURN_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float *As = lds;
     float *Bs = lds + ((BK * LDA + 3) & ~3);
@@ -1166,20 +1168,10 @@ extern "C" int lvt_conv3d_bwd_data(const lvt_conv_geom *g, const float *dy, cons
 
 static int bwd_weight_splits(const lvt_conv_geom *g) {
     const long long Mg = (long long)g->Kt * g->Kh * g->Kw * g->Ci;
-    const long long tiles = lvt_cdiv(Mg, 128) * lvt_cdiv(g->Co, 128);
+    const long long tiles = lvt_cdiv(Mg, Mg <= 64 ? 64 : 128) * lvt_cdiv(g->Co, 128);
     const long long pix = (long long)g->N * g->To * g->Ho * g->Wo;
     const int s = choose_splits(tiles, (int)(pix < 0x7fffffffLL ? pix : 0x7fffffff), 512);
     return s < 2 ? 2 : s;   // always go through the partial buffer (the unpack kernel reduces it)
-}
-
-int lvt_unpack_wgrad(const void *partial, long long stride, int splits, float *dw, int taps, int Ci, int Co,
-                     int Ci_real, int Co_real, void *stream) {
-    const long long total = (long long)taps * Ci * Co;
-    const int blocks = (int)(lvt_cdiv(total, 256) < 4096 ? lvt_cdiv(total, 256) : 4096);
-    hipLaunchKernelGGL(lvt_unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)partial,
-                       stride, splits, dw, taps, Ci, Co, Ci_real, Co_real, (const float *)nullptr, (float *)nullptr);
-    LVT_CHECK_LAUNCH("lvt_unpack_wgrad_kernel");
-    return LVT_OK;
 }
 
 extern "C" size_t lvt_conv3d_bwd_weight_workspace_bytes(const lvt_conv_geom *g) {
@@ -1210,7 +1202,8 @@ extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, con
     p.partial_stride = (long long)p.M * p.N;
     p.colsum_partial = db ? p.partial + (long long)p.splits * p.partial_stride : nullptr;
     hipStream_t s = (hipStream_t)stream;
-    rc = launch_tile<A_CONV_M, B_NPLAIN, 128, 128, 2, 2>(p, 1, s);
+    if (p.M <= 64) rc = launch_tile<A_CONV_M, B_NPLAIN, 64, 128, 2, 2>(p, 1, s);     // image-side layers: 16 taps x 4 channels
+    else rc = launch_tile<A_CONV_M, B_NPLAIN, 128, 128, 2, 2>(p, 1, s);
     if (rc) return rc;
     const long long total = (long long)Co_real * Ci_real * taps;
     int blocks = (int)(lvt_cdiv(total, 256) < 4096 ? lvt_cdiv(total, 256) : 4096);

@@ -30,6 +30,3 @@ static inline __host__ __device__ long long lvt_cdiv(long long a, long long b) {
 // 256 CUs x 8 XCDs on MI355X; used only to size grids / split-K, never for correctness.
 #define LVT_NUM_CU 256
 
-// partial[split][(tap*Ci + ci)][co] -> dw[co][ci][tap], splits summed in order (defined in gemm_engine.hip)
-int lvt_unpack_wgrad(const void *partial, long long stride, int splits, float *dw, int taps, int Ci, int Co,
-                     int Ci_real, int Co_real, void *stream);

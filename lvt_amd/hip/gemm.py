@@ -131,26 +131,12 @@ def convT4_fwd(x, w, bias, act_tanh):
     return y
 
 
-def thin_wgrad_ok(g):
-    return (g.Ci == 4 and g.Kt == 1 and g.Ti == 1 and g.To == 1 and (g.Kh, g.Kw) in ((3, 3), (4, 4)) and 256 % g.Co == 0
-            and g.Wo % 32 == 0)
-
-
 def conv_bwd_weight(g, x, dy, Ci_real, Co_real, want_bias=False):
     """-> dw, or (dw, db) with want_bias: db = column sums of dy (the bias gradient of a forward conv), produced by
-    the same launch; db is None when this geometry takes the image-side kernel (the caller falls back to colsum)."""
+    the same launch."""
     L.require(x, dy)
     lib = L.lib()
     dw = torch.empty(Co_real, Ci_real, g.Kt, g.Kh, g.Kw, dtype=torch.float32, device=x.device)
-    if thin_wgrad_ok(g):
-        nws = lib.lvt_conv4_bwd_weight_workspace_bytes(C.byref(g))
-        ws = L.workspace(nws, x.device, "wgrad4")
-        t0 = L.TIMER.begin() if L.TIMER is not None else None
-        L.check(lib.lvt_conv4_bwd_weight(C.byref(g), L.ptr(x), L.ptr(dy), L.ptr(dw), Ci_real, Co_real, L.ptr(ws), nws,
-                                         L.stream_ptr()), "lvt_conv4_bwd_weight")
-        if t0 is not None:
-            L.TIMER.end("thin_bwd_weight", conv_flops(g), t0)
-        return (dw, None) if want_bias else dw
     nws = lib.lvt_conv3d_bwd_weight_workspace_bytes(C.byref(g))
     ws = L.workspace(nws, x.device, "wgrad")
     db = torch.empty(Co_real, dtype=torch.float32, device=x.device) if want_bias else None
