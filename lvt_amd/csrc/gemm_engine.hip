@@ -899,9 +899,11 @@ __global__ void lvt_pack_weight_kernel(const float *__restrict__ w, float *__res
     }
 }
 // partial[split][(tap,ci)][co] -> dw[co][ci][tap]   (fixed summation order over splits).
-// Threads walk the SOURCE layout (co fastest) so that the splits-times-repeated reads are coalesced;
-// the one scattered write per element is the cheap side.
-__global__ void lvt_unpack_wgrad_kernel(const float *__restrict__ partial, long long stride, int splits,
+// L lanes share one output element (L a power of two <= 64, chosen from the split count): lane s adds splits
+// s, s+L, ... and the L lane sums are combined by a butterfly -- a fixed tree.  With one thread per element the
+// image-side layers (1 tile, 512 splits) paid a chain of 512 dependent loads per thread.  Threads walk the SOURCE
+// layout (co fastest) so the reads are contiguous per split; the one scattered write per element is the cheap side.
+__global__ void lvt_unpack_wgrad_kernel(const float *__restrict__ partial, long long stride, int splits, int L,
                                         float *__restrict__ dw, int taps, int Ci, int Co, int Ci_real,
                                         int Co_real, const float *__restrict__ colsum_partial, float *__restrict__ db) {
     if (db) {
@@ -916,14 +918,19 @@ __global__ void lvt_unpack_wgrad_kernel(const float *__restrict__ partial, long 
         }
     }
     const long long total = (long long)taps * Ci * Co;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int co = i % Co; long long t = i / Co;
-        const int ci = t % Ci; const int tap = t / Ci;
-        if (co >= Co_real || ci >= Ci_real) continue;
-        float s = partial[i];
-        for (int k = 1; k < splits; ++k) s += partial[k * stride + i];
-        dw[((long long)co * Ci_real + ci) * taps + tap] = s;
+    const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = (int)(gtid & (L - 1));
+    // the L lanes of an element share `i`, so they enter and leave the loop together and the butterfly only ever
+    // exchanges inside such a group
+    for (long long i = gtid / L; i < total; i += ((long long)gridDim.x * blockDim.x) / L) {
+        float s = 0.f;
+        for (int k = sub; k < splits; k += L) s += partial[k * stride + i];
+        for (int d = L >> 1; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+        if (sub == 0) {
+            const int co = i % Co; long long t = i / Co;
+            const int ci = t % Ci; const int tap = t / Ci;
+            if (co < Co_real && ci < Ci_real) dw[((long long)co * Ci_real + ci) * taps + tap] = s;
+        }
     }
 }
 
@@ -1205,11 +1212,14 @@ extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, con
     if (p.M <= 64) rc = launch_tile<A_CONV_M, B_NPLAIN, 64, 128, 2, 2>(p, 1, s);     // image-side layers: 16 taps x 4 channels
     else rc = launch_tile<A_CONV_M, B_NPLAIN, 128, 128, 2, 2>(p, 1, s);
     if (rc) return rc;
-    const long long total = (long long)Co_real * Ci_real * taps;
-    int blocks = (int)(lvt_cdiv(total, 256) < 4096 ? lvt_cdiv(total, 256) : 4096);
-    if (db && blocks < (int)lvt_cdiv(Co_real, 4)) blocks = (int)lvt_cdiv(Co_real, 4);      // one wave per bias entry
-    hipLaunchKernelGGL(lvt_unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, s, p.partial, p.partial_stride,
-                       p.splits, dw, taps, g->Ci, g->Co, Ci_real, Co_real, (const float *)p.colsum_partial, db);
+    const long long total = (long long)taps * g->Ci * g->Co;
+    int L = 1;
+    while (L < 64 && L * 4 <= p.splits) L <<= 1;                     // ~4 splits per lane
+    long long blocks = lvt_cdiv(total * L, 256);
+    if (blocks > 8192) blocks = 8192;
+    if (db && blocks < lvt_cdiv(Co_real, 4)) blocks = lvt_cdiv(Co_real, 4);          // one wave per bias entry
+    hipLaunchKernelGGL(lvt_unpack_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.partial, p.partial_stride,
+                       p.splits, L, dw, taps, g->Ci, g->Co, Ci_real, Co_real, (const float *)p.colsum_partial, db);
     LVT_CHECK_LAUNCH("lvt_unpack_wgrad_kernel");
     return LVT_OK;
 }
