@@ -873,11 +873,24 @@ __global__ void lvt_reduce_splits_kernel(const float *__restrict__ partial, long
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long step = (long long)gridDim.x * blockDim.x;
     for (; i < n4; i += step) {
-        float4 s = ldg4(partial + i * 4);
-        for (int k = 1; k < splits; ++k) {
-            const float4 t = ldg4(partial + k * stride + i * 4);
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        // four independent running sums (the loads of a thread do not wait on each other), combined in a fixed order
+        float4 s0 = ldg4(partial + i * 4), s1 = zero4(), s2 = zero4(), s3 = zero4();
+        int k = 1;
+        for (; k + 3 < splits; k += 4) {
+            const float4 t0 = ldg4(partial + k * stride + i * 4), t1 = ldg4(partial + (k + 1) * stride + i * 4);
+            const float4 t2 = ldg4(partial + (k + 2) * stride + i * 4), t3 = ldg4(partial + (k + 3) * stride + i * 4);
+            s0.x += t0.x; s0.y += t0.y; s0.z += t0.z; s0.w += t0.w;
+            s1.x += t1.x; s1.y += t1.y; s1.z += t1.z; s1.w += t1.w;
+            s2.x += t2.x; s2.y += t2.y; s2.z += t2.z; s2.w += t2.w;
+            s3.x += t3.x; s3.y += t3.y; s3.z += t3.z; s3.w += t3.w;
         }
+        for (; k < splits; ++k) {
+            const float4 t = ldg4(partial + k * stride + i * 4);
+            s0.x += t.x; s0.y += t.y; s0.z += t.z; s0.w += t.w;
+        }
+        float4 s;
+        s.x = (s0.x + s1.x) + (s2.x + s3.x); s.y = (s0.y + s1.y) + (s2.y + s3.y);
+        s.z = (s0.z + s1.z) + (s2.z + s3.z); s.w = (s0.w + s1.w) + (s2.w + s3.w);
         float4 *o = reinterpret_cast<float4 *>(out + i * 4);
         if (accumulate) { const float4 c = *o; s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w; }
         *o = s;
