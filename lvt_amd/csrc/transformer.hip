@@ -493,13 +493,26 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void lvt_attn_decode_kernel(const f
     if (lane == 0) reds[wave] = sum;
     __syncthreads();
     sum = ((reds[0] + reds[1]) + reds[2]) + reds[3];
-    float a0 = 0.f, a1 = 0.f;
+    // four value rows in flight per wave (independent accumulator pairs, combined in a fixed order)
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f, c0 = 0.f, c1 = 0.f, d0 = 0.f, d1 = 0.f;
     const float *vp = Vc + (long long)b * S * hd + h * DEC_DA;
-    for (int j = wave; j < nk; j += DEC_WAVES) {
+    int j = wave;
+    for (; j + 3 * DEC_WAVES < nk; j += 4 * DEC_WAVES) {
+        const float *v0 = vp + (long long)j * hd, *v1 = v0 + (long long)DEC_WAVES * hd, *v2 = v1 + (long long)DEC_WAVES * hd,
+                    *v3 = v2 + (long long)DEC_WAVES * hd;
+        const float x0 = v0[lane], y0 = v0[lane + 64], x1 = v1[lane], y1 = v1[lane + 64];
+        const float x2 = v2[lane], y2 = v2[lane + 64], x3 = v3[lane], y3 = v3[lane + 64];
+        a0 = fmaf(ps[j], x0, a0); a1 = fmaf(ps[j], y0, a1);
+        b0 = fmaf(ps[j + DEC_WAVES], x1, b0); b1 = fmaf(ps[j + DEC_WAVES], y1, b1);
+        c0 = fmaf(ps[j + 2 * DEC_WAVES], x2, c0); c1 = fmaf(ps[j + 2 * DEC_WAVES], y2, c1);
+        d0 = fmaf(ps[j + 3 * DEC_WAVES], x3, d0); d1 = fmaf(ps[j + 3 * DEC_WAVES], y3, d1);
+    }
+    for (; j < nk; j += DEC_WAVES) {
         const float p = ps[j];
         a0 = fmaf(p, vp[(long long)j * hd + lane], a0);
         a1 = fmaf(p, vp[(long long)j * hd + lane + 64], a1);
     }
+    a0 = (a0 + b0) + (c0 + d0); a1 = (a1 + b1) + (c1 + d1);
     acc[wave][lane] = a0; acc[wave][lane + 64] = a1;
     __syncthreads();
     if (tid < DEC_DA)
