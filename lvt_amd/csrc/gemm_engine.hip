@@ -332,6 +332,7 @@ template <int BM, int MATH> struct ALoader<A_MPLAIN, BM, MATH> : AMLoaderBase<BM
             for (int r = 0; r < Base::KPP; ++r) s_ += scratch[(r * Base::UPK + tid / 4) * 4 + (tid & 3)];
             if (m0 + tid < M) dst[m0 + tid] = s_;
         }
+        __syncthreads();             // the epilogue reuses this memory
     }
     __device__ __forceinline__ void seek(int k0) {
         kcur = k0 + this->kk0 * Base::KMUL;
@@ -550,6 +551,7 @@ template <int BN, int MATH> struct BLoader<B_NPLAIN, BN, MATH> {
             for (int r = 0; r < KROWS; ++r) s_ += scratch[(r * UPK + tid / 4) * 4 + (tid & 3)];
             if (n0 + tid < N) dst[n0 + tid] = s_;
         }
+        __syncthreads();             // the epilogue reuses this memory
     }
     __device__ __forceinline__ void store(float *lds) const {
         if (!active) return;
