@@ -164,6 +164,25 @@ def test_conv_transpose_as_bwd_data(Cin, Cout, H):
     assert rel_err(dw.squeeze(2), w.grad) < 5e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,Ci,Cr,Hi,Wi,act", [(2, 128, 3, 32, 32, True), (3, 32, 3, 5, 7, False), (1, 16, 1, 9, 40, True),
+                                               (2, 48, 2, 8, 33, False)])
+def test_thin_conv_transpose_forward(N, Ci, Cr, Hi, Wi, act):
+    """The dedicated image-side ConvTranspose2d(Ci -> <=3, k4 s2 p1) kernel (K6): full and ragged tiles, 1..3 real
+    channels, with and without tanh; the carried 4th channel is exactly act(0) = 0."""
+    from lvt_amd.hip import gemm as G
+    x, w, b = _rand(N, Ci, Hi, Wi), _rand(Ci, Cr, 4, 4, seed=1) * 0.1, _rand(Cr, seed=2)
+    y = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    if act:
+        y = torch.tanh(y)
+    dev = _dev()
+    yd = G.convT4_fwd(_nhwc(x).to(dev), w.to(dev), b.to(dev), act).cpu()
+    assert yd.shape == (N, 1, 2 * Hi, 2 * Wi, 4)
+    got = yd[:, 0].permute(0, 3, 1, 2)
+    assert rel_err(got[:, :Cr], y.float()) < 2e-6
+    assert (got[:, Cr:] == 0).all()
+
+
 def test_conv_bwd_data_residual_and_mask():
     from lvt_amd.hip import gemm as G
     N, C, H = 2, 128, 16
