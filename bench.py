@@ -49,7 +49,9 @@ MATH_NOTE = {
 PEAK_NOTE = {
     "f32": "dense fp32 MFMA peak (MI355X_MICROARCH.md)",
     "bf16x3": "dense bf16 MFMA peak 2516.6 TFLOP/s / 6 MFMA products per algorithmic fp32 product; `achieved` counts "
-              "ALGORITHMIC fp32 FLOPs only (not the 6x executed bf16 FLOPs)",
+              "ALGORITHMIC fp32 FLOPs only (not the 6x executed bf16 FLOPs); an MFMA-only loop on random bf16 operands "
+              "sustains 71 % of that peak on this part (power throttling by operand toggling, "
+              "profiles/r01_ubench_engine_bounds.txt), i.e. ~300 TFLOP/s in these units",
 }
 
 
