@@ -207,8 +207,8 @@ _ws = {}
 
 
 def workspace(nbytes, device, tag="default"):
-    """Grow-only scratch buffer per (device, tag), reused across calls on the same stream."""
-    key = (device, tag)
+    """Grow-only scratch buffer per (device, tag, stream), reused across calls on the same stream."""
+    key = (device, tag, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
