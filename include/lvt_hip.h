@@ -87,6 +87,23 @@ int lvt_gemm_smallm_f32(int M, int N, int K, int tb, const float *A, long long l
                         long long ldb, float *C, long long ldc, int batch, long long sB, long long sC,
                         float alpha, int flags, const float *bias, const float *res, long long ldr,
                         void *stream);
+/* Split-K form of the small-M product for long reductions (K >= 1024: the FFN down-projection, the attention output
+ * projection and the wide predictor layers of a decode step).  K is cut into `splits` equal ranges (each a multiple
+ * of 8) that run as independent workgroups; the partial tiles go through `workspace` and are added in split order by
+ * a second launch that also applies the epilogue (deterministic).  tb == 0 layout only, N % 4 == 0.            */
+size_t lvt_gemm_smallm_splitk_workspace_bytes(int M, int N, int splits);
+int lvt_gemm_smallm_splitk_f32(int M, int N, int K, int splits, const float *A, long long lda, const float *B,
+                               long long ldb, float *C, long long ldc, float alpha, int flags, const float *bias,
+                               const float *res, long long ldr, void *workspace, size_t workspace_bytes, void *stream);
+/* The same partial products without the reduction launch (workspace = [splits][M][N] raw partial tiles), and the
+ * LayerNorm that consumes them:  x = sum_s partials[s] (+ bias) (+ res);  x_out = x;  y = LN(x) * w + b.
+ * In a decoder layer both products that end in a residual feed a LayerNorm (vt_attention.py:121,138), so the split-K
+ * reduction rides on a launch that exists anyway.  One wave per row, d % 4 == 0, d <= 1024, splits summed in order. */
+int lvt_gemm_smallm_partial_f32(int M, int N, int K, int splits, const float *A, long long lda, const float *B,
+                                long long ldb, void *workspace, size_t workspace_bytes, void *stream);
+int lvt_splitsum_layernorm_fwd(const float *partials, int splits, int rows, int d, const float *bias, const float *res,
+                               long long ldr, float *x_out, float eps, const float *w, const float *b, float *y,
+                               void *stream);
 
 /* ---- 3-D convolution family, channels-last  (torch conv2d / conv3d / conv_transpose2d: K1-K6,K16) --
  * Geometry of the *forward* convolution  y[n,to,ho,wo,co] = sum x[n,to*st-pt+kt, ...,ci] w[co,ci,kt,kh,kw].

@@ -17,7 +17,7 @@ struct SmallParams {
     const float *A; long long lda;
     const float *B; long long ldb;
     float *C; long long ldc;
-    long long sB, sC;                 // per-batch (blockIdx.y) offsets of B and C (A is shared)
+    long long sA, sB, sC;             // per-batch (blockIdx.y) offsets of A (0: shared), B and C
     float alpha; int flags;
     const float *bias; const float *res; long long ldr;
 };
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64 * SMM_WAVES) void lvt_gemm_smallm_mfma_kernel(co
     const int l31 = lane & 31, half = lane >> 5;
     const int n0 = blockIdx.x * 32, z = blockIdx.y;
     const float *B = p.B + z * p.sB;
+    const float *A = p.A + z * p.sA;
     const int nchunks = (p.K + SMM_KC - 1) / SMM_KC;
     constexpr int RP = 64 * SMM_WAVES / 32;                       // rows covered per pass of the workgroup
     const int q4 = (tid & 31) * 4, r0 = tid >> 5;                 // this thread's float4 column and first row
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64 * SMM_WAVES) void lvt_gemm_smallm_mfma_kernel(co
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int m = r0 + RP * i;
-            ra[i] = (m < p.M && k < p.K) ? *reinterpret_cast<const float4 *>(p.A + (long long)m * p.lda + k)
+            ra[i] = (m < p.M && k < p.K) ? *reinterpret_cast<const float4 *>(A + (long long)m * p.lda + k)
                                          : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -236,7 +237,7 @@ extern "C" int lvt_gemm_smallm_f32(int M, int N, int K, int tb, const float *A, 
     LVT_REQUIRE(!(flags & LVT_EPI_RESIDUAL) || res, "gemm_smallm: RESIDUAL without res");
     SmallParams p;
     p.M = M; p.N = N; p.K = K; p.tb = tb; p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
-    p.sB = sB; p.sC = sC; p.alpha = alpha; p.flags = flags; p.bias = bias; p.res = res; p.ldr = ldr;
+    p.sA = 0; p.sB = sB; p.sC = sC; p.alpha = alpha; p.flags = flags; p.bias = bias; p.res = res; p.ldr = ldr;
     if (tb == 0 && K % 8 == 0) {
         dim3 grid((unsigned)lvt_cdiv(N, 32), (unsigned)batch);
         if (M <= 32) hipLaunchKernelGGL(lvt_gemm_smallm_mfma_kernel<1>, grid, dim3(64 * SMM_WAVES), 0, (hipStream_t)stream, p);
@@ -248,5 +249,168 @@ extern "C" int lvt_gemm_smallm_f32(int M, int N, int K, int tb, const float *A, 
     if (tb == 0) hipLaunchKernelGGL(lvt_gemm_smallm_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(lvt_gemm_smallm_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
     LVT_CHECK_LAUNCH("lvt_gemm_smallm_kernel");
+    return LVT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split-K form for long reductions.  One workgroup per 32 output columns walks K in 128-deep chunks at ~1.3 us per
+// chunk (a memory round trip; the arithmetic of a chunk is a quarter of that), and a 64 x 512 x 2048 product has only
+// 16 such workgroups: 23 us with 240 CUs idle.  Here the k range is cut into `splits` equal parts that run as the
+// batch dimension of the same kernel (raw partial tiles into the workspace), and a second launch adds the parts in
+// split order and applies the epilogue -- deterministic, ~8 us for the same product.
+// ------------------------------------------------------------------------------------------------
+__global__ void lvt_smallm_reduce_kernel(const float *__restrict__ ws, int splits, int M, int N, float *__restrict__ C,
+                                         long long ldc, float alpha, int flags, const float *__restrict__ bias,
+                                         const float *__restrict__ res, long long ldr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // float4 index over M x N
+    const int n4 = N / 4;
+    if (i >= M * n4) return;
+    const int m = i / n4, c = (i - m * n4) * 4;
+    const long long plane = (long long)M * N;
+    float4 t[8];
+    float4 s = *reinterpret_cast<const float4 *>(ws + (long long)m * N + c);
+    for (int k0 = 1; k0 < splits; k0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            t[u] = (k0 + u < splits) ? *reinterpret_cast<const float4 *>(ws + (k0 + u) * plane + (long long)m * N + c)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += t[u].x; s.y += t[u].y; s.z += t[u].z; s.w += t[u].w; }
+    }
+    float v[4] = {s.x * alpha, s.y * alpha, s.z * alpha, s.w * alpha};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (flags & LVT_EPI_BIAS) v[j] += bias[c + j];
+        if (flags & LVT_EPI_RESIDUAL) v[j] += res[(long long)m * ldr + c + j];
+        if (flags & LVT_EPI_RELU) v[j] = fmaxf(v[j], 0.f);
+        C[(long long)m * ldc + c + j] = v[j];
+    }
+}
+
+extern "C" size_t lvt_gemm_smallm_splitk_workspace_bytes(int M, int N, int splits) {
+    return (size_t)(splits > 1 ? splits : 1) * M * N * sizeof(float);
+}
+
+static int smallm_partial(int M, int N, int K, int splits, const float *A, long long lda, const float *B,
+                          long long ldb, void *workspace, size_t workspace_bytes, hipStream_t s, const char *who) {
+    LVT_REQUIRE(A && B && M > 0 && M <= 64 && N > 0 && K > 0, "%s: bad shape (M=%d)", who, M);
+    LVT_REQUIRE(splits >= 2 && K % splits == 0 && (K / splits) % 8 == 0, "%s: K=%d is not %d ranges of a multiple of 8", who, K, splits);
+    LVT_REQUIRE(N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && lvt_aligned16(A) && lvt_aligned16(B), "%s: alignment", who);
+    if (!workspace || workspace_bytes < lvt_gemm_smallm_splitk_workspace_bytes(M, N, splits) || !lvt_aligned16(workspace)) {
+        lvt_set_error("%s: workspace too small or misaligned", who);
+        return LVT_EWORKSPACE;
+    }
+    const int Kc = K / splits;
+    SmallParams p;
+    p.M = M; p.N = N; p.K = Kc; p.tb = 0; p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;
+    p.C = (float *)workspace; p.ldc = N; p.sA = Kc; p.sB = Kc; p.sC = (long long)M * N;
+    p.alpha = 1.f; p.flags = 0; p.bias = nullptr; p.res = nullptr; p.ldr = 0;
+    dim3 grid((unsigned)lvt_cdiv(N, 32), (unsigned)splits);
+    if (M <= 32) hipLaunchKernelGGL(lvt_gemm_smallm_mfma_kernel<1>, grid, dim3(64 * SMM_WAVES), 0, s, p);
+    else hipLaunchKernelGGL(lvt_gemm_smallm_mfma_kernel<2>, grid, dim3(64 * SMM_WAVES), 0, s, p);
+    LVT_CHECK_LAUNCH("lvt_gemm_smallm_mfma_kernel");
+    return LVT_OK;
+}
+
+extern "C" int lvt_gemm_smallm_splitk_f32(int M, int N, int K, int splits, const float *A, long long lda, const float *B,
+                                          long long ldb, float *C, long long ldc, float alpha, int flags,
+                                          const float *bias, const float *res, long long ldr, void *workspace,
+                                          size_t workspace_bytes, void *stream) {
+    LVT_REQUIRE(C, "gemm_smallm_splitk: null output");
+    LVT_REQUIRE(!(flags & ~(LVT_EPI_BIAS | LVT_EPI_RESIDUAL | LVT_EPI_RELU)), "gemm_smallm_splitk: unsupported flag");
+    LVT_REQUIRE(!(flags & LVT_EPI_BIAS) || bias, "gemm_smallm_splitk: BIAS without bias");
+    LVT_REQUIRE(!(flags & LVT_EPI_RESIDUAL) || res, "gemm_smallm_splitk: RESIDUAL without res");
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = smallm_partial(M, N, K, splits, A, lda, B, ldb, workspace, workspace_bytes, s, "gemm_smallm_splitk");
+    if (rc) return rc;
+    const int total4 = M * (N / 4);
+    hipLaunchKernelGGL(lvt_smallm_reduce_kernel, dim3((unsigned)lvt_cdiv(total4, 256)), dim3(256), 0, s,
+                       (const float *)workspace, splits, M, N, C, ldc, alpha, flags, bias, res, ldr);
+    LVT_CHECK_LAUNCH("lvt_smallm_reduce_kernel");
+    return LVT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Partial products only + the reduction folded into the LayerNorm that consumes them.  In a decoder layer both
+// k = 512..1024 products that end in a residual (attention output projection, FFN down-projection) feed a LayerNorm:
+//     x = sum_s partial[s] (+ bias) (+ res);   y = LN(x) * w + b
+// so the split-K reduction costs no launch of its own, and the products run as 4 x 16 workgroups of one 128-deep
+// chunk each instead of 16 workgroups walking four chunks.  One wave per row; the split order is fixed.
+// ------------------------------------------------------------------------------------------------
+extern "C" int lvt_gemm_smallm_partial_f32(int M, int N, int K, int splits, const float *A, long long lda, const float *B,
+                                           long long ldb, void *workspace, size_t workspace_bytes, void *stream) {
+    return smallm_partial(M, N, K, splits, A, lda, B, ldb, workspace, workspace_bytes, (hipStream_t)stream,
+                          "gemm_smallm_partial");
+}
+
+#define SLN_MAXV 4          // float4 per lane -> d <= 1024
+__global__ __launch_bounds__(256) void lvt_splitsum_layernorm_kernel(const float *__restrict__ ws, int splits, int rows,
+                                                                    int d, const float *__restrict__ bias,
+                                                                    const float *__restrict__ res, long long ldr,
+                                                                    float *__restrict__ x_out, float eps,
+                                                                    const float *__restrict__ w, const float *__restrict__ b,
+                                                                    float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= rows) return;
+    const int d4 = d / 4;
+    const long long plane = (long long)rows * d;
+    float4 v[SLN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < SLN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < d4) {
+            const float *src = ws + (long long)row * d + c * 4;
+            float4 a = *reinterpret_cast<const float4 *>(src);
+            for (int k = 1; k < splits; ++k) {
+                const float4 t = *reinterpret_cast<const float4 *>(src + k * plane);
+                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            }
+            if (bias) { const float4 t = reinterpret_cast<const float4 *>(bias)[c]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+            if (res) { const float4 t = *reinterpret_cast<const float4 *>(res + (long long)row * ldr + c * 4); a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+            v[i] = a;
+            reinterpret_cast<float4 *>(x_out + (long long)row * d)[c] = a;
+            s += (a.x + a.y) + (a.z + a.w);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < SLN_MAXV; ++i) {
+        if (lane + 64 * i < d4) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q / d + eps);
+#pragma unroll
+    for (int i = 0; i < SLN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < d4) {
+            const float4 ww = reinterpret_cast<const float4 *>(w)[c], bb = reinterpret_cast<const float4 *>(b)[c];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * ww.x + bb.x; o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
+            o.z = (v[i].z - mean) * rstd * ww.z + bb.z; o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
+            reinterpret_cast<float4 *>(y + (long long)row * d)[c] = o;
+        }
+    }
+}
+
+extern "C" int lvt_splitsum_layernorm_fwd(const float *partials, int splits, int rows, int d, const float *bias,
+                                          const float *res, long long ldr, float *x_out, float eps, const float *w,
+                                          const float *b, float *y, void *stream) {
+    LVT_REQUIRE(partials && x_out && w && b && y && splits >= 1 && rows > 0, "splitsum_layernorm: bad args");
+    LVT_REQUIRE(d % 4 == 0 && d <= 256 * SLN_MAXV && (!res || ldr % 4 == 0), "splitsum_layernorm: d=%d must be a multiple of 4, <= 1024", d);
+    LVT_REQUIRE(lvt_aligned16(partials) && lvt_aligned16(x_out) && lvt_aligned16(y) && lvt_aligned16(w) && lvt_aligned16(b) &&
+                (!bias || lvt_aligned16(bias)) && (!res || lvt_aligned16(res)), "splitsum_layernorm: 16-byte alignment");
+    hipLaunchKernelGGL(lvt_splitsum_layernorm_kernel, dim3((unsigned)lvt_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       partials, splits, rows, d, bias, res, ldr, x_out, eps, w, b, y);
+    LVT_CHECK_LAUNCH("lvt_splitsum_layernorm_kernel");
     return LVT_OK;
 }

@@ -64,6 +64,10 @@ def _declare(lib):
         "lvt_gemm_workspace_bytes": (sz, [P(GemmDesc)]),
         "lvt_gemm_f32": (ci, [P(GemmDesc), vp, sz, vp]),
         "lvt_gemm_smallm_f32": (ci, [ci, ci, ci, ci, vp, cll, vp, cll, vp, cll, ci, cll, cll, cf, ci, vp, vp, cll, vp]),
+        "lvt_gemm_smallm_splitk_workspace_bytes": (sz, [ci, ci, ci]),
+        "lvt_gemm_smallm_splitk_f32": (ci, [ci, ci, ci, ci, vp, cll, vp, cll, vp, cll, cf, ci, vp, vp, cll, vp, sz, vp]),
+        "lvt_gemm_smallm_partial_f32": (ci, [ci, ci, ci, ci, vp, cll, vp, cll, vp, sz, vp]),
+        "lvt_splitsum_layernorm_fwd": (ci, [vp, ci, ci, ci, vp, vp, cll, vp, cf, vp, vp, vp, vp]),
         "lvt_conv3d_pack_weight": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
         "lvt_conv3d_fwd": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
         "lvt_conv3d_bwd_data": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),

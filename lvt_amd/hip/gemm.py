@@ -40,6 +40,14 @@ def gemm(A, B, C_out, M, N, K, ta=0, tb=0, lda=None, ldb=None, ldc=None, a_kb=0,
     return C_out
 
 
+def _smallm_splits(N, K):
+    """k ranges of 256 for reductions of 1024 and more (one workgroup per 32 columns walks k at ~1.3 us per 128: a
+    64 x 512 x 2048 product takes 23 us on 16 CUs unsplit, ~8 us as 8 x 16 workgroups plus the reduction launch)."""
+    if K < 1024 or K % 256 != 0:
+        return 1
+    return K // 256
+
+
 def gemm_small(A, B, C_out, M, N, K, tb=0, lda=None, ldb=None, ldc=None, batch=1, sB=0, sC=0, alpha=1.0, flags=0,
                bias=None, res=None, ldr=0):
     """C = epi(alpha * A @ B) for M <= 64 rows (incremental decoding); see lvt_gemm_smallm_f32."""
@@ -47,12 +55,46 @@ def gemm_small(A, B, C_out, M, N, K, tb=0, lda=None, ldb=None, ldc=None, batch=1
     if M > 64:
         return gemm(A, B, C_out, M, N, K, ta=0, tb=tb, lda=lda, ldb=ldb, ldc=ldc, batch_inner=batch, sB=(0, sB),
                     sC=(0, sC), alpha=alpha, flags=flags, bias=bias, res=res, ldr=ldr)
+    splits = _smallm_splits(N, K) if (tb == 0 and batch == 1 and N % 4 == 0) else 1
+    if splits > 1:
+        lib = L.lib()
+        nws = lib.lvt_gemm_smallm_splitk_workspace_bytes(M, N, splits)
+        ws = L.workspace(nws, A.device, "smallm")
+        L.check(lib.lvt_gemm_smallm_splitk_f32(M, N, K, splits, L.ptr(A), lda if lda is not None else K, L.ptr(B),
+                                               ldb if ldb is not None else K, L.ptr(C_out), ldc if ldc is not None else N,
+                                               alpha, flags, L.ptr(bias), L.ptr(res),
+                                               ldr if ldr else (ldc if ldc is not None else N), L.ptr(ws), nws,
+                                               L.stream_ptr()), "lvt_gemm_smallm_splitk_f32")
+        return C_out
     L.check(L.lib().lvt_gemm_smallm_f32(M, N, K, tb, L.ptr(A), lda if lda is not None else K, L.ptr(B),
                                         ldb if ldb is not None else (K if tb == 0 else N), L.ptr(C_out),
                                         ldc if ldc is not None else N, batch, sB, sC, alpha, flags, L.ptr(bias),
                                         L.ptr(res), ldr if ldr else (ldc if ldc is not None else N), L.stream_ptr()),
             "lvt_gemm_smallm_f32")
     return C_out
+
+
+def gemm_small_partial(A, B, M, N, K, splits, ws):
+    """Raw split-K partial tiles (splits, M, N) of A @ B^T for M <= 64 into the caller's buffer `ws` (float32,
+    >= splits*M*N elements); the consumer (`splitsum_layernorm`) reduces them."""
+    L.require(A, B, ws)
+    lib = L.lib()
+    nws = lib.lvt_gemm_smallm_splitk_workspace_bytes(M, N, splits)
+    if ws.numel() * ws.element_size() < nws:
+        raise L.LvtError("gemm_small_partial: buffer of %d bytes, need %d" % (ws.numel() * ws.element_size(), nws))
+    L.check(lib.lvt_gemm_smallm_partial_f32(M, N, K, splits, L.ptr(A), K, L.ptr(B), K, L.ptr(ws), nws, L.stream_ptr()),
+            "lvt_gemm_smallm_partial_f32")
+    return ws
+
+
+def splitsum_layernorm(partials, splits, rows, d, w, b, bias=None, res=None, eps=1e-5):
+    """x = sum of the partial tiles (+ bias) (+ res); returns (x, LayerNorm(x) * w + b) from one launch."""
+    L.require(partials, w, b, bias, res)
+    x = torch.empty(rows, d, dtype=torch.float32, device=w.device)
+    y = torch.empty(rows, d, dtype=torch.float32, device=w.device)
+    L.check(L.lib().lvt_splitsum_layernorm_fwd(L.ptr(partials), splits, rows, d, L.ptr(bias), L.ptr(res), d, L.ptr(x), eps,
+                                               L.ptr(w), L.ptr(b), L.ptr(y), L.stream_ptr()), "lvt_splitsum_layernorm_fwd")
+    return x, y
 
 
 def conv_geom(N, Ti, Hi, Wi, Ci, Co, kernel, stride, pad, out=None):

@@ -61,6 +61,10 @@ class IncrementalDecoder:
         # the layout the matrix-core small-M GEMM streams; refreshed at every begin_slice (weights may have been
         # trained in between), in place so that captured graphs keep reading the same buffers
         self.wqkv = [torch.empty(3, hd, d, dtype=torch.float32, device=dev) for _ in self.layers]
+        # split-K partial tiles of the two residual products of a layer (see step): sized here, outside any capture
+        self._pbuf = {}
+        self._partials("proj", max(2, hd // 128))
+        self._partials("ffn", max(2, self.layers[0].ffn[1].weight.shape[0] // 128))
         self.begin_slice(zl_tok)
 
     def _refresh_weights(self):
@@ -96,6 +100,14 @@ class IncrementalDecoder:
                      bias=self.dec.conv.conv.bias, res=self.base.view(-1)[i * self.d:], ldr=self.S * self.d)
         return x
 
+    def _partials(self, which, splits):
+        """Split-K partial buffers of the decode step: ordinary tensors owned by this object (sized in __init__), so
+        captured launches keep pointing at live memory."""
+        buf = self._pbuf.get(which)
+        if buf is None or buf.numel() < splits * self.b * self.d:
+            buf = self._pbuf[which] = torch.empty(splits * self.b * self.d, dtype=torch.float32, device=self.base.device)
+        return buf
+
     def step(self, sl, i):
         """Hidden state y_i (b, d) of token i given the codes of tokens < i in `sl`; fills the caches at i."""
         b, d, S = self.b, self.d, self.S
@@ -105,22 +117,41 @@ class IncrementalDecoder:
             self.sl.copy_(sl)
         x = self._front_row(i)
         dev = x.device
+        # Both products of a layer that end in a residual (output projection, FFN down-projection) are followed by a
+        # LayerNorm: they run split-K (one 128-deep chunk per workgroup, 4x the workgroups) and leave raw partial
+        # tiles; the LayerNorm launch sums them, adds bias / residual and normalises (`pend`: partials not reduced yet).
+        KS = 128
+        nlayers = len(self.layers)
+        pend = None
         for li, layer in enumerate(self.layers):
             m, f = layer.mha, layer.ffn
-            xn, _, _ = ew.layernorm_fwd(x, m.layer_norm.weight, m.layer_norm.bias, save_stats=False)
+            if pend is None:
+                xn, _, _ = ew.layernorm_fwd(x, m.layer_norm.weight, m.layer_norm.bias, save_stats=False)
+            else:
+                x, xn = G.splitsum_layernorm(pend[0], pend[1], b, d, m.layer_norm.weight, m.layer_norm.bias,
+                                             bias=pend[2], res=pend[3])
             # q_i / k_i / v_i of every sample in one launch: output row i of slot z, row stride S*hd, slot stride b*S*hd
             qkv = self.qkv[li]
             G.gemm_small(xn, self.wqkv[li], qkv.view(-1)[i * hd:], b, hd, d, ldc=S * hd, batch=3, sB=hd * d, sC=b * S * hd)
             o = tx.attn_decode(qkv.view(-1)[i * hd:], self.kc[li], self.vc[li], na, i, math.sqrt(da), layer.dt_bank,
                                layer.dh_bank, layer.dw_bank, layer.block_size, ldq=S * hd)
-            y1 = torch.empty(b, d, dtype=torch.float32, device=dev)
-            G.gemm_small(o, m.proj.weight, y1, b, d, hd, flags=L.EPI_RESIDUAL, res=x)
-            fn, _, _ = ew.layernorm_fwd(y1, f[0].weight, f[0].bias, save_stats=False)
-            h1 = torch.empty(b, f[1].weight.shape[0], dtype=torch.float32, device=dev)
-            G.gemm_small(fn, f[1].weight, h1, b, f[1].weight.shape[0], d, flags=L.EPI_BIAS | L.EPI_RELU, bias=f[1].bias)
-            x = torch.empty(b, d, dtype=torch.float32, device=dev)
-            G.gemm_small(h1, f[3].weight, x, b, d, f[3].weight.shape[1], flags=L.EPI_BIAS | L.EPI_RESIDUAL,
-                         bias=f[3].bias, res=y1)
+            if hd % KS == 0 and d % 4 == 0:
+                ws = G.gemm_small_partial(o, m.proj.weight, b, d, hd, hd // KS, self._partials("proj", hd // KS))
+                y1, fn = G.splitsum_layernorm(ws, hd // KS, b, d, f[0].weight, f[0].bias, res=x)
+            else:
+                y1 = torch.empty(b, d, dtype=torch.float32, device=dev)
+                G.gemm_small(o, m.proj.weight, y1, b, d, hd, flags=L.EPI_RESIDUAL, res=x)
+                fn, _, _ = ew.layernorm_fwd(y1, f[0].weight, f[0].bias, save_stats=False)
+            dff = f[1].weight.shape[0]
+            h1 = torch.empty(b, dff, dtype=torch.float32, device=dev)
+            G.gemm_small(fn, f[1].weight, h1, b, dff, d, flags=L.EPI_BIAS | L.EPI_RELU, bias=f[1].bias)
+            if li + 1 < nlayers and dff % KS == 0 and dff // KS >= 2 and d % 4 == 0:
+                ws = G.gemm_small_partial(h1, f[3].weight, b, d, dff, dff // KS, self._partials("ffn", dff // KS))
+                pend = (ws, dff // KS, f[3].bias, y1)
+            else:
+                pend = None
+                x = torch.empty(b, d, dtype=torch.float32, device=dev)
+                G.gemm_small(h1, f[3].weight, x, b, d, dff, flags=L.EPI_BIAS | L.EPI_RESIDUAL, bias=f[3].bias, res=y1)
         return x
 
 

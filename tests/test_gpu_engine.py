@@ -249,7 +249,7 @@ def test_math_modes_accuracy(math_mode):
 
 
 @pytest.mark.parametrize("M,N,K,tb", [(64, 512, 512, 0), (3, 512, 1024, 0), (33, 100, 136, 0), (64, 2048, 512, 0),
-                                      (16, 128, 512, 1), (64, 512, 2560, 0)])
+                                      (16, 128, 512, 1), (64, 512, 2560, 0), (64, 512, 2048, 0), (40, 1024, 1536, 0)])
 def test_gemm_small_m(M, N, K, tb):
     """Decode-time GEMM (M <= 64): matrix-core kernel for k-contiguous weights, FMA kernel for n-contiguous ones;
     bias + residual + ReLU epilogue; ragged M / N / K tails."""
@@ -262,6 +262,28 @@ def test_gemm_small_m(M, N, K, tb):
     G.gemm_small(a.to(d), w.to(d), out, M, N, K, tb=tb, alpha=0.5, flags=L.EPI_BIAS | L.EPI_RESIDUAL | L.EPI_RELU,
                  bias=b.to(d), res=r.to(d))
     assert rel_err(out, ref) < TOL
+
+
+@pytest.mark.parametrize("M,N,K,splits,with_bias", [(64, 512, 1024, 8, False), (64, 512, 512, 4, True), (5, 256, 256, 2, True)])
+def test_gemm_small_partial_and_splitsum_layernorm(M, N, K, splits, with_bias):
+    """Decode-step pair: raw split-K partial tiles, then ONE launch that sums them, adds bias / residual and applies
+    LayerNorm (the reduction of the attention-output and FFN-down products rides on the LayerNorm that follows)."""
+    from lvt_amd.hip import gemm as G
+    a, w, r = _rand(M, K), _rand(N, K, seed=1), _rand(M, N, seed=3)
+    bias = _rand(N, seed=4) if with_bias else None
+    g, b = _rand(N, seed=5), _rand(N, seed=6)
+    x_ref = a.double() @ w.double().t() + r.double() + (bias.double() if with_bias else 0.0)
+    y_ref = F.layer_norm(x_ref, (N,), g.double(), b.double(), 1e-5)
+    d = _dev()
+    ws = torch.full((splits * M * N,), float("nan"), device=d)
+    G.gemm_small_partial(a.to(d), w.to(d), M, N, K, splits, ws)
+    x, y = G.splitsum_layernorm(ws, splits, M, N, g.to(d), b.to(d), bias=bias.to(d) if with_bias else None, res=r.to(d))
+    assert rel_err(x, x_ref.float()) < TOL
+    assert rel_err(y, y_ref.float()) < 5e-5
+    # the partial tiles really are the k ranges, in order
+    part = ws.view(splits, M, N)[1].cpu()
+    kc = K // splits
+    assert rel_err(part, (a[:, kc:2 * kc].double() @ w[:, kc:2 * kc].double().t()).float()) < TOL
 
 
 def test_gemm_tn_splitk_with_a_colsum():
