@@ -40,6 +40,10 @@ class _XentFn(torch.autograd.Function):
             None, None, None, None
 
 
+# groups of a large sampling batch run on their own streams (False: one after the other on the caller's stream;
+# the results are identical -- tests/test_gpu_sampling.py)
+DECODE_GROUP_STREAMS = True
+
 @META_ARCH_REGISTRY.register()
 class VideoTransformerModel(nn.Module):
     def __init__(self, cfg):
@@ -171,12 +175,21 @@ class VideoTransformerModel(nn.Module):
         # block, e.g. DSSVT at 16 frames) fall back to the reference schedule
         if any(tuple(l.block_size) != (t, h, w) for l in self.model.decoder.block_local_attention):
             incremental = False
+        groups = None
         if incremental:
+            # A decode step is ~90 dependent launches of 16-512 workgroups each: latency bound, most CUs idle.  Batches
+            # larger than the 64 rows of the small-M kernels are therefore decoded as independent groups of <= 64
+            # videos on separate streams (own K/V caches and graphs), whose steps interleave on the GPU.
+            ng = (B + 63) // 64
+            bounds = [B * g // ng for g in range(ng + 1)]
             key = (B, t, h, w, float(temp))
-            sampler = self._samplers.get(key) if hasattr(self, "_samplers") else None
-            if sampler is None:
-                sampler = GraphedSliceSampler(self.model, B, (t, h, w), temp)
-                self._samplers = {key: sampler}           # keep the most recent geometry's graphs
+            groups = self._samplers.get(key) if hasattr(self, "_samplers") else None
+            if groups is None:
+                groups = [(bounds[g], bounds[g + 1], GraphedSliceSampler(self.model, bounds[g + 1] - bounds[g], (t, h, w), temp),
+                           (torch.cuda.Stream(device=video.device) if DECODE_GROUP_STREAMS else
+                            torch.cuda.current_stream(video.device)) if ng > 1 else None) for g in range(ng)]
+                self._samplers = {key: groups}            # keep the most recent geometry's graphs
+            sampler = groups[0][2]
         for si, (a, b_, c) in enumerate(idx2abc):
             sl, ctx = slice_and_context(video, a, b_, c, v.STRIDE, v.KERNEL, v.PAD_VALUE)
             prime_sl = prime[a::st, b_::sh, c::sw]
@@ -185,11 +198,32 @@ class VideoTransformerModel(nn.Module):
             sidx = torch.full((B,), si, dtype=torch.long, device=video.device)
             zl = self.model.encoder.forward_tokens(ctx.contiguous(), sidx, class_idx)   # context is fixed per slice
             if sampler is not None:
-                sampler.begin_slice(zl, sl)
                 flat = prime_sl.reshape(-1).tolist()
-                for pos in range(t * h * w):
-                    sampler.step(pos, sample=not flat[pos])     # primed pixels only fill the K/V caches
-                sl = sampler.sl.clone()
+                S = t * h * w
+                if len(groups) == 1:
+                    sampler.begin_slice(zl, sl)
+                    for pos in range(S):
+                        sampler.step(pos, sample=not flat[pos])     # primed pixels only fill the K/V caches
+                    sl = sampler.sl.clone()
+                else:
+                    main = torch.cuda.current_stream(video.device)
+                    zl3 = zl.view(B, S, -1)
+                    for g0, g1, smp, stream in groups:
+                        stream.wait_stream(main)
+                        with torch.cuda.stream(stream):
+                            smp.begin_slice(zl3[g0:g1].reshape((g1 - g0) * S, -1), sl[g0:g1])
+                    for _, _, _, stream in groups:              # every group starts after ALL slice set-ups (shared tables)
+                        for _, _, _, other in groups:
+                            if other is not stream:
+                                stream.wait_stream(other)
+                    for pos in range(S):
+                        for g0, g1, smp, stream in groups:
+                            with torch.cuda.stream(stream):
+                                smp.step(pos, sample=not flat[pos])
+                    for g0, g1, smp, stream in groups:
+                        with torch.cuda.stream(stream):
+                            sl[g0:g1] = smp.sl
+                        main.wait_stream(stream)
             else:
                 for ti in range(t):
                     for hi in range(h):
