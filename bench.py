@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--no-dsfvt", action="store_true", help="skip the secondary DSFVT train-step figure")
     ap.add_argument("--dsfvt-batch", type=int, default=64)
     ap.add_argument("--no-generate", action="store_true", help="skip the secondary generation figure")
-    ap.add_argument("--generate-batch", type=int, default=128, help="videos generated at once (decoded as groups of <= 64 on separate streams)")
+    ap.add_argument("--generate-batch", type=int, default=192, help="videos generated at once (decoded as groups of <= 64 on separate streams)")
     ap.add_argument("--no-strict-f32", action="store_true", help="skip the secondary LVT_MATH=f32 figure")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
