@@ -107,6 +107,17 @@ def test_large_batches_decode_as_stream_groups(vt):
         vt._samplers = {}
     print("serial vs concurrent groups: %d codes differ" % int((serial != both).sum()))
     assert torch.equal(serial, both)
+    # waves (more groups than may run concurrently): one group per wave here; the uniforms are consumed in another
+    # order, so only arg-max near-ties may differ
+    vtmod.MAX_CONCURRENT_GROUPS = 1
+    try:
+        vt._samplers = {}
+        with torch.no_grad():
+            waves = vt.sample_video(video, n_prime=15, temp=1e-4)
+    finally:
+        vtmod.MAX_CONCURRENT_GROUPS = 3
+        vt._samplers = {}
+    assert float((waves != both)[:, :, 15:].float().mean()) < 0.01
     # the encoder pass over 70 vs 35 videos may pick another split-K count (last-bit differences in the context), so
     # arg-max near-ties of this random-init model can flip; anything beyond that would be a race between the groups
     mism = float((torch.cat([lo, hi]) != both)[:, :, 15:].float().mean())
