@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--no-dsfvt", action="store_true", help="skip the secondary DSFVT train-step figure")
     ap.add_argument("--dsfvt-batch", type=int, default=64)
     ap.add_argument("--no-generate", action="store_true", help="skip the secondary generation figure")
-    ap.add_argument("--generate-batch", type=int, default=192, help="videos generated at once (decoded as groups of <= 64 on separate streams)")
+    ap.add_argument("--generate-batch", type=int, default=768, help="videos generated at once (decoded as groups of <= 256 on separate streams)")
     ap.add_argument("--no-strict-f32", action="store_true", help="skip the secondary LVT_MATH=f32 figure")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
@@ -226,7 +226,7 @@ def bench_generate(device, batch):
     return {"frames_per_s": round(16 * batch / dt, 2), "videos_per_s": round(batch / dt, 3), "batch_videos": batch,
             "seconds": round(dt, 3), "decoder_steps": 11 * 256,
             "note": "5 priming + 11 generated frames per video; random-init weights; sampling is sequential "
-                    "(2816 single-token decoder steps per group of <= 64 videos; the groups of a batch run on separate "
+                    "(2816 single-token decoder steps per group of <= 256 videos; the groups of a batch run on separate "
                     "streams), videos are replicas across GPUs"}
 
 

@@ -81,8 +81,9 @@ typedef struct {
 size_t lvt_gemm_workspace_bytes(const lvt_gemm_desc *d);
 int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Small-M variant (M <= 64 rows, e.g. one token per sample in incremental decoding): same addressing as
- * lvt_gemm_f32 with ta == 0, a single batch level (A shared, B += z*sB, C += z*sC), flags BIAS|RESIDUAL|RELU. */
+/* Small-M variant (a few rows, e.g. one token per sample in incremental decoding): same addressing as
+ * lvt_gemm_f32 with ta == 0, a single batch level (A shared, B += z*sB, C += z*sC), flags BIAS|RESIDUAL|RELU.
+ * One workgroup per 64 rows x 32 columns; M > 64 needs the k-contiguous layout (tb == 0, K % 8 == 0).        */
 int lvt_gemm_smallm_f32(int M, int N, int K, int tb, const float *A, long long lda, const float *B,
                         long long ldb, float *C, long long ldc, int batch, long long sB, long long sC,
                         float alpha, int flags, const float *bias, const float *res, long long ldr,

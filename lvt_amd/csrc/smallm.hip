@@ -132,6 +132,7 @@ __global__ __launch_bounds__(64 * SMM_WAVES) void lvt_gemm_smallm_mfma_kernel(co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int n0 = blockIdx.x * 32, z = blockIdx.y;
+    const int mb = blockIdx.z * AR;                               // row block (M > 64: one workgroup per 64 rows and tile)
     const float *B = p.B + z * p.sB;
     const float *A = p.A + z * p.sA;
     const int nchunks = (p.K + SMM_KC - 1) / SMM_KC;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64 * SMM_WAVES) void lvt_gemm_smallm_mfma_kernel(co
         const int k = c * SMM_KC + q4;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int m = r0 + RP * i;
+            const int m = mb + r0 + RP * i;
             ra[i] = (m < p.M && k < p.K) ? *reinterpret_cast<const float4 *>(A + (long long)m * p.lda + k)
                                          : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(64 * SMM_WAVES) void lvt_gemm_smallm_mfma_kernel(co
 #pragma unroll
         for (int rr = 0; rr < 16 / SMM_WAVES; ++rr) {
             const int r = (16 / SMM_WAVES) * wave + rr;
-            const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int m = mb + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (m >= p.M) continue;
             float v = red[0][t][r][lane];
 #pragma unroll
@@ -229,7 +230,8 @@ extern "C" int lvt_gemm_smallm_f32(int M, int N, int K, int tb, const float *A, 
                                    long long ldb, float *C, long long ldc, int batch, long long sB, long long sC,
                                    float alpha, int flags, const float *bias, const float *res, long long ldr,
                                    void *stream) {
-    LVT_REQUIRE(A && B && C && M > 0 && M <= 64 && N > 0 && K > 0 && batch > 0, "gemm_smallm: bad shape (M=%d)", M);
+    LVT_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0, "gemm_smallm: bad shape (M=%d)", M);
+    LVT_REQUIRE(M <= 64 || (tb == 0 && K % 8 == 0), "gemm_smallm: M=%d > 64 needs the k-contiguous layout (tb == 0, K %% 8 == 0)", M);
     LVT_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && lvt_aligned16(A) && lvt_aligned16(B), "gemm_smallm: alignment");
     LVT_REQUIRE(tb == 0 || N % 4 == 0, "gemm_smallm: tb=1 needs N %% 4 == 0");
     LVT_REQUIRE(!(flags & ~(LVT_EPI_BIAS | LVT_EPI_RESIDUAL | LVT_EPI_RELU)), "gemm_smallm: unsupported flag");
@@ -239,7 +241,7 @@ extern "C" int lvt_gemm_smallm_f32(int M, int N, int K, int tb, const float *A, 
     p.M = M; p.N = N; p.K = K; p.tb = tb; p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
     p.sA = 0; p.sB = sB; p.sC = sC; p.alpha = alpha; p.flags = flags; p.bias = bias; p.res = res; p.ldr = ldr;
     if (tb == 0 && K % 8 == 0) {
-        dim3 grid((unsigned)lvt_cdiv(N, 32), (unsigned)batch);
+        dim3 grid((unsigned)lvt_cdiv(N, 32), (unsigned)batch, (unsigned)(M <= 32 ? 1 : lvt_cdiv(M, 64)));
         if (M <= 32) hipLaunchKernelGGL(lvt_gemm_smallm_mfma_kernel<1>, grid, dim3(64 * SMM_WAVES), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(lvt_gemm_smallm_mfma_kernel<2>, grid, dim3(64 * SMM_WAVES), 0, (hipStream_t)stream, p);
         LVT_CHECK_LAUNCH("lvt_gemm_smallm_mfma_kernel");
@@ -293,7 +295,7 @@ extern "C" size_t lvt_gemm_smallm_splitk_workspace_bytes(int M, int N, int split
 
 static int smallm_partial(int M, int N, int K, int splits, const float *A, long long lda, const float *B,
                           long long ldb, void *workspace, size_t workspace_bytes, hipStream_t s, const char *who) {
-    LVT_REQUIRE(A && B && M > 0 && M <= 64 && N > 0 && K > 0, "%s: bad shape (M=%d)", who, M);
+    LVT_REQUIRE(A && B && M > 0 && N > 0 && K > 0, "%s: bad shape (M=%d)", who, M);
     LVT_REQUIRE(splits >= 2 && K % splits == 0 && (K / splits) % 8 == 0, "%s: K=%d is not %d ranges of a multiple of 8", who, K, splits);
     LVT_REQUIRE(N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && lvt_aligned16(A) && lvt_aligned16(B), "%s: alignment", who);
     if (!workspace || workspace_bytes < lvt_gemm_smallm_splitk_workspace_bytes(M, N, splits) || !lvt_aligned16(workspace)) {
@@ -305,7 +307,7 @@ static int smallm_partial(int M, int N, int K, int splits, const float *A, long 
     p.M = M; p.N = N; p.K = Kc; p.tb = 0; p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;
     p.C = (float *)workspace; p.ldc = N; p.sA = Kc; p.sB = Kc; p.sC = (long long)M * N;
     p.alpha = 1.f; p.flags = 0; p.bias = nullptr; p.res = nullptr; p.ldr = 0;
-    dim3 grid((unsigned)lvt_cdiv(N, 32), (unsigned)splits);
+    dim3 grid((unsigned)lvt_cdiv(N, 32), (unsigned)splits, (unsigned)(M <= 32 ? 1 : lvt_cdiv(M, 64)));
     if (M <= 32) hipLaunchKernelGGL(lvt_gemm_smallm_mfma_kernel<1>, grid, dim3(64 * SMM_WAVES), 0, s, p);
     else hipLaunchKernelGGL(lvt_gemm_smallm_mfma_kernel<2>, grid, dim3(64 * SMM_WAVES), 0, s, p);
     LVT_CHECK_LAUNCH("lvt_gemm_smallm_mfma_kernel");

@@ -50,9 +50,11 @@ def _smallm_splits(N, K):
 
 def gemm_small(A, B, C_out, M, N, K, tb=0, lda=None, ldb=None, ldc=None, batch=1, sB=0, sC=0, alpha=1.0, flags=0,
                bias=None, res=None, ldr=0):
-    """C = epi(alpha * A @ B) for M <= 64 rows (incremental decoding); see lvt_gemm_smallm_f32."""
+    """C = epi(alpha * A @ B) for a few rows (incremental decoding: M = videos per step); see lvt_gemm_smallm_f32."""
     L.require(A, B, bias, res)
-    if M > 64:
+    # up to 512 rows stay on the decode kernels (one workgroup per 64 rows x 32 columns: 3x the workgroups of the
+    # 128x128 engine tile at these shapes); the n-contiguous layout only exists for M <= 64
+    if M > 512 or (M > 64 and (tb != 0 or K % 8 != 0)):
         return gemm(A, B, C_out, M, N, K, ta=0, tb=tb, lda=lda, ldb=ldb, ldc=ldc, batch_inner=batch, sB=(0, sB),
                     sC=(0, sC), alpha=alpha, flags=flags, bias=bias, res=res, ldr=ldr)
     splits = _smallm_splits(N, K) if (tb == 0 and batch == 1 and N % 4 == 0) else 1

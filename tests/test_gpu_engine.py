@@ -249,7 +249,8 @@ def test_math_modes_accuracy(math_mode):
 
 
 @pytest.mark.parametrize("M,N,K,tb", [(64, 512, 512, 0), (3, 512, 1024, 0), (33, 100, 136, 0), (64, 2048, 512, 0),
-                                      (16, 128, 512, 1), (64, 512, 2560, 0), (64, 512, 2048, 0), (40, 1024, 1536, 0)])
+                                      (16, 128, 512, 1), (64, 512, 2560, 0), (64, 512, 2048, 0), (40, 1024, 1536, 0),
+                                      (150, 512, 512, 0), (256, 96, 1024, 0), (70, 128, 512, 1)])
 def test_gemm_small_m(M, N, K, tb):
     """Decode-time GEMM (M <= 64): matrix-core kernel for k-contiguous weights, FMA kernel for n-contiguous ones;
     bias + residual + ReLU epilogue; ragged M / N / K tails."""
@@ -264,7 +265,8 @@ def test_gemm_small_m(M, N, K, tb):
     assert rel_err(out, ref) < TOL
 
 
-@pytest.mark.parametrize("M,N,K,splits,with_bias", [(64, 512, 1024, 8, False), (64, 512, 512, 4, True), (5, 256, 256, 2, True)])
+@pytest.mark.parametrize("M,N,K,splits,with_bias", [(64, 512, 1024, 8, False), (64, 512, 512, 4, True), (5, 256, 256, 2, True),
+                                                    (192, 512, 512, 4, True)])
 def test_gemm_small_partial_and_splitsum_layernorm(M, N, K, splits, with_bias):
     """Decode-step pair: raw split-K partial tiles, then ONE launch that sums them, adds bias / residual and applies
     LayerNorm (the reduction of the attention-output and FFN-down products rides on the LayerNorm that follows)."""

@@ -82,7 +82,23 @@ def test_sample_videos_contract_and_priming(vt):
 def test_large_batches_decode_as_stream_groups(vt):
     """More than 64 videos are decoded as independent groups of <= 64 on separate streams; every group must produce
     exactly what it produces alone (arg-max sampling, so the draws do not depend on the random stream)."""
+    import lvt_amd.modeling.meta_arch.vt as vtmod
     B = 70                                                   # two groups of 35
+    monkey_rows = vtmod.DECODE_GROUP_ROWS
+    vtmod.DECODE_GROUP_ROWS = 64
+    try:
+        video, both = _check_stream_groups(vt, vtmod, B)
+    finally:
+        vtmod.DECODE_GROUP_ROWS = monkey_rows
+        vt._samplers = {}
+    # the same 70 videos as ONE group: every decode launch then covers two 64-row blocks
+    with torch.no_grad():
+        one = vt.sample_video(video, n_prime=15, temp=1e-4)
+    assert len(vt._samplers[(B, 1, 16, 16, 1e-4)]) == 1
+    assert float((one != both)[:, :, 15:].float().mean()) < 0.01
+
+
+def _check_stream_groups(vt, vtmod, B):
     codes = torch.stack([seeded.seeded_codes("g%d" % (i % 5), (16, 4, 16, 16), 8 + i % 7) for i in range(B)])
     with torch.no_grad():
         video = codes.transpose(1, 2).contiguous().to(DEV)
@@ -95,7 +111,6 @@ def test_large_batches_decode_as_stream_groups(vt):
         hi = vt.sample_video(video[35:].contiguous(), n_prime=15, temp=1e-4)
     assert torch.equal(both[:, :, :15].cpu(), codes.transpose(1, 2)[:, :, :15])
     # concurrent groups == the same groups run one after the other on one stream, bit for bit
-    import lvt_amd.modeling.meta_arch.vt as vtmod
     vtmod.DECODE_GROUP_STREAMS = False
     try:
         vt._samplers = {}
@@ -123,6 +138,7 @@ def test_large_batches_decode_as_stream_groups(vt):
     mism = float((torch.cat([lo, hi]) != both)[:, :, 15:].float().mean())
     print("grouped vs alone: %.4f of the generated codes differ" % mism)
     assert mism < 0.01
+    return video, both
 
 
 def test_sample_categorical_matches_oracle_rule():
