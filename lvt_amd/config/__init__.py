@@ -1,3 +1,9 @@
-from .config import CfgNode, get_cfg, global_cfg, set_global_cfg
+"""Configuration surface of the package (same four names as `vidgen.config`)."""
+from . import config as _impl
 
-__all__ = ["CfgNode", "get_cfg", "global_cfg", "set_global_cfg"]
+get_cfg = _impl.get_cfg
+CfgNode = _impl.CfgNode
+set_global_cfg = _impl.set_global_cfg
+global_cfg = _impl.global_cfg
+
+__all__ = ("get_cfg", "CfgNode", "set_global_cfg", "global_cfg")

@@ -1,16 +1,18 @@
-import logging
-
+"""Autoregressive-prior registry and factory (reference surface: vidgen/modeling/autoregressive/build.py:16-29)."""
 from ...utils.registry import Registry
-from .autoregressive import Autoregressive
+from .._factory import component_builder
 
 AUTOREGRESSIVE_REGISTRY = Registry("AUTOREGRESSIVE")
 
 
-def build_autoregressive(cfg, **kwargs):
-    """`cfg.MODEL.AUTOREGRESSIVE.NAME` -> instance (vidgen/modeling/autoregressive/build.py:16-29)."""
+def _base():
+    from .autoregressive import Autoregressive
+    return Autoregressive
+
+
+def _register_implementations():
     from . import videotransformer  # noqa: F401  (registers VideoTransformer)
-    model = AUTOREGRESSIVE_REGISTRY.get(cfg.MODEL.AUTOREGRESSIVE.NAME).from_config(cfg, **kwargs)
-    assert isinstance(model, Autoregressive)
-    logging.getLogger(__name__).info(
-        "#params in autoregressive: {}M".format(sum(p.numel() for p in model.parameters()) / 1e6))
-    return model
+
+
+build_autoregressive = component_builder(AUTOREGRESSIVE_REGISTRY, "AUTOREGRESSIVE", "autoregressive", base=_base,
+                                         preload=_register_implementations)

@@ -1,15 +1,13 @@
-import logging
-
+"""Encoder registry and factory (reference surface: vidgen/modeling/encoder/build.py:16-28)."""
 from ...utils.registry import Registry
-from .encoder import Encoder
+from .._factory import component_builder
 
 ENCODER_REGISTRY = Registry("ENCODER")
 
 
-def build_encoder(cfg, **kwargs):
-    """`cfg.MODEL.ENCODER.NAME` -> instance via `from_config` (vidgen/modeling/encoder/build.py:16-28)."""
-    encoder = ENCODER_REGISTRY.get(cfg.MODEL.ENCODER.NAME).from_config(cfg, **kwargs)
-    assert isinstance(encoder, Encoder)
-    logging.getLogger(__name__).info(
-        "#params in encoder: {}M".format(sum(p.numel() for p in encoder.parameters()) / 1e6))
-    return encoder
+def _base():
+    from .encoder import Encoder
+    return Encoder
+
+
+build_encoder = component_builder(ENCODER_REGISTRY, "ENCODER", "encoder", base=_base)

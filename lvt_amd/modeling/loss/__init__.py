@@ -1,3 +1,6 @@
-from .loss import PixelLoss
+"""Training losses of the auto-encoders (`PixelLoss`: L1 / L2 reconstruction term)."""
+from . import loss as _impl
 
-__all__ = ["PixelLoss"]
+PixelLoss = _impl.PixelLoss
+
+__all__ = ("PixelLoss",)

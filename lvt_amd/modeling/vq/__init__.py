@@ -1,3 +1,8 @@
-from .vq_embedding import DVQEmbedding, VQEmbedding
+"""Vector quantisation: one codebook (`VQEmbedding`) and the product quantiser over channel groups
+(`DVQEmbedding`), both backed by the HIP nearest / gather / EMA kernels."""
+from . import vq_embedding as _impl
 
-__all__ = ["DVQEmbedding", "VQEmbedding"]
+VQEmbedding = _impl.VQEmbedding
+DVQEmbedding = _impl.DVQEmbedding
+
+__all__ = ("VQEmbedding", "DVQEmbedding")
