@@ -2,31 +2,42 @@
 import numpy as np
 import torch
 from torch import nn
-from torch.nn import init
+
+
+def _normal_fill(weight, slope):
+    # He-style std for a leaky-ReLU of the given slope, fan computed over every dim but the last (as the reference does)
+    fan = np.prod(weight.shape[:-1])
+    weight.normal_(std=1 / np.sqrt((1 + slope ** 2) * fan))      # evaluated exactly as the reference does (same float)
+
+
+def _xavier_fill(weight, slope):
+    nn.init.xavier_uniform_(weight)
+
+
+_FILLS = {"normal": _normal_fill, "xavier_uniform": _xavier_fill}
 
 
 def init_weights(module, init_type="normal", slope=0.2):
-    """Reference initialiser (ae.py:41-61 / vt.py:34-54): every sub-module whose class name contains
-    "Conv" or "Linear" and has a `.weight` gets normal(std) / xavier_uniform, bias <- 0; then direct
-    children exposing `init_weights` are asked to re-initialise themselves."""
+    """The reference's initialiser (ae.py:41-61 / vt.py:34-54), same visiting order and random draws: every sub-module
+    whose class name contains "Conv" or "Linear" and that owns a `.weight` is filled (normal with the std above, or
+    xavier-uniform) and its bias zeroed; afterwards each DIRECT child that defines `init_weights` re-initialises itself."""
+    fill = _FILLS.get(init_type)
+    if fill is None:
+        raise ValueError("unknown INIT_TYPE %r" % (init_type,))
 
-    def init_func(m):
-        name = m.__class__.__name__
-        if hasattr(m, "weight") and ("Conv" in name or "Linear" in name):
-            if init_type == "normal":
-                std = 1 / np.sqrt((1 + slope ** 2) * np.prod(m.weight.data.shape[:-1]))
-                m.weight.data.normal_(std=std)
-            elif init_type == "xavier_uniform":
-                nn.init.xavier_uniform_(m.weight.data)
-            else:
-                raise ValueError
-            if getattr(m, "bias", None) is not None:
-                init.constant_(m.bias.data, 0.0)
+    def visit(sub):
+        kind = type(sub).__name__
+        if ("Conv" in kind or "Linear" in kind) and hasattr(sub, "weight"):
+            fill(sub.weight.data, slope)
+            bias = getattr(sub, "bias", None)
+            if bias is not None:
+                bias.data.zero_()
 
-    module.apply(init_func)
-    for m in module.children():
-        if hasattr(m, "init_weights"):
-            m.init_weights(init_type, slope)
+    module.apply(visit)
+    for child in module.children():
+        own = getattr(child, "init_weights", None)
+        if own is not None:
+            own(init_type, slope)
 
 
 def stack_to_device(items, device):
