@@ -493,27 +493,37 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void lvt_attn_decode_kernel(const f
     if (lane == 0) reds[wave] = sum;
     __syncthreads();
     sum = ((reds[0] + reds[1]) + reds[2]) + reds[3];
-    // four value rows in flight per wave (independent accumulator pairs, combined in a fixed order)
+    // value rows: a lane owns dims 2*lane, 2*lane+1 (one 8-byte load per row: a wave instruction is one whole 512-byte
+    // row), eight rows in flight per wave in four independent accumulator pairs, combined in a fixed order
     float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f, c0 = 0.f, c1 = 0.f, d0 = 0.f, d1 = 0.f;
-    const float *vp = Vc + (long long)b * S * hd + h * DEC_DA;
+    const float *vp = Vc + (long long)b * S * hd + h * DEC_DA + 2 * lane;
+    const long long rs = (long long)DEC_WAVES * hd;                     // stride between the rows of one wave
     int j = wave;
-    for (; j + 3 * DEC_WAVES < nk; j += 4 * DEC_WAVES) {
-        const float *v0 = vp + (long long)j * hd, *v1 = v0 + (long long)DEC_WAVES * hd, *v2 = v1 + (long long)DEC_WAVES * hd,
-                    *v3 = v2 + (long long)DEC_WAVES * hd;
-        const float x0 = v0[lane], y0 = v0[lane + 64], x1 = v1[lane], y1 = v1[lane + 64];
-        const float x2 = v2[lane], y2 = v2[lane + 64], x3 = v3[lane], y3 = v3[lane + 64];
-        a0 = fmaf(ps[j], x0, a0); a1 = fmaf(ps[j], y0, a1);
-        b0 = fmaf(ps[j + DEC_WAVES], x1, b0); b1 = fmaf(ps[j + DEC_WAVES], y1, b1);
-        c0 = fmaf(ps[j + 2 * DEC_WAVES], x2, c0); c1 = fmaf(ps[j + 2 * DEC_WAVES], y2, c1);
-        d0 = fmaf(ps[j + 3 * DEC_WAVES], x3, d0); d1 = fmaf(ps[j + 3 * DEC_WAVES], y3, d1);
+    for (; j + 7 * DEC_WAVES < nk; j += 8 * DEC_WAVES) {
+        const float *v0 = vp + (long long)j * hd;
+        float2 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float2 *>(v0 + u * rs);
+        float pj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pj[u] = ps[j + u * DEC_WAVES];
+        a0 = fmaf(pj[0], x[0].x, a0); a1 = fmaf(pj[0], x[0].y, a1);
+        b0 = fmaf(pj[1], x[1].x, b0); b1 = fmaf(pj[1], x[1].y, b1);
+        c0 = fmaf(pj[2], x[2].x, c0); c1 = fmaf(pj[2], x[2].y, c1);
+        d0 = fmaf(pj[3], x[3].x, d0); d1 = fmaf(pj[3], x[3].y, d1);
+        a0 = fmaf(pj[4], x[4].x, a0); a1 = fmaf(pj[4], x[4].y, a1);
+        b0 = fmaf(pj[5], x[5].x, b0); b1 = fmaf(pj[5], x[5].y, b1);
+        c0 = fmaf(pj[6], x[6].x, c0); c1 = fmaf(pj[6], x[6].y, c1);
+        d0 = fmaf(pj[7], x[7].x, d0); d1 = fmaf(pj[7], x[7].y, d1);
     }
     for (; j < nk; j += DEC_WAVES) {
         const float p = ps[j];
-        a0 = fmaf(p, vp[(long long)j * hd + lane], a0);
-        a1 = fmaf(p, vp[(long long)j * hd + lane + 64], a1);
+        const float2 x = *reinterpret_cast<const float2 *>(vp + (long long)j * hd);
+        a0 = fmaf(p, x.x, a0);
+        a1 = fmaf(p, x.y, a1);
     }
     a0 = (a0 + b0) + (c0 + d0); a1 = (a1 + b1) + (c1 + d1);
-    acc[wave][lane] = a0; acc[wave][lane + 64] = a1;
+    acc[wave][2 * lane] = a0; acc[wave][2 * lane + 1] = a1;
     __syncthreads();
     if (tid < DEC_DA)
         o[(long long)b * hd + h * DEC_DA + tid] = (((acc[0][tid] + acc[1][tid]) + acc[2][tid]) + acc[3][tid]) / sum;
