@@ -365,10 +365,15 @@ __global__ __launch_bounds__(256) void lvt_splitsum_layernorm_kernel(const float
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < d4) {
             const float *src = ws + (long long)row * d + c * 4;
+            // the loads of up to eight partial tiles are issued together; they are added in split order
             float4 a = *reinterpret_cast<const float4 *>(src);
-            for (int k = 1; k < splits; ++k) {
-                const float4 t = *reinterpret_cast<const float4 *>(src + k * plane);
-                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            for (int k0 = 1; k0 < splits; k0 += 8) {
+                float4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    t[u] = (k0 + u < splits) ? *reinterpret_cast<const float4 *>(src + (k0 + u) * plane) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a.x += t[u].x; a.y += t[u].y; a.z += t[u].z; a.w += t[u].w; }
             }
             if (bias) { const float4 t = reinterpret_cast<const float4 *>(bias)[c]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
             if (res) { const float4 t = *reinterpret_cast<const float4 *>(res + (long long)row * ldr + c * 4); a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
