@@ -250,12 +250,21 @@ __global__ void lvt_embbag_fwd_kernel(const long long *__restrict__ idx, long lo
         const long long *ip = idx + b * bstride + pos;
         for (int c = lane; c < d4; c += 64) {
             float4 acc = bias ? reinterpret_cast<const float4 *>(bias)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int s = 0; s < sl.n; ++s) {
-                const long long id = ip[sl.off[s]];
-                if (id >= 0) {
-                    const float4 v = reinterpret_cast<const float4 *>(table + (sl.tab_row[s] + id) * D)[c];
-                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-                }
+            // eight slots at a time: their indices, then their table rows, are requested together (a decode step has
+            // ONE row per sample here, so the slot loop used to be a chain of 2 x n dependent round trips); rows are
+            // added in slot order
+            for (int s0 = 0; s0 < sl.n; s0 += 8) {
+                long long id[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) id[u] = (s0 + u < sl.n) ? ip[sl.off[s0 + u]] : -1;
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = (id[u] >= 0) ? reinterpret_cast<const float4 *>(table + (sl.tab_row[s0 + u] + id[u]) * D)[c]
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (id[u] >= 0) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
             }
             if (btable) {
                 const float4 v = reinterpret_cast<const float4 *>(btable + bindex[b] * D)[c];
