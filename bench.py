@@ -90,8 +90,6 @@ def vqvae_step(model, optimizers, data, storage_iter):
         losses = model(data, mode="supervised")
     total = sum(losses.values())
     total.backward()
-    if hasattr(model, "finish_gradient_sync"):
-        model.finish_gradient_sync()
     for o in optimizers:
         o["optimizer"].step()
     for o in optimizers:
@@ -127,7 +125,6 @@ def bench_dsfvt(device, world, rank, steps, warmup, batch, strict_f32=True):
         with EventStorage(i):
             loss = model.compute_supervised_loss(ctx, sl, sidx, ign)["loss_cross_entropy"]
         loss.backward()
-        model.finish_gradient_sync()
         for o in optimizers:
             o["optimizer"].step()
         for o in optimizers:

@@ -89,13 +89,22 @@ class DatasetMapper:
 
     def __call__(self, dataset_dict):
         d = dict(dataset_dict)
-        if "image_sequence" not in d:
+        if "latent_paths" in d or "latent_names" in d:
+            # loader records of data/latents.py:get_latent_video_paths (reference dataset_mapper.py:68-77): only the
+            # frames of the drawn window are read from disk
+            files = d["latent_paths"] if "latent_paths" in d else [d["video_root"] + "/" + n for n in d["latent_names"]]
+            win = self._window(len(files))
+            if win is None:
+                return None
+            seq = np.stack([np.load(f) for f in files[win]], axis=0)
+        elif "image_sequence" in d:
+            seq = np.asarray(d["image_sequence"])
+            win = self._window(len(seq))
+            if win is None:
+                return None                               # too short: the loader retries another index
+            seq = seq[win]
+        else:
             raise NotImplementedError("only latent-code clips are handled by this mapper (image I/O is out of scope)")
-        seq = np.asarray(d["image_sequence"])
-        win = self._window(len(seq))
-        if win is None:
-            return None                                   # too short: the loader retries another index
-        seq = seq[win]
         if not self.prepare_slices:
             d["image_sequence"] = seq
             return d
@@ -103,5 +112,5 @@ class DatasetMapper:
         T = seq.shape[0]
         abc = draw_abc(self.stride, T // self.stride[0], self.n_prime)
         d.update(prepare_slices(seq, abc, self.stride, self.kernel, self.n_prime, self.pad_value))
-        del d["image_sequence"]
+        d.pop("image_sequence", None)
         return d

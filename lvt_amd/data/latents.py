@@ -1,5 +1,6 @@
 """On-disk latent-code format of the reference (evaluation/codes_extractor.py:36-53, data/datasets/latents.py:10-40):
-one int64 `.npy` of shape (nc, h, w) per frame under `<root>/[<class>/]video_<idx>/<frame>.npy`."""
+one int64 `.npy` of shape (nc, h, w) per frame under `<root>/[<class>/]video_<idx>/<frame>.npy`, indexed by a
+`latent_video_paths.npy` cache (a pickled list of records) at the dataset root."""
 import os
 import re
 
@@ -34,3 +35,36 @@ def load_video_codes(video_dir, frames=None, n_frames=-1):
     if n_frames > 0:
         frames = frames[:n_frames]
     return np.stack([np.load(os.path.join(video_dir, f)) for f in frames], axis=0)
+
+
+CACHE_NAME = "latent_video_paths.npy"
+
+
+def _natural_key(name):
+    # "10.npy" after "9.npy": digit runs compare as integers (the reference's natural_sorted, utils/strings.py:9-23)
+    return [int(tok) if tok.isdigit() else tok for tok in re.split(r"(\d+)", name)]
+
+
+def get_latent_video_paths(root, use_cache=True):
+    """Loader records of the reference (data/datasets/latents.py:10-40):
+    `{"video_path": dir, "latent_paths": [frame files in natural order], "video_idx": running index}` for every LEAF
+    directory under `root` that holds nothing but `.npy` files, visited in `os.walk` order.  With `use_cache` the list
+    is read from `<root>/latent_video_paths.npy` when that file exists (whatever the directory holds by now) and
+    written there after the first scan -- the same pickle-in-npy container, so caches written by either
+    implementation are interchangeable."""
+    if not (os.path.isdir(root) or os.path.islink(root)):
+        raise AssertionError("%s is not a valid directory" % root)
+    cache = os.path.join(root, CACHE_NAME)
+    if use_cache and os.path.exists(cache):
+        return np.load(cache, allow_pickle=True).tolist()
+    records = []
+    for cur, dirs, files in os.walk(root):
+        if dirs:
+            continue                                   # only leaf directories can be videos
+        files = sorted(files, key=_natural_key)
+        if all(f.endswith(".npy") for f in files):     # (an empty leaf directory is a video of zero frames there too)
+            records.append({"video_path": cur, "latent_paths": [os.path.join(cur, f) for f in files],
+                            "video_idx": len(records)})
+    if use_cache and not os.path.exists(cache):
+        np.save(cache, records)
+    return records

@@ -2,16 +2,33 @@
 torch DistributedDataParallel: ae.py:69-73, vt.py:61-63).
 
 One process per GPU.  Parameters are grouped, in reverse registration order (the order their
-gradients become available in the backward pass), into flat buckets of >= `bucket_bytes`.  A
-post-accumulate-grad hook copies each finished gradient into its bucket slot; when a bucket is
-complete it is all-reduced asynchronously on a dedicated communication stream (RCCL drives all 7
-xGMI links), overlapping the remaining backward kernels.  `wait()` (called before the optimizer
-step) joins the streams, scales by 1/world and points `.grad` at the averaged bucket views.
+gradients become available in the backward pass), into flat buckets of >= `bucket_bytes`, and every
+`.grad` IS a view of its bucket slot: autograd accumulates straight into the bucket, so there is no
+copy-in, no copy-out and no separate 1/world pass (RCCL reduces with ReduceOp.AVG).  When the last
+gradient of a bucket has been accumulated the bucket is all-reduced asynchronously on a dedicated
+communication stream (RCCL drives all 7 xGMI links) while the remaining backward kernels run.
 
-On CPU (gloo, used by the world_size-2 unit tests) the same logic runs synchronously.
+Semantics are those of torch DDP, with no call required from the training loop
+(vidgen/engine/trainer.py:79-87 has none):
+
+  * EVERY backward averages the gradients (a DDP without `no_sync`).  With gradient accumulation the
+    bucket holds avg(g1) + local g2 before the second reduction and avg(g1) + avg(g2) after it.
+  * the reduction is joined automatically (a) before any `torch.optim.Optimizer.step()` (global
+    step pre-hook), (b) at the next forward of the owning meta-architecture, (c) when a gradient
+    arrives for a bucket whose previous reduction is still in flight, and (d) by an explicit
+    `wait()` for callers that read `.grad` themselves.
+  * `optimizer.zero_grad(set_to_none=True)` (torch's default) detaches `.grad` from the bucket; the
+    next gradient is then moved into the slot once and `.grad` re-pointed -- still no copy-back.
+    `zero_()` restores the zero-copy path and is what `solver/fused.py` optimizers do.
+
+On CPU (gloo, used by the world_size-2 unit tests) the same logic runs with SUM + a division, because
+gloo has no AVG.
 """
+import weakref
+
 import torch
 import torch.distributed as dist
+from torch.optim.optimizer import register_optimizer_step_pre_hook
 
 
 class BucketedGradReducer:
@@ -24,7 +41,7 @@ class BucketedGradReducer:
             with torch.no_grad():
                 for p in self.params:
                     dist.broadcast(p.data, 0, group=group)
-        self.buckets = []          # list of dict(flat, params, offsets, pending, work)
+        self.buckets = []          # dict(flat, params, views, pending, work)
         self._slot = {}
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
@@ -36,19 +53,33 @@ class BucketedGradReducer:
         if cur:
             self._make_bucket(cur)
         self._comm_stream = None
-        self._handles = []
-        for p in self.params:
-            p.register_post_accumulate_grad_hook(self._on_grad)
+        # gloo (CPU unit tests, and the 2-ranks-on-one-GPU tests) has no AVG: SUM + one division there
+        self._avg = self.world > 1 and dist.get_backend(group) == "nccl"
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        ref = weakref.ref(self)
+
+        def _before_step(optimizer, args, kwargs):
+            me = ref()
+            if me is not None:
+                me.wait()
+        self._hooks.append(register_optimizer_step_pre_hook(_before_step))
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
     def _make_bucket(self, plist):
         dev, dt = plist[0].device, plist[0].dtype
         total = sum(p.numel() for p in plist)
-        b = {"flat": torch.zeros(total, dtype=dt, device=dev), "params": list(plist), "pending": len(plist),
-             "offsets": []}
+        flat = torch.zeros(total, dtype=dt, device=dev)
+        b = {"flat": flat, "params": list(plist), "views": [], "pending": len(plist), "work": None}
         off = 0
         for p in plist:
-            b["offsets"].append(off)
-            self._slot[p] = (len(self.buckets), off)
+            v = flat[off:off + p.numel()].view_as(p)
+            b["views"].append(v)
+            self._slot[p] = (len(self.buckets), v)
+            p._lvt_reducer = weakref.ref(self)
             off += p.numel()
         self.buckets.append(b)
 
@@ -59,12 +90,38 @@ class BucketedGradReducer:
             self._comm_stream = torch.cuda.Stream(device=device)
         return self._comm_stream
 
+    def zero_grad(self, only=None):
+        """Zero the gradients (of the parameters in `only`, default all) inside their buckets and keep `.grad`
+        attached to the slot: the zero-copy state.  Parameters that have no gradient keep `None` (an optimizer
+        skips them, as it does in the reference)."""
+        if self.world == 1:
+            return False
+        self.wait()
+        for b in self.buckets:
+            mine = [only is None or p in only for p in b["params"]]
+            if all(mine):
+                b["flat"].zero_()
+            for p, v, m in zip(b["params"], b["views"], mine):
+                if m and p.grad is not None:
+                    if not all(mine):
+                        v.zero_()
+                    p.grad = v
+        return True
+
     def _on_grad(self, p):
         if self.world == 1:
             return
-        bi, off = self._slot[p]
+        bi, view = self._slot[p]
         b = self.buckets[bi]
-        b["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
+        if b["work"] is not None:
+            # a second backward without a join in between: finish the reduction in flight first (p.grad, if it
+            # is the view, was accumulated while the all-reduce was reading it -- DDP forbids that too; the
+            # built-in joins (a)/(b) make sure a training loop never gets here)
+            self._join(b)
+        g = p.grad
+        if g.data_ptr() != view.data_ptr():
+            view.copy_(g)                      # .grad was detached by zero_grad(set_to_none=True)
+            p.grad = view
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch(b)
@@ -72,32 +129,32 @@ class BucketedGradReducer:
     def _launch(self, b):
         flat = b["flat"]
         cs = self._stream(flat.device)
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         if cs is not None:
             cs.wait_stream(torch.cuda.current_stream(flat.device))
             with torch.cuda.stream(cs):
-                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b["work"] = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
         else:
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._handles.append((b, work))
+            b["work"] = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
 
-    def wait(self):
-        """Join outstanding all-reduces, average, and expose the result through `.grad`."""
-        if self.world == 1:
-            return
-        # buckets whose parameters did not all receive a gradient this step are reduced as they are
-        for b in self.buckets:
-            if 0 < b["pending"] < len(b["params"]):
-                self._launch(b)
-        for b, work in self._handles:
-            work.wait()
+    def _join(self, b):
+        b["work"].wait()
         cs = self._comm_stream
         if cs is not None:
             torch.cuda.current_stream(cs.device).wait_stream(cs)
-        for b, _ in self._handles:
+        if not self._avg:
             b["flat"].div_(self.world)
-            for p, off in zip(b["params"], b["offsets"]):
-                if p.grad is not None:
-                    p.grad = b["flat"][off:off + p.numel()].view_as(p)
-        self._handles = []
+        b["work"] = None
+        b["pending"] = len(b["params"])
+
+    def wait(self):
+        """Join outstanding all-reduces; afterwards every `.grad` holds the cross-rank mean."""
+        if self.world == 1:
+            return
+        # buckets whose parameters did not all receive a gradient this backward are reduced as they are
         for b in self.buckets:
-            b["pending"] = len(b["params"])
+            if b["work"] is None and 0 < b["pending"] < len(b["params"]):
+                self._launch(b)
+        for b in self.buckets:
+            if b["work"] is not None:
+                self._join(b)

@@ -43,8 +43,6 @@ class Trainer:
         losses = sum(loss_dict.values())
         losses.backward()
         if (self.iter + 1) % self.accumulation_steps == 0:
-            if hasattr(self.model, "finish_gradient_sync"):
-                self.model.finish_gradient_sync()
             for item in self.optimizers:
                 item["optimizer"].step()
             for item in self.optimizers:

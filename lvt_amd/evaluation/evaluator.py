@@ -84,6 +84,10 @@ class _SumEvaluator(DatasetEvaluator):
         self._acc = v if self._acc is None else self._acc + v
 
     def _totals(self):
+        if self._acc is None:                 # a rank that saw no sample still takes part in the all-reduce
+            dev = "cuda" if (self._distributed and torch.cuda.is_available() and
+                             torch.distributed.get_backend() == "nccl") else "cpu"
+            self._acc = torch.zeros(2, dtype=torch.float64, device=dev)
         acc = self._acc.clone()
         if self._distributed:
             all_reduce_sum_(acc)
@@ -101,7 +105,7 @@ class MSEEvaluator(_SumEvaluator):
         s, n = self._totals()
         if not comm.is_main_process():
             return None
-        results = OrderedDict({"reconstruction": {"mse": s / n}})
+        results = OrderedDict({"reconstruction": {"MSE": s / n}})
         self._logger.info(results)
         return results
 

@@ -49,8 +49,11 @@ def _smallm_splits(N, K):
 
 
 def gemm_small(A, B, C_out, M, N, K, tb=0, lda=None, ldb=None, ldc=None, batch=1, sB=0, sC=0, alpha=1.0, flags=0,
-               bias=None, res=None, ldr=0):
-    """C = epi(alpha * A @ B) for a few rows (incremental decoding: M = videos per step); see lvt_gemm_smallm_f32."""
+               bias=None, res=None, ldr=0, split_ws=None):
+    """C = epi(alpha * A @ B) for a few rows (incremental decoding: M = videos per step); see lvt_gemm_smallm_f32.
+    `split_ws`: the caller's own split-K scratch (a callable bytes -> uint8/float tensor).  Callers that record
+    launches into hipGraphs replayed on several streams (autoregressive/incremental.py) must pass one: the
+    default workspace is shared per stream and every capture runs on the same capture stream."""
     L.require(A, B, bias, res)
     # up to 512 rows stay on the decode kernels (one workgroup per 64 rows x 32 columns: 3x the workgroups of the
     # 128x128 engine tile at these shapes); the n-contiguous layout only exists for M <= 64
@@ -61,7 +64,9 @@ def gemm_small(A, B, C_out, M, N, K, tb=0, lda=None, ldb=None, ldc=None, batch=1
     if splits > 1:
         lib = L.lib()
         nws = lib.lvt_gemm_smallm_splitk_workspace_bytes(M, N, splits)
-        ws = L.workspace(nws, A.device, "smallm")
+        ws = L.workspace(nws, A.device, "smallm") if split_ws is None else split_ws(nws)
+        if ws.numel() * ws.element_size() < nws:
+            raise L.LvtError("gemm_small: split-K scratch of %d bytes, need %d" % (ws.numel() * ws.element_size(), nws))
         L.check(lib.lvt_gemm_smallm_splitk_f32(M, N, K, splits, L.ptr(A), lda if lda is not None else K, L.ptr(B),
                                                ldb if ldb is not None else K, L.ptr(C_out), ldc if ldc is not None else N,
                                                alpha, flags, L.ptr(bias), L.ptr(res),

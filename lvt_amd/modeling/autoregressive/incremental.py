@@ -64,7 +64,11 @@ class IncrementalDecoder:
         # split-K partial tiles of the two residual products of a layer (see step): sized here, outside any capture
         self._pbuf = {}
         self._partials("proj", max(2, hd // 128))
-        self._partials("ffn", max(2, self.layers[0].ffn[1].weight.shape[0] // 128))
+        dff = self.layers[0].ffn[1].weight.shape[0]
+        self._partials("ffn", max(2, dff // 128))
+        # scratch of the generic products that split k themselves (reductions of 1024 and more, hip/gemm.py)
+        kmax = max(hd, dff, d, len(self.taps) * self.de)
+        self._split_ws(4 * b * max(d, dff, hd) * max(1, kmax // 256))
         self.begin_slice(zl_tok)
 
     def _refresh_weights(self):
@@ -97,7 +101,7 @@ class IncrementalDecoder:
                           self.tables, self.de)                                      # (b*taps, de) == (b, taps*de)
         x = torch.empty(b, self.d, dtype=torch.float32, device=a.device)
         G.gemm_small(a, self.wfront, x, b, self.d, nt * self.de, flags=L.EPI_BIAS | L.EPI_RESIDUAL,
-                     bias=self.dec.conv.conv.bias, res=self.base.view(-1)[i * self.d:], ldr=self.S * self.d)
+                     bias=self.dec.conv.conv.bias, res=self.base.view(-1)[i * self.d:], ldr=self.S * self.d, split_ws=self._split_ws)
         return x
 
     def _partials(self, which, splits):
@@ -106,6 +110,13 @@ class IncrementalDecoder:
         buf = self._pbuf.get(which)
         if buf is None or buf.numel() < splits * self.b * self.d:
             buf = self._pbuf[which] = torch.empty(splits * self.b * self.d, dtype=torch.float32, device=self.base.device)
+        return buf
+
+    def _split_ws(self, nbytes):
+        """Split-K scratch of the generic small-M products of a step, owned by this decoder (one per hipGraph group)."""
+        buf = self._pbuf.get("generic")
+        if buf is None or buf.numel() * 4 < nbytes:
+            buf = self._pbuf["generic"] = torch.empty((int(nbytes) + 3) // 4, dtype=torch.float32, device=self.base.device)
         return buf
 
     def step(self, sl, i):
@@ -132,7 +143,7 @@ class IncrementalDecoder:
                                              bias=pend[2], res=pend[3])
             # q_i / k_i / v_i of every sample in one launch: output row i of slot z, row stride S*hd, slot stride b*S*hd
             qkv = self.qkv[li]
-            G.gemm_small(xn, self.wqkv[li], qkv.view(-1)[i * hd:], b, hd, d, ldc=S * hd, batch=3, sB=hd * d, sC=b * S * hd)
+            G.gemm_small(xn, self.wqkv[li], qkv.view(-1)[i * hd:], b, hd, d, ldc=S * hd, batch=3, sB=hd * d, sC=b * S * hd, split_ws=self._split_ws)
             o = tx.attn_decode(qkv.view(-1)[i * hd:], self.kc[li], self.vc[li], na, i, math.sqrt(da), layer.dt_bank,
                                layer.dh_bank, layer.dw_bank, layer.block_size, ldq=S * hd)
             if hd % KS == 0 and d % 4 == 0:
@@ -140,18 +151,18 @@ class IncrementalDecoder:
                 y1, fn = G.splitsum_layernorm(ws, hd // KS, b, d, f[0].weight, f[0].bias, res=x)
             else:
                 y1 = torch.empty(b, d, dtype=torch.float32, device=dev)
-                G.gemm_small(o, m.proj.weight, y1, b, d, hd, flags=L.EPI_RESIDUAL, res=x)
+                G.gemm_small(o, m.proj.weight, y1, b, d, hd, flags=L.EPI_RESIDUAL, res=x, split_ws=self._split_ws)
                 fn, _, _ = ew.layernorm_fwd(y1, f[0].weight, f[0].bias, save_stats=False)
             dff = f[1].weight.shape[0]
             h1 = torch.empty(b, dff, dtype=torch.float32, device=dev)
-            G.gemm_small(fn, f[1].weight, h1, b, dff, d, flags=L.EPI_BIAS | L.EPI_RELU, bias=f[1].bias)
+            G.gemm_small(fn, f[1].weight, h1, b, dff, d, flags=L.EPI_BIAS | L.EPI_RELU, bias=f[1].bias, split_ws=self._split_ws)
             if li + 1 < nlayers and dff % KS == 0 and dff // KS >= 2 and d % 4 == 0:
                 ws = G.gemm_small_partial(h1, f[3].weight, b, d, dff, dff // KS, self._partials("ffn", dff // KS))
                 pend = (ws, dff // KS, f[3].bias, y1)
             else:
                 pend = None
                 x = torch.empty(b, d, dtype=torch.float32, device=dev)
-                G.gemm_small(h1, f[3].weight, x, b, d, dff, flags=L.EPI_BIAS | L.EPI_RESIDUAL, bias=f[3].bias, res=y1)
+                G.gemm_small(h1, f[3].weight, x, b, d, dff, flags=L.EPI_BIAS | L.EPI_RESIDUAL, bias=f[3].bias, res=y1, split_ws=self._split_ws)
         return x
 
 

@@ -55,11 +55,15 @@ class AutoEncoderModel(nn.Module):
     def wrap_parallel(self, device_ids, broadcast_buffers):
         """Data-parallel gradient averaging for encoder and generator.  The reference wraps each
         sub-network in torch DDP; here a bucketed RCCL all-reduce is hooked onto the parameters and
-        runs on a side stream while the rest of the backward is still computing."""
+        runs on a side stream while the rest of the backward is still computing.  Self-joining like DDP:
+        the reducers hook `Optimizer.step`, so the reference loop (engine/trainer.py:79-87) needs no extra call."""
+        for r in self._reducers:
+            r.remove()
         self._reducers = [BucketedGradReducer(self.encoder.parameters()),
                           BucketedGradReducer(self.generator.parameters())]
 
     def finish_gradient_sync(self):
+        """Optional early join for callers that read `.grad` before `optimizer.step()`."""
         for r in self._reducers:
             r.wait()
 
@@ -105,6 +109,7 @@ class AutoEncoderModel(nn.Module):
     # ---- forward modes (ae.py:101-149) ------------------------------------------------------------
     def forward(self, data, mode="inference"):
         if mode in ("generator", "supervised"):
+            self.finish_gradient_sync()      # accumulation: the previous micro-step's all-reduce owns the buckets
             x, _ = self._preprocess_cl(data)
             if mode == "generator":
                 it = get_event_storage().iter

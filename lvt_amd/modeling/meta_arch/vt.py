@@ -66,10 +66,15 @@ class VideoTransformerModel(nn.Module):
         return self
 
     def wrap_parallel(self, device_ids, broadcast_buffers):
-        """Bucketed RCCL gradient averaging overlapped with backward (reference: torch DDP, vt.py:61-63)."""
+        """Bucketed RCCL gradient averaging overlapped with backward (reference: torch DDP, vt.py:61-63).
+        Self-joining like DDP: the reducer hooks `Optimizer.step`, so the reference loop
+        (engine/trainer.py:79-87: forward, backward, step) needs no extra call."""
+        for r in self._reducers:
+            r.remove()
         self._reducers = [BucketedGradReducer(self.model.parameters())]
 
     def finish_gradient_sync(self):
+        """Optional early join for callers that read `.grad` before `optimizer.step()`."""
         for r in self._reducers:
             r.wait()
 
@@ -110,6 +115,7 @@ class VideoTransformerModel(nn.Module):
 
     def forward(self, data, mode="inference"):
         if mode == "supervised":
+            self.finish_gradient_sync()      # accumulation: the previous micro-step's all-reduce owns the buckets
             context, slice, slice_idx, ignore_mask, class_idx = self.preprocess_data(data)
             it = get_event_storage().iter
             return self.compute_supervised_loss(context, slice, slice_idx, ignore_mask, it, class_idx)

@@ -24,6 +24,29 @@ def _entries(items):
 
 
 class _FusedBase(Optimizer):
+    def zero_grad(self, set_to_none=True):
+        """torch semantics, except that gradients living in a data-parallel bucket (engine/grad_reducer.py) are
+        zeroed in place -- one memset per bucket -- and stay attached to it, so the next backward accumulates
+        straight into the buffer RCCL reduces."""
+        bucketed, plain = {}, []
+        for group in self.param_groups:
+            for p in group["params"]:
+                ref = getattr(p, "_lvt_reducer", None)
+                red = ref() if ref is not None else None
+                if red is not None and red.world > 1:
+                    bucketed.setdefault(id(red), (red, set()))[1].add(p)
+                else:
+                    plain.append(p)
+        for red, ps in bucketed.values():
+            red.zero_grad(only=ps)
+        for p in plain:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.detach_()
+                    p.grad.zero_()
+
     def _collect(self, make_state):
         """-> dict step_count -> list of (p, grad, s0, s1, lr, wd)."""
         by_step = {}

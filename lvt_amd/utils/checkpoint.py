@@ -1,6 +1,7 @@
 """Minimal checkpointer with the on-disk convention the reference gets from fvcore
 (`{"model": state_dict}` in `<save_dir>/<name>.pth`; model_{iter:07d}.pth / model_final.pth;
 `last_checkpoint` marker).  The reference constructs one per sub-network (ae.py:231-238)."""
+import logging
 import os
 
 import torch
@@ -41,10 +42,19 @@ class Checkpointer:
     def load(self, path):
         if not path:
             return {}
+        if not os.path.isfile(path):
+            raise FileNotFoundError("Checkpoint {} not found!".format(path))
         ckpt = torch.load(path, map_location="cpu")
         state = ckpt.pop("model")
         state = {(k[7:] if k.startswith("module.") else k): v for k, v in state.items()}
-        self.model.load_state_dict(state, strict=False)
+        incompatible = self.model.load_state_dict(state, strict=False)
+        self.last_incompatible = incompatible           # (missing_keys, unexpected_keys), also logged like fvcore does
+        if incompatible.missing_keys:
+            logging.getLogger("lvt_amd").warning("checkpoint %s: keys missing from the file: %s", path,
+                                                 ", ".join(incompatible.missing_keys))
+        if incompatible.unexpected_keys:
+            logging.getLogger("lvt_amd").warning("checkpoint %s: keys not used by the model: %s", path,
+                                                 ", ".join(incompatible.unexpected_keys))
         for k, obj in self.checkpointables.items():
             if k in ckpt:
                 obj.load_state_dict(ckpt.pop(k))

@@ -38,11 +38,16 @@ def save_video(video_thwc_u8, out_dir):
         Image.fromarray(frame).save(os.path.join(out_dir, "%d.png" % i))
 
 
+ALLOW_RANDOM_WEIGHTS = False
+
+
 def _load(module, path):
-    if path and os.path.isfile(path):
-        Checkpointer(module).resume_or_load(path, resume=False)
+    """A configured weight file that does not exist is an error (as with the reference's Checkpointer), unless the
+    caller asked for random weights explicitly (`--random-weights`, smoke runs without pretrained files)."""
+    if path and (os.path.isfile(path) or not ALLOW_RANDOM_WEIGHTS):
+        Checkpointer(module).resume_or_load(path, resume=False)          # raises FileNotFoundError when absent
     elif path:
-        print("checkpoint %s not found: keeping the current weights" % path)
+        print("checkpoint %s not found: --random-weights given, keeping the initialised weights" % path)
 
 
 @torch.no_grad()
@@ -90,7 +95,10 @@ if __name__ == "__main__":
     parser = argparse.ArgumentParser(description="Sample video with 16 frames given priming frames")
     parser.add_argument("--config-file", required=True, metavar="FILE")
     parser.add_argument("--video-dir", required=True)
+    parser.add_argument("--random-weights", action="store_true",
+                        help="run with the initialised weights when a configured checkpoint file is absent")
     parser.add_argument("opts", default=None, nargs=argparse.REMAINDER)
     args = parser.parse_args()
     print("Command Line Args:", args)
+    ALLOW_RANDOM_WEIGHTS = args.random_weights
     sample_videos(args)

@@ -434,8 +434,95 @@ def golden_variants():
          **{"new_" + k: v for k, v in cb_state_of(model.codebook).items() if "running_size" in k})
 
 
+def tensor_pins(state_dict):
+    """Per-tensor checksums (float64 sum, sum of |.|, first and last element): what a same-seed construction of the
+    product's build_model has to reproduce exactly."""
+    names, rows = [], []
+    for k, v in state_dict.items():
+        if not v.dtype.is_floating_point:
+            continue
+        d = v.detach().double().reshape(-1)
+        names.append(k)
+        rows.append([float(d.sum()), float(d.abs().sum()), float(d[0]), float(d[-1]), float(d.numel())])
+    return np.array(names), np.array(rows, dtype=np.float64)
+
+
+LATENT_TREE = {                      # relative leaf directory -> file names (the test rebuilds the same tree)
+    "video_0": ["%d.npy" % i for i in range(12)],
+    "video_1": ["0.npy", "1.npy", "2.npy", "10.npy", "9.npy"],
+    "clsA/video_7": ["3.npy", "1.npy", "2.npy"],
+    "clsA/video_8": ["0.npy"],
+    "mixed": ["0.npy", "notes.txt"],
+    "emptyleaf": [],
+}
+
+
+def golden_pins():
+    """G19: weight initialisation (A21) -- checksums of every tensor of a same-seed `build_model`; G20: the loader
+    records / `latent_video_paths.npy` cache (f2) on a small directory tree; the mapper fed with such a record."""
+    import random
+    import tempfile
+    from vidgen.modeling.meta_arch.build import build_model
+    import vidgen.modeling.meta_arch  # noqa: F401
+    from vidgen.data.datasets.latents import get_latent_video_paths
+    from vidgen.data.dataset_mapper import DatasetMapper
+
+    out = {}
+    for tag, path, seed in (("prdvqvae2", "configs/vqvae/PR-DVQVAE2.yaml", 29871897),
+                            ("kdvqvae", "configs/vqvae/K-DVQVAE.yaml", 11),
+                            ("dsfvt", "configs/vt/DSFVT.yaml", 29871897),
+                            ("dssvt", "configs/vt/DSSVT.yaml", 5)):
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        random.seed(seed)
+        model = build_model(ref_cfg(path))
+        parts = {"encoder": model.encoder, "generator": model.generator, "codebook": model.codebook} \
+            if hasattr(model, "codebook") else {"model": model.model}
+        for part, mod in parts.items():
+            names, rows = tensor_pins(mod.state_dict())
+            out["%s.%s.names" % (tag, part)] = names
+            out["%s.%s.pins" % (tag, part)] = rows
+        out[tag + ".seed"] = seed
+    save("g19_init_pins", **out)
+
+    with tempfile.TemporaryDirectory() as root:
+        rng = np.random.RandomState(3)
+        for leaf, files in LATENT_TREE.items():
+            os.makedirs(os.path.join(root, leaf), exist_ok=True)
+            for f in files:
+                full = os.path.join(root, leaf, f)
+                if f.endswith(".npy"):
+                    np.save(full, rng.randint(0, 512, (4, 16, 16)).astype(np.int64))
+                else:
+                    open(full, "w").write("x")
+        recs = get_latent_video_paths(root, use_cache=True)
+        assert os.path.exists(os.path.join(root, "latent_video_paths.npy"))
+        again = get_latent_video_paths(root, use_cache=True)
+        assert again == recs
+        rel = lambda p_: os.path.relpath(p_, root)            # noqa: E731
+        g20 = {"video_path": np.array([rel(r["video_path"]) for r in recs]),
+               "latent_paths": np.array(["|".join(rel(q) for q in r["latent_paths"]) for r in recs]),
+               "video_idx": np.array([r["video_idx"] for r in recs]),
+               "record_keys": np.array(sorted(recs[0]))}
+        # the mapper on a loader record: window + slice drawn with python `random` seeded to 77
+        cfg = ref_cfg("configs/vt/DSFVT.yaml")
+        cfg.INPUT.N_FRAMES_PER_VIDEO_TRAIN = 8
+        cfg.MODEL.AUTOREGRESSIVE.VT.STRIDE = (8, 1, 1)
+        cfg.MODEL.AUTOREGRESSIVE.VT.N_PRIME = 2
+        mapper = DatasetMapper(cfg, True)
+        rec0 = [r for r in recs if rel(r["video_path"]) == "video_0"][0]
+        random.seed(77)
+        d = mapper(rec0)
+        g20.update(mapped_context=d["context"], mapped_slice=d["slice"], mapped_slice_idx=d["slice_idx"],
+                   mapped_ignore=d["ignore_mask"], mapped_keys=np.array(sorted(k for k in d)),
+                   video_0=np.stack([np.load(q) for q in rec0["latent_paths"]]))
+    save("g20_latent_paths", **g20)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["vqvae", "vt", "variants"]
+    which = sys.argv[1:] or ["vqvae", "vt", "variants", "pins"]
+    if "pins" in which:
+        golden_pins()
     if "vqvae" in which:
         golden_vqvae()
     if "vt" in which:

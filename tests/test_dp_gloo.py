@@ -51,8 +51,9 @@ def _reducer_case(rank, world):
     for step in range(2):                               # two steps: buckets must re-arm
         x = torch.full((3, 8), float(rank + 1 + step))
         net.zero_grad()
+        # this rank's own gradient, taken without touching .grad (whose buckets are reduced while backward runs)
+        local = [g.clone() for g in torch.autograd.grad(net(x).sum(), list(net.parameters()))]
         net(x).sum().backward()
-        local = [p.grad.clone() for p in net.parameters()]
         red.wait()
         outs.append(([p.grad.clone() for p in net.parameters()], local))
     return w0, outs
@@ -68,6 +69,60 @@ def test_bucketed_reducer_broadcasts_and_averages():
         for ga, gb, la, lb in zip(avg_a, avg_b, loc_a, loc_b):
             assert torch.equal(ga, gb)
             assert torch.allclose(ga, (la + lb) / 2, rtol=1e-6, atol=1e-7)
+
+
+def _reference_loop_case(rank, world):
+    """The reference's own loop (vidgen/engine/trainer.py:79-87): forward, backward, every ACCUMULATION_STEPS
+    `optimizer.step()` then `optimizer.zero_grad()` -- no join call.  The reducer must behave like torch DDP
+    there: every backward averages, the step sees averaged gradients."""
+    from lvt_amd.engine.grad_reducer import BucketedGradReducer
+    out = {}
+    for acc, set_to_none in ((1, True), (2, True), (2, False), (3, True)):
+        torch.manual_seed(5)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 10), torch.nn.Tanh(), torch.nn.Linear(10, 3))
+        red = BucketedGradReducer(net.parameters(), bucket_bytes=128)
+        opt = torch.optim.SGD(net.parameters(), lr=0.1)
+        seen = []
+        for it in range(2 * acc):
+            g = torch.Generator().manual_seed(1000 * it + rank)
+            x = torch.randn(4, 6, generator=g)
+            if it > 0:
+                red.wait()              # what the meta-architecture's forward does (finish_gradient_sync)
+            net(x).pow(2).sum().backward()
+            if (it + 1) % acc == 0:
+                opt.step()              # pre-step hook joins the all-reduce
+                seen.append([p.grad.clone() for p in net.parameters()])
+                opt.zero_grad(set_to_none=set_to_none)
+        out[(acc, set_to_none)] = ([p.detach().clone() for p in net.parameters()], seen)
+        red.remove()
+    return out
+
+
+def test_reference_loop_with_accumulation_matches_big_batch():
+    res = _run(_reference_loop_case)
+    for key in res[0]:
+        acc, _ = key
+        wa, ga = res[0][key]
+        wb, gb = res[1][key]
+        for a, b in zip(wa, wb):
+            assert torch.equal(a, b), key                          # replicas stay identical
+        # one process, both ranks' data: gradient = mean over ranks of the per-rank accumulated gradient
+        torch.manual_seed(5)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 10), torch.nn.Tanh(), torch.nn.Linear(10, 3))
+        opt = torch.optim.SGD(net.parameters(), lr=0.1)
+        k = 0
+        for it in range(2 * acc):
+            for rank in range(2):
+                x = torch.randn(4, 6, generator=torch.Generator().manual_seed(1000 * it + rank))
+                (net(x).pow(2).sum() / 2).backward()
+            if (it + 1) % acc == 0:
+                for g1, g2 in zip(ga[k], [p.grad for p in net.parameters()]):
+                    assert torch.allclose(g1, g2, rtol=1e-5, atol=1e-6), key
+                k += 1
+                opt.step()
+                opt.zero_grad()
+        for a, p in zip(wa, net.parameters()):
+            assert torch.allclose(a, p.detach(), rtol=1e-5, atol=1e-6), key
 
 
 def _ema_case(rank, world):

@@ -91,3 +91,87 @@ def test_vqvae_two_ranks_equal_one_big_batch():
         assert rel_err(a["cb"][k], one[k]) < 1e-5, k
     mean_loss = 0.5 * (a["loss"]["loss_reconstruction"] + b["loss"]["loss_reconstruction"])
     assert abs(mean_loss - float(losses["loss_reconstruction"].detach())) < 1e-5 * mean_loss
+
+
+# ---- BASELINE configs[3]: DSFVT on Kinetics codes (configs/vt/KDSFVT.yaml), data parallel -------------------------
+def _vt_cfg(acc):
+    from lvt_amd.config import get_cfg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(root, "configs/vt/KDSFVT.yaml"))
+    cfg.MODEL.DEVICE = "cuda:0"
+    cfg.OUTPUT_DIR = "/tmp/lvt_test_out_dp"
+    cfg.SOLVER.ACCUMULATION_STEPS = acc
+    cfg.SOLVER.MAX_ITER = 2 * acc
+    cfg.SOLVER.CHECKPOINT_PERIOD = 10 ** 6
+    return cfg
+
+
+def _vt_batches(cfg, ranks, per_rank, iters):
+    """Deterministic mapper output: micro-step `it` of rank r = clips seeded by (it, r) with forced slice offsets."""
+    from lvt_amd.data.dataset_mapper import prepare_slices
+    v = cfg.MODEL.AUTOREGRESSIVE.VT
+    for it in range(iters):
+        batch = []
+        for r in ranks:
+            g = torch.Generator().manual_seed(977 * it + 31 * r + 5)
+            for j in range(per_rank):
+                codes = torch.randint(0, v.NV, (16, v.NC, 16, 16), generator=g)
+                a = int(torch.randint(v.N_PRIME, 16, (1,), generator=g))
+                batch.append(prepare_slices(codes, (a, 0, 0), v.STRIDE, v.KERNEL, v.N_PRIME, v.PAD_VALUE))
+        yield batch
+
+
+def _vt_train(cfg, ranks, per_rank, seed):
+    """The product Trainer -- the reference's loop shape (vidgen/engine/trainer.py:79-87): forward, backward,
+    every ACCUMULATION_STEPS step + zero_grad; NO gradient-sync call anywhere."""
+    from lvt_amd.engine.trainer import Trainer
+    from lvt_amd.modeling import build_model
+    torch.manual_seed(seed)
+    model = build_model(cfg)
+    tr = Trainer(cfg, model, _vt_batches(cfg, ranks, per_rank, cfg.SOLVER.MAX_ITER), log_period=10 ** 6)
+    last = tr.train()
+    torch.cuda.synchronize()
+    sd = model.model.state_dict()
+    keys = ["encoder.conv.weight", "decoder.block_local_attention.7.mha.w_q", "decoder.block_local_attention.0.dh_bank",
+            "encoder.block_local_attention.3.ffn.1.weight", "ch_predictor.U.2.weight", "ch_predictor.P.0.bias",
+            "decoder.ch_embedder.1.weight"]
+    return {k: sd[k].detach().cpu() for k in keys if k in sd}, float(last["loss_cross_entropy"].detach()), sorted(sd)
+
+
+def _vt_worker(rank, world, port, acc, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = _vt_train(_vt_cfg(acc), [rank], 2, 300 + rank)           # ranks start from different weights
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("acc", [1, 2])
+def test_kdsfvt_two_ranks_reference_loop_equals_one_big_batch(acc):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_vt_worker, args=(r, 2, port, acc, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    (wa, la, keys), (wb, lb, _) = ret[0], ret[1]
+    assert len(wa) >= 6, keys
+    for k in wa:                                    # replicas identical after two optimizer steps
+        assert torch.equal(wa[k], wb[k]), k
+    one, l1, _ = _vt_train(_vt_cfg(acc), [0, 1], 2, 300)                      # rank 0's weights, both ranks' data
+    for k in wa:
+        moved = float((one[k] - wa[k]).abs().max())
+        assert rel_err(wa[k], one[k]) < 2e-4, (k, moved)
+    assert abs(0.5 * (la + lb) - l1) < 1e-4 * abs(l1)

@@ -26,7 +26,7 @@ def test_codes_extractor_mse_and_reload(tmp_path):
     res = inference_on_dataset(model, loader, build_evaluator(cfg, "bair_test_seq"))
     rec, lat = O.vqvae_inference(enc, dec, st, torch.cat(clips), MEAN, STD)
     ref_mse = float(F.mse_loss(rec, torch.cat(clips)))
-    assert abs(res["reconstruction"]["mse"] - ref_mse) < 1e-4 * ref_mse
+    assert abs(res["reconstruction"]["MSE"] - ref_mse) < 1e-4 * ref_mse
     vids = list_latent_videos(os.path.join(str(tmp_path), "inference", "bair_test_seq"))
     assert len(vids) == 3 and len(vids[0][1]) == 16
     codes = load_video_codes(*vids[1])

@@ -53,8 +53,13 @@ def test_generate_videos_on_example_frames(tmp_path, golden):
     out = str(tmp_path / "sample")
     # restrict the sampled region for the smoke test: generate 2 frames (frames 5 and 6), keep the rest primed
     log = _run(["scripts/generate_videos.py", "--video-dir", str(vdir), "--config-file", "configs/vt/DSFVT.yaml",
-                "OUTPUT_DIR", out], timeout=1500)
+                "--random-weights", "OUTPUT_DIR", out], timeout=1500)
     assert "Sampled new video." in log and "Saved new video" in log
+    # without the flag a configured-but-absent checkpoint is an error, not a silent run on random weights
+    r = subprocess.run([sys.executable, "scripts/generate_videos.py", "--video-dir", str(vdir), "--config-file",
+                        "configs/vt/DSFVT.yaml", "OUTPUT_DIR", out], cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "not found" in r.stderr
     pngs = sorted(os.listdir(out), key=lambda f: int(f.split(".")[0]))
     assert pngs == ["%d.png" % i for i in range(16)]
     img = np.asarray(Image.open(os.path.join(out, "7.png")))

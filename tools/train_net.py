@@ -15,6 +15,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+import random
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -59,6 +61,7 @@ def setup(args):
     seed = cfg.SEED if cfg.SEED >= 0 else 0
     torch.manual_seed(seed + comm.get_rank())            # per-rank seed, defaults.py:113
     np.random.seed(seed + comm.get_rank())
+    random.seed(seed + comm.get_rank())                  # DatasetMapper draws windows / slices with `random`
     return cfg
 
 
