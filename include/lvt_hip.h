@@ -253,6 +253,17 @@ int lvt_onehot_tn_gemm(const long long *idx, int nslots, int V, const int *slot_
 int lvt_permute3(const float *in, long long s0, long long s1, long long s2, int n0, int n1, int n2,
                  float *out, void *stream);
 
+/* ---- subscale slice / context builder for a batch of code clips (DatasetMapper.prepare_slices,
+ * vidgen/data/dataset_mapper.py:113-149 with vt_utils.py:24-57,104-128; the reference runs it per sample in CPU
+ * data-loader workers).  video (B,T,nc,H,W) int64, abc (B,3) int32 slice offsets on the device.  Outputs:
+ * ctx (B,nc,Tc,Hc,Wc) with Xc = 2*(kx/2) + (X/sx - 1)*sx + 1 -- the clip masked to the slices generated before (a,b,c)
+ * and shifted so that a (kt,kh,kw)/(st,sh,sw) conv is centred on the slice's first element, `pad_value` elsewhere;
+ * slice (B,nc,T/st,H/sh,W/sw); slice_idx (B) = raster index of (a,b,c); ignore (B,1,T/st,H/sh,W/sw) bytes =
+ * frame < n_prime.                                                                                       */
+int lvt_slice_context(const long long *video, int B, int T, int nc, int H, int W, const int *abc, int st, int sh,
+                      int sw, int kt, int kh, int kw, int n_prime, long long pad_value, long long *ctx,
+                      long long *slice, long long *slice_idx, unsigned char *ignore, void *stream);
+
 /* ---- cross entropy with ignore_index (F.cross_entropy; vt.py:305-313; K26) ---------------------------
  * rows = B*P rows of V logits; target(b,pos) = target[b*tstride_b + pos*tstride_pos].
  * loss[0] = scale * mean_{non-ignored}(lse - logit[target]); count[0] = #non-ignored.                  */

@@ -392,3 +392,76 @@ extern "C" int lvt_layernorm_bwd(const float *dy, const float *x, const float *m
     LVT_CHECK_LAUNCH("lvt_rowsum_partials_kernel");
     return LVT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Subscale slice / context builder for a batch of code clips (reference: DatasetMapper.prepare_slices,
+// vidgen/data/dataset_mapper.py:113-149 with vt_utils.py:24-57,104-128 -- per sample on the CPU there).
+// One thread per output element; every output is a pure index function of (sample offset (a,b,c), position):
+//   slice [b][ch][ti][hi][wi] = video[b][ti*st + a][ch][hi*sh + bo][wi*sw + c]
+//   ctx   [b][ch][ot][oh][ow] = video at (ot - kt/2 + a, oh - kh/2 + bo, ow - kw/2 + c) when that position is inside the
+//                               clip AND belongs to a slice generated strictly before (a,bo,c) in raster order of the
+//                               offsets, else pad_value   (ss_shift of the visibility-masked clip)
+//   ignore[b][0][ti][hi][wi] = (ti*st + a) < n_prime ;  slice_idx[b] = (a*sh + bo)*sw + c
+// ------------------------------------------------------------------------------------------------
+struct SliceGeom { int B, T, nc, H, W, st, sh, sw, kt, kh, kw, n_prime, t, h, w, Tc, Hc, Wc; long long pad; };
+__global__ void lvt_slice_context_kernel(const long long *__restrict__ video, const int *__restrict__ abc, SliceGeom g,
+                                         long long *__restrict__ ctx, long long *__restrict__ slice,
+                                         long long *__restrict__ slice_idx, unsigned char *__restrict__ ignore) {
+    const long long n_ctx = (long long)g.B * g.nc * g.Tc * g.Hc * g.Wc;
+    const long long n_sl = (long long)g.B * g.nc * g.t * g.h * g.w;
+    const long long n_ig = (long long)g.B * g.t * g.h * g.w;
+    const long long total = n_ctx + n_sl + n_ig + g.B;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        if (i < n_ctx) {
+            long long r = i;
+            const int ow = r % g.Wc; r /= g.Wc;
+            const int oh = r % g.Hc; r /= g.Hc;
+            const int ot = r % g.Tc; r /= g.Tc;
+            const int ch = r % g.nc; const int b = r / g.nc;
+            const int a = abc[3 * b], bo = abc[3 * b + 1], c = abc[3 * b + 2];
+            const int ti = ot - g.kt / 2 + a, hi = oh - g.kh / 2 + bo, wi = ow - g.kw / 2 + c;
+            long long v = g.pad;
+            if ((unsigned)ti < (unsigned)g.T && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) {
+                const int mine = ((ti % g.st) * g.sh + (hi % g.sh)) * g.sw + (wi % g.sw);
+                if (mine < (a * g.sh + bo) * g.sw + c)
+                    v = video[((((long long)b * g.T + ti) * g.nc + ch) * g.H + hi) * g.W + wi];
+            }
+            ctx[i] = v;
+        } else if (i < n_ctx + n_sl) {
+            long long r = i - n_ctx;
+            const int wi = r % g.w; r /= g.w;
+            const int hi = r % g.h; r /= g.h;
+            const int ti = r % g.t; r /= g.t;
+            const int ch = r % g.nc; const int b = r / g.nc;
+            const int a = abc[3 * b], bo = abc[3 * b + 1], c = abc[3 * b + 2];
+            slice[i - n_ctx] = video[((((long long)b * g.T + ti * g.st + a) * g.nc + ch) * g.H + hi * g.sh + bo) * g.W + wi * g.sw + c];
+        } else if (i < n_ctx + n_sl + n_ig) {
+            long long r = i - n_ctx - n_sl;
+            r /= (long long)g.h * g.w;
+            const int ti = r % g.t; const int b = r / g.t;
+            ignore[i - n_ctx - n_sl] = (ti * g.st + abc[3 * b]) < g.n_prime ? 1 : 0;
+        } else {
+            const int b = (int)(i - n_ctx - n_sl - n_ig);
+            slice_idx[b] = (abc[3 * b] * g.sh + abc[3 * b + 1]) * g.sw + abc[3 * b + 2];
+        }
+    }
+}
+extern "C" int lvt_slice_context(const long long *video, int B, int T, int nc, int H, int W, const int *abc, int st, int sh,
+                                 int sw, int kt, int kh, int kw, int n_prime, long long pad_value, long long *ctx,
+                                 long long *slice, long long *slice_idx, unsigned char *ignore, void *stream) {
+    LVT_REQUIRE(video && abc && ctx && slice && slice_idx && ignore, "slice_context: null pointer");
+    LVT_REQUIRE(B > 0 && nc > 0 && st > 0 && sh > 0 && sw > 0 && T % st == 0 && H % sh == 0 && W % sw == 0 &&
+                kt > 0 && kh > 0 && kw > 0, "slice_context: bad geometry");
+    SliceGeom g;
+    g.B = B; g.T = T; g.nc = nc; g.H = H; g.W = W; g.st = st; g.sh = sh; g.sw = sw; g.kt = kt; g.kh = kh; g.kw = kw;
+    g.n_prime = n_prime; g.pad = pad_value;
+    g.t = T / st; g.h = H / sh; g.w = W / sw;
+    // extent of the shifted clip: 2*(k/2) + (n/s - 1)*s + 1 per dimension, whatever the offset (vt_utils.py:104-128)
+    g.Tc = 2 * (kt / 2) + (g.t - 1) * st + 1; g.Hc = 2 * (kh / 2) + (g.h - 1) * sh + 1; g.Wc = 2 * (kw / 2) + (g.w - 1) * sw + 1;
+    const long long total = (long long)B * nc * g.Tc * g.Hc * g.Wc + (long long)B * (nc + 1) * g.t * g.h * g.w + B;
+    const int blocks = (int)(lvt_cdiv(total, 256) < 4096 ? lvt_cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(lvt_slice_context_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, video, abc, g, ctx, slice,
+                       slice_idx, ignore);
+    LVT_CHECK_LAUNCH("lvt_slice_context_kernel");
+    return LVT_OK;
+}

@@ -42,7 +42,11 @@ def draw_abc(stride, t_slice, n_prime, rng=random):
 
 def prepare_slices_batch(videos_btchw, abcs, stride, kernel, n_prime, pad_value=-1):
     """Batched, device-side builder: videos (B, T, nc, H, W) int64 on any device, abcs list of (a,b,c).
-    Returns stacked (context, slice, slice_idx, ignore_mask) ready for compute_supervised_loss."""
+    Returns stacked (context, slice, slice_idx, ignore_mask) ready for compute_supervised_loss.
+    On a GPU this is ONE launch of `lvt_slice_context` (a pure index gather); the torch-indexing form below serves
+    host tensors (data-loader workers, as in the reference)."""
+    if videos_btchw.is_cuda:
+        return _prepare_slices_batch_hip(videos_btchw, abcs, stride, kernel, n_prime, pad_value)
     st, sh, sw = stride
     video = videos_btchw.transpose(1, 2)
     B, nc, T, H, W = video.shape
@@ -67,6 +71,26 @@ def prepare_slices_batch(videos_btchw, abcs, stride, kernel, n_prime, pad_value=
     cat = lambda xs: torch.cat(xs, 0).index_select(0, inv).contiguous()     # noqa: E731
     sidx = torch.tensor([abc2idx[tuple(x)] for x in abcs], dtype=torch.long, device=video.device)
     return cat(ctxs).long(), cat(sls).long(), sidx, cat(igs)
+
+
+def _prepare_slices_batch_hip(videos, abcs, stride, kernel, n_prime, pad_value):
+    from ..hip import binding as L
+    videos = videos.long().contiguous()
+    B, T, nc, H, W = videos.shape
+    (st, sh, sw), (kt, kh, kw) = stride, kernel
+    assert T % st == 0 and H % sh == 0 and W % sw == 0
+    dev = videos.device
+    abc = torch.as_tensor([list(x) for x in abcs], dtype=torch.int32).to(dev, non_blocking=True)
+    t, h, w = T // st, H // sh, W // sw
+    tc, hc, wc = 2 * (kt // 2) + (t - 1) * st + 1, 2 * (kh // 2) + (h - 1) * sh + 1, 2 * (kw // 2) + (w - 1) * sw + 1
+    ctx = torch.empty(B, nc, tc, hc, wc, dtype=torch.int64, device=dev)
+    sl = torch.empty(B, nc, t, h, w, dtype=torch.int64, device=dev)
+    sidx = torch.empty(B, dtype=torch.int64, device=dev)
+    ign = torch.empty(B, 1, t, h, w, dtype=torch.bool, device=dev)
+    L.check(L.lib().lvt_slice_context(L.ptr(videos), B, T, nc, H, W, L.ptr(abc), st, sh, sw, kt, kh, kw, n_prime,
+                                      pad_value, L.ptr(ctx), L.ptr(sl), L.ptr(sidx), L.ptr(ign), L.stream_ptr()),
+            "lvt_slice_context")
+    return ctx, sl, sidx, ign
 
 
 class DatasetMapper:

@@ -79,6 +79,22 @@ class MultiHeadAttention(nn.Module):
         init.xavier_normal_(self.w_v)
         init.xavier_normal_(self.proj.weight)
 
+    def packed_qkv(self):
+        """One (3, na, d, da) buffer whose slices ARE w_q / w_k / w_v (the parameters keep their names, shapes and
+        state_dict entries): the three projections, their data gradient and their weight gradient then run as one
+        engine launch each.  `.to(device)` / a foreign `.data =` breaks the aliasing; it is re-established here."""
+        ws = (self.w_q, self.w_k, self.w_v)
+        buf = getattr(self, "_wqkv", None)
+        n = self.w_q.numel()
+        if (buf is None or buf.device != self.w_q.device or
+                any(w.data_ptr() != buf.data_ptr() + 4 * n * i for i, w in enumerate(ws))):
+            with torch.no_grad():
+                buf = torch.stack([w.detach() for w in ws], 0).contiguous()
+                for i, w in enumerate(ws):
+                    w.data = buf[i]
+            self._wqkv = buf
+        return buf
+
 
 def _splits(tiles, k):
     """split-K factor: one full wave of workgroups (2 resident per CU -> 512 slots), >= 512 rows each.  Measured on
@@ -109,7 +125,8 @@ FUSED_ATTENTION = True      # scores + bias + mask + softmax + P.V in one launch
 
 class _BlockLocalAttentionFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, block, masked, dt, dh, dw, ln_w, ln_b, w_q, w_k, w_v, proj_w, f0w, f0b, f1w, f1b, f3w, f3b):
+    def forward(ctx, x, block, masked, dt, dh, dw, ln_w, ln_b, w_q, w_k, w_v, proj_w, f0w, f0b, f1w, f1b, f3w, f3b,
+                wqkv):
         L.require(x)
         M, d = x.shape
         S = block[0] * block[1] * block[2]
@@ -119,12 +136,11 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         temper = math.sqrt(da)
         dev = x.device
         xn, mean1, rstd1 = ew.layernorm_fwd(x, ln_w, ln_b)
-        qkv = []
-        for w in (w_q, w_k, w_v):
-            out = torch.empty(M, hd, dtype=torch.float32, device=dev)
-            G.gemm(xn, w, out, M, da, d, ta=0, tb=1, lda=d, ldb=da, ldc=hd, batch_inner=na, sB=(0, d * da), sC=(0, da))
-            qkv.append(out)
-        q, k, v = qkv
+        # q, k, v of all heads in ONE launch: 3 x na batches of (M x da x d) against the packed weights, C = (3, M, hd)
+        qkv = torch.empty(3, M, hd, dtype=torch.float32, device=dev)
+        G.gemm(xn, wqkv, qkv, M, da, d, ta=0, tb=1, lda=d, ldb=da, ldc=hd, batch_outer=3, batch_inner=na,
+               sB=(na * d * da, d * da), sC=(M * hd, da))
+        q, k, v = qkv[0], qkv[1], qkv[2]
         if FUSED_ATTENTION and tx.attn_fwd_supported(S, da):
             P, o = tx.attn_fwd(q, k, v, b, na, S, da, temper, dt, dh, dw, block, masked)
         else:
@@ -142,15 +158,16 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         G.gemm(fn, f1w, h1, M, f1w.shape[0], d, flags=L.EPI_BIAS | L.EPI_RELU, bias=f1b)
         y2 = torch.empty(M, d, dtype=torch.float32, device=dev)
         G.gemm(h1, f3w, y2, M, d, f3w.shape[1], flags=L.EPI_BIAS | L.EPI_RESIDUAL, bias=f3b, res=y1)
-        ctx.save_for_backward(x, mean1, rstd1, xn, q, k, v, P, o, y1, mean2, rstd2, fn, h1,
-                              ln_w, w_q, w_k, w_v, proj_w, f0w, f1w, f3w)
+        ctx.save_for_backward(x, mean1, rstd1, xn, qkv, P, o, y1, mean2, rstd2, fn, h1,
+                              ln_w, wqkv, proj_w, f0w, f1w, f3w)
         ctx.block, ctx.dims = block, (M, d, S, b, na, da)
         return y2
 
     @staticmethod
     def backward(ctx, dy2):
-        (x, mean1, rstd1, xn, q, k, v, P, o, y1, mean2, rstd2, fn, h1,
-         ln_w, w_q, w_k, w_v, proj_w, f0w, f1w, f3w) = ctx.saved_tensors
+        (x, mean1, rstd1, xn, qkv, P, o, y1, mean2, rstd2, fn, h1,
+         ln_w, wqkv, proj_w, f0w, f1w, f3w) = ctx.saved_tensors
+        q, k, v = qkv[0], qkv[1], qkv[2]
         M, d, S, b, na, da = ctx.dims
         hd = na * da
         temper = math.sqrt(da)
@@ -171,33 +188,30 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         dproj = linear_wgrad(dy1, o, d, hd, M)
         # attention core
         bh = dict(batch_outer=b, batch_inner=na)
-        dv = torch.empty(M, hd, dtype=torch.float32, device=dev)
+        dqkv = torch.empty(3, M, hd, dtype=torch.float32, device=dev)
+        dq, dk, dv = dqkv[0], dqkv[1], dqkv[2]
         G.gemm(P, do, dv, S, da, S, ta=1, tb=1, lda=S, ldb=hd, ldc=hd, sA=(na * S * S, S * S), sB=(S * hd, da),
                sC=(S * hd, da), **bh)
         dP = torch.empty(b, na, S, S, dtype=torch.float32, device=dev)
         G.gemm(do, v, dP, S, S, da, ta=0, tb=0, lda=hd, ldb=hd, ldc=S, sA=(S * hd, da), sB=(S * hd, da),
                sC=(na * S * S, S * S), **bh)
         ddt, ddh, ddw = tx.attn_softmax_bwd_(P, dP, temper, ctx.block)       # dP now holds dS
-        dq = torch.empty(M, hd, dtype=torch.float32, device=dev)
         G.gemm(dP, k, dq, S, da, S, ta=0, tb=1, lda=S, ldb=hd, ldc=hd, sA=(na * S * S, S * S), sB=(S * hd, da),
                sC=(S * hd, da), **bh)
-        dk = torch.empty(M, hd, dtype=torch.float32, device=dev)
         G.gemm(dP, q, dk, S, da, S, ta=1, tb=1, lda=S, ldb=hd, ldc=hd, sA=(na * S * S, S * S), sB=(S * hd, da),
                sC=(S * hd, da), **bh)
         del dP
-        # per-head projections: q = xn w_q[h]
+        # per-head projections q = xn w_q[h] (k, v alike), all three at once: the data gradient is one GEMM whose
+        # reduction runs over (projection, head, da) = 3*hd -- A walks the (3, M, hd) gradient with a 2-level k,
+        # B the packed (3, na, d, da) weights -- and the weight gradient one launch of 3 x na batches
         dxn = torch.empty(M, d, dtype=torch.float32, device=dev)
-        dws = []
-        for i, (g_, w) in enumerate(((dq, w_q), (dk, w_k), (dv, w_v))):
-            G.gemm(g_, w, dxn, M, d, hd, ta=0, tb=0, lda=hd, ldb=da, b_kb=da, b_skb=d * da,
-                   flags=L.EPI_ACCUM if i else 0)
-            dwh = torch.empty(na, d, da, dtype=torch.float32, device=dev)
-            G.gemm(xn, g_, dwh, d, da, M, ta=1, tb=1, lda=d, ldb=hd, ldc=da, batch_inner=na, sB=(0, da),
-                   sC=(0, d * da), splits=_splits(na * -(-d // 128), M))
-            dws.append(dwh)
+        G.gemm(dqkv, wqkv, dxn, M, d, 3 * hd, ta=0, tb=0, lda=hd, a_kb=hd, a_skb=M * hd, ldb=da, b_kb=da, b_skb=d * da)
+        dws = torch.empty(3, na, d, da, dtype=torch.float32, device=dev)
+        G.gemm(xn, dqkv, dws, d, da, M, ta=1, tb=1, lda=d, ldb=hd, ldc=da, batch_outer=3, batch_inner=na,
+               sB=(M * hd, da), sC=(na * d * da, d * da), splits=_splits(3 * na * -(-d // 128), M))
         dx, dlnw, dlnb = ew.layernorm_bwd(dxn, x, mean1, rstd1, ln_w, add=dy1)
         return (dx, None, None, ddt, ddh, ddw, dlnw, dlnb, dws[0], dws[1], dws[2], dproj, df0w, df0b,
-                df1w, df1b, df3w, df3b)
+                df1w, df1b, df3w, df3b, None)
 
 
 class BlockLocalAttention(nn.Module):
@@ -243,7 +257,7 @@ class BlockLocalAttention(nn.Module):
         y = _BlockLocalAttentionFn.apply(
             x_tok, self.block_size, self.masked, self.dt_bank, self.dh_bank, self.dw_bank,
             m.layer_norm.weight, m.layer_norm.bias, m.w_q, m.w_k, m.w_v, m.proj.weight,
-            f[0].weight, f[0].bias, f[1].weight, f[1].bias, f[3].weight, f[3].bias)
+            f[0].weight, f[0].bias, f[1].weight, f[1].bias, f[3].weight, f[3].bias, m.packed_qkv())
         if split:
             y = _RowPermuteFn.apply(y, inv, perm, S)
         return y

@@ -9,6 +9,7 @@ from oracle import lvt_oracle as O
 from util_models import MEAN, STD, dsfvt_cfg, vqvae_seeded
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
 DS = dict(blocks_e=((1, 16, 16),) * 8, blocks_d=((1, 16, 16),) * 8, stride=(16, 1, 1))
 
 
@@ -89,3 +90,40 @@ def test_dsfvt_all_positions_ignored_slice0_is_never_trained():
     tgt = torch.full((1, 4, 256), -100, dtype=torch.int64, device="cuda:0")
     loss, _, cnt = tx.xent_fwd(logits, tgt[0, 0], 1024, 1, 256, -100, 1.0)
     assert float(cnt) == 0.0 and bool(torch.isnan(loss))
+
+
+@pytest.mark.parametrize("tag,stride,kernel", [("g8", (16, 1, 1), (7, 1, 1)), ("g15_dssvt", (1, 2, 2), (1, 3, 3)),
+                                               ("g16_dstsvt", (4, 2, 2), (5, 3, 3))])
+def test_slice_context_kernel_equals_reference_mapper(golden, tag, stride, kernel):
+    """`lvt_slice_context` run ON THE DEVICE against what the reference's DatasetMapper produced (fixtures G8, G15,
+    G16: contexts / slices / slice indices / ignore masks captured from the real reference), and against the
+    per-sample host builder for every slice offset of the geometry."""
+    import itertools
+    from lvt_amd.data.dataset_mapper import prepare_slices, prepare_slices_batch
+    if tag == "g8":
+        g = golden("g8_mapper")
+        aa = (1, 2, 5, 9, 15)
+        codes = torch.stack([g["codes"]] * len(aa))
+        abcs = [(a, 0, 0) for a in aa]
+        want = {k: torch.stack([g["a%d_%s" % (a, k)] for a in aa]) for k in ("context", "slice", "slice_idx", "ignore_mask")}
+    else:
+        g = golden(tag)
+        codes = g["codes"]
+        abcs = [tuple(int(x) for x in g["abc"][i]) for i in range(codes.shape[0])]
+        ds = [prepare_slices(codes[i].numpy(), abcs[i], stride, kernel, 1, -1) for i in range(len(abcs))]
+        want = {"context": g["context"], "slice_idx": g["slice_idx"],
+                "slice": torch.stack([d["slice"] for d in ds]), "ignore_mask": torch.stack([d["ignore_mask"] for d in ds])}
+    ctx, sl, sidx, ign = prepare_slices_batch(codes.to(DEV), abcs, stride, kernel, 1, -1)
+    assert ctx.is_cuda and ctx.dtype == torch.int64 and ign.dtype == torch.bool
+    assert torch.equal(ctx.cpu(), want["context"]) and torch.equal(sl.cpu(), want["slice"])
+    assert torch.equal(sidx.cpu(), want["slice_idx"]) and torch.equal(ign.cpu(), want["ignore_mask"])
+    # every offset of the geometry, several clips, n_prime 3, another pad value: device kernel == host builder
+    T = 16 if stride[0] != 1 else 4
+    vids = torch.randint(0, 512, (3, T, 4, 16, 16), generator=torch.Generator().manual_seed(11))
+    for abc in itertools.product(range(stride[0]), range(stride[1]), range(stride[2])):
+        if stride == (16, 1, 1) and abc[0] % 5:
+            continue
+        dev = prepare_slices_batch(vids.to(DEV), [abc] * 3, stride, kernel, 3, -7)
+        host = prepare_slices_batch(vids, [abc] * 3, stride, kernel, 3, -7)
+        for a_, b_ in zip(dev, host):
+            assert a_.shape == b_.shape and torch.equal(a_.cpu(), b_), abc

@@ -146,7 +146,10 @@ def test_g5_supervised_loss_and_grads(golden, tag):
         rows = z[:, 64 * i:64 * (i + 1)].permute(0, 2, 3, 1).reshape(-1, 64)
         ok = margin_ok(rows, st0["ve.%d.embedding.weight" % i], rel=1e-4).view(-1, 16, 16)
         assert torch.equal(mine[:, i][ok], theirs[:, i][ok])
-    assert flips <= 2, flips
+    # The fixture is deterministic, so is the kernel: the number of sub-margin rows on which MI355X and the CPU
+    # reference pick different codes is pinned (measured on the GPU box: none), so that no part of this test can be
+    # switched off silently by a flip.
+    assert flips == 0, flips
     # ---- gradients: accuracy is judged against an fp64 evaluation of the same graph (same indices).
     # The HIP path must be as close to fp64 as the CPU fp32 path is (x4 slack): the differences between
     # two fp32 evaluations of this deep chain are roundoff amplified by cancellation (z_e - z_q) and by
@@ -162,19 +165,16 @@ def test_g5_supervised_loss_and_grads(golden, tag):
         assert e_mine < max(4 * e_cpu, 2e-5), (n, e_mine, e_cpu)
         assert float((got.double().cpu() - ref).norm() / ref.norm()) < 1e-3, n
     # ---- and against the golden vectors captured from the reference (same indices only) ---------------
-    if flips == 0:
-        for got, key in ((E["layers.0.weight"], "grad_enc_first"), (E["layers.0.bias"], "grad_enc_first_bias"),
-                         (E["layers.6.block.3.weight"], "grad_enc_last"), (G["layers.6.weight"], "grad_dec_last"),
-                         (G["layers.6.bias"], "grad_dec_last_bias")):
-            assert rel_err(got.grad, g[key]) < 5e-3, key
-        assert rel_err(E["layers.4.weight"].grad[:8], g["grad_enc_mid_rows"]) < 5e-3
-        assert rel_err(G["layers.0.weight"].grad[:8], g["grad_dec_first_rows"]) < 5e-3
-        assert rel_err(G["layers.4.weight"].grad[:4], g["grad_dec_ct1_rows"]) < 5e-3
-        names = [str(n) for n in g["grad_names"]]
-        got = torch.tensor([float((G[n[2:]] if n.startswith("G.") else E[n]).grad.norm()) for n in names])
-        assert float(((got - g["grad_norms"]).abs() / g["grad_norms"]).max()) < 1e-3
-    else:
-        return
+    for got, key in ((E["layers.0.weight"], "grad_enc_first"), (E["layers.0.bias"], "grad_enc_first_bias"),
+                     (E["layers.6.block.3.weight"], "grad_enc_last"), (G["layers.6.weight"], "grad_dec_last"),
+                     (G["layers.6.bias"], "grad_dec_last_bias")):
+        assert rel_err(got.grad, g[key]) < 5e-3, key
+    assert rel_err(E["layers.4.weight"].grad[:8], g["grad_enc_mid_rows"]) < 5e-3
+    assert rel_err(G["layers.0.weight"].grad[:8], g["grad_dec_first_rows"]) < 5e-3
+    assert rel_err(G["layers.4.weight"].grad[:4], g["grad_dec_ct1_rows"]) < 5e-3
+    names = [str(n) for n in g["grad_names"]]
+    got = torch.tensor([float((G[n[2:]] if n.startswith("G.") else E[n]).grad.norm()) for n in names])
+    assert float(((got - g["grad_norms"]).abs() / g["grad_norms"]).max()) < 1e-3
     new = model.codebook.state_dict()
     for k in ("embedding.weight", "running_size", "running_sum"):
         assert rel_err(new["ve.0." + k], g["new.ve.0." + k]) < 1e-5, k
