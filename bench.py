@@ -2,7 +2,7 @@
 """Headline benchmark: PR-DVQVAE2 train step on synthetic BAIR-shaped clips (64x64x16), batch 32 clips
 per GPU, fp32, on N MI355X of one node (BASELINE.json `configs[1]`, metric video-clips/s/node).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -58,8 +58,9 @@ PEAK_NOTE = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batches", type=int, default=4, help="distinct synthetic batches rotated through the steps")
     ap.add_argument("--batch-clips", type=int, default=32, help="clips per GPU per step (BASELINE: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dsfvt", action="store_true", help="skip the secondary DSFVT train-step figure")
@@ -69,6 +70,58 @@ def parse():
     ap.add_argument("--no-strict-f32", action="store_true", help="skip the secondary LVT_MATH=f32 figure")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
+
+
+def _pct(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    pos = q * (len(xs) - 1)
+    lo = int(pos)
+    hi = min(lo + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (pos - lo)
+
+
+def step_stats(events):
+    """Per-step durations from HIP events recorded on the launch stream at the step boundaries (one event per step:
+    18+ ms apart, so the barrier packet an event inserts is not measurable)."""
+    ms = [events[i].elapsed_time(events[i + 1]) for i in range(len(events) - 1)]
+    return {"median_ms": round(_pct(ms, 0.5), 3), "p10_ms": round(_pct(ms, 0.1), 3), "p90_ms": round(_pct(ms, 0.9), 3),
+            "n": len(ms)}
+
+
+def timed_steps(step, steps, first_iter, world, device):
+    """The timed region of the contract: barrier + synchronize, EXACTLY `steps` steps, synchronize + barrier; MAX over
+    ranks.  Returns (seconds, per-step stats, last step's result)."""
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    events = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    events[0].record()
+    out = None
+    for i in range(steps):
+        out = step(first_iter + i)
+        events[i + 1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    return float(el.item()), step_stats(events), out
+
+
+def traffic_from_profile(name):
+    """HBM bytes per engine launch from this round's committed PMC passes (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in
+    separate runs of this command, summarised by scratch/pmc_summary.py): counters cannot be read inside the run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return round(json.load(f)["hbm_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def build_vqvae(device, seed):
@@ -90,16 +143,30 @@ def vqvae_step(model, optimizers, data, storage_iter):
         losses = model(data, mode="supervised")
     total = sum(losses.values())
     total.backward()
-    for o in optimizers:
+    for o in optimizers:          # (under data parallelism the gradient all-reduce joins itself before step)
         o["optimizer"].step()
     for o in optimizers:
         o["optimizer"].zero_grad()
     return losses
 
 
-def bench_dsfvt(device, world, rank, steps, warmup, batch, strict_f32=True):
-    """Secondary figure: DSFVT train step (fwd + bwd + RMSprop) on synthetic code clips, one random
-    subscale slice per clip (BASELINE.json configs[2]); reported under `extra.dsfvt`."""
+def engine_summary(timer, steps, mode):
+    summ = timer.summary()
+    eng = {k: v for k, v in summ.items() if k.startswith("conv_") or k.startswith("gemm_") or k.startswith("attn_")}
+    tot_ms = sum(v["ms"] for v in eng.values())
+    tot_fl = sum(v["flops"] for v in eng.values())
+    launches = sum(v["launches"] for v in eng.values())
+    achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    per_kind = {k: {"launches_per_step": v["launches"] // steps, "avg_us": round(v["ms"] / v["launches"] * 1e3, 1),
+                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                    "ms_per_step": round(v["ms"] / steps, 3)} for k, v in sorted(eng.items())}
+    return {"achieved": achieved, "ms_per_step": tot_ms / steps, "launches_per_step": launches // steps,
+            "flops_per_launch": tot_fl / max(launches, 1), "per_kind": per_kind, "frac": achieved / engine_peak(mode)}
+
+
+def bench_dsfvt(device, world, rank, steps, warmup, batch, nbatches, strict_f32=True, cpu_seconds=0.0):
+    """Second workload of the metric: DSFVT train step (fwd + bwd + RMSprop) on synthetic code clips, one random
+    subscale slice per clip (BASELINE.json configs[2] / [3]); reported under `extra.dsfvt` with its own roofline block."""
     from lvt_amd.config import get_cfg
     from lvt_amd.data.dataset_mapper import prepare_slices_batch
     from lvt_amd.hip import binding as L
@@ -117,14 +184,17 @@ def bench_dsfvt(device, world, rank, steps, warmup, batch, strict_f32=True):
         model.wrap_parallel(device_ids=[0], broadcast_buffers=False)
     v = cfg.MODEL.AUTOREGRESSIVE.VT
     g = torch.Generator(device="cpu").manual_seed(4321 + rank)
-    codes = torch.randint(0, v.NV, (batch, 16, v.NC, 16, 16), generator=g).to(device)
-    abcs = [(int(a), 0, 0) for a in torch.randint(v.N_PRIME, 16, (batch,), generator=g)]
-    ctx, sl, sidx, ign = prepare_slices_batch(codes, abcs, v.STRIDE, v.KERNEL, v.N_PRIME, v.PAD_VALUE)
+    batches = []
+    for _ in range(nbatches):                      # distinct clips and slice offsets per batch, built on the device
+        codes = torch.randint(0, v.NV, (batch, 16, v.NC, 16, 16), generator=g).to(device)
+        abcs = [(int(a), 0, 0) for a in torch.randint(v.N_PRIME, 16, (batch,), generator=g)]
+        batches.append(prepare_slices_batch(codes, abcs, v.STRIDE, v.KERNEL, v.N_PRIME, v.PAD_VALUE))
 
     def step(i):
+        ctx, sl, sidx, ign = batches[i % nbatches]
         with EventStorage(i):
             loss = model.compute_supervised_loss(ctx, sl, sidx, ign)["loss_cross_entropy"]
-        loss.backward()
+        loss.backward()                            # (the gradient all-reduce joins itself before optimizer.step)
         for o in optimizers:
             o["optimizer"].step()
         for o in optimizers:
@@ -135,54 +205,54 @@ def bench_dsfvt(device, world, rank, steps, warmup, batch, strict_f32=True):
         step(i)
     torch.cuda.synchronize()
     gc.collect()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        loss = step(warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed, stats, loss = timed_steps(step, steps, warmup, world, device)
     L.TIMER = L.KernelTimer()          # instrumented pass (per-launch events), see main()
     for i in range(steps):
         step(warmup + steps + i)
     torch.cuda.synchronize()
     timer, L.TIMER = L.TIMER, None
-    summ = timer.summary()
-    eng_ms = sum(v_["ms"] for v_ in summ.values())
-    eng_fl = sum(v_["flops"] for v_ in summ.values())
+    mode = L.get_math_mode()
+    es = engine_summary(timer, steps, mode)
     out = {"samples_per_s": round(batch * world * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 2),
+           "step_ms": stats, "steps": steps, "warmup": warmup,
            "batch_per_gpu": batch, "loss": round(float(loss.detach()), 5),
-           "engine_tflops": round(eng_fl / (eng_ms * 1e-3) / 1e12, 2) if eng_ms else None,
-           "engine_ms_per_step": round(eng_ms / steps, 2),
-           "engine_frac_of_peak": round(eng_fl / (eng_ms * 1e-3) / 1e12 / engine_peak(L.get_math_mode()), 4) if eng_ms else None,
-           "note": "one subscale slice (256 tokens x 4 code channels) of one 16-frame clip per sample; fp32 data; 49.87M "
-                   "parameters; engine_tflops counts algorithmic fp32 GEMM FLOPs of the engine launches (event-timed "
-                   "in a second pass)"}
+           "engine_tflops": round(es["achieved"], 2), "engine_ms_per_step": round(es["ms_per_step"], 2),
+           "engine_frac_of_peak": round(es["frac"], 4),
+           "roofline": {"bound": "mfma", "achieved": round(es["achieved"], 2), "peak": round(engine_peak(mode), 1),
+                        "unit": "TFLOP/s", "frac": round(es["frac"], 4),
+                        "traffic": traffic_from_profile("r02_dsfvt_pmc_hbm_traffic.json"),
+                        "traffic_unit": "HBM bytes per engine launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate "
+                                        "passes, profiles/r02_dsfvt_pmc_hbm_traffic.txt); algorithmic flops per launch = %.3e"
+                                        % es["flops_per_launch"],
+                        "kernel": "lvt_gemm_kernel<*> (LN'd tokens x packed QKV / proj / FFN weights, their data and weight "
+                                  "gradients, attention-backward GEMMs) + lvt_attn_fwd_kernel; %d launches per step, "
+                                  "event-timed in a second pass of the same %d steps: %.2f ms of engine time"
+                                  % (es["launches_per_step"], steps, es["ms_per_step"]),
+                        "per_kind": es["per_kind"]},
+           "note": "one subscale slice (256 tokens x 4 code channels) of one 16-frame clip per sample, %d distinct batches "
+                   "rotated; fp32 data; 49.87M parameters; `achieved` counts algorithmic fp32 FLOPs of the engine and "
+                   "fused-attention launches (one-hot products are gathers and are not counted)" % nbatches}
     if L.get_math_mode() != "f32" and strict_f32:
-        # MFMA utilisation of the attention / MLP GEMMs on the plain fp32 instruction (target: >= 50 %)
-        mode = L.get_math_mode()
+        # MFMA utilisation of the attention / MLP GEMMs on the plain fp32 instruction
         L.set_math_mode("f32")
         for i in range(2):
             step(i)
         torch.cuda.synchronize()
         L.TIMER = L.KernelTimer()
-        for i in range(steps):
+        n2 = max(3, steps // 3)
+        for i in range(n2):
             step(i)
         torch.cuda.synchronize()
         timer, L.TIMER = L.TIMER, None
         L.set_math_mode(mode)
-        s2 = timer.summary()
-        ms2 = sum(v_["ms"] for v_ in s2.values())
-        fl2 = sum(v_["flops"] for v_ in s2.values())
-        out["strict_f32_mfma"] = {"engine_tflops": round(fl2 / (ms2 * 1e-3) / 1e12, 2),
-                                  "mfma_utilisation": round(fl2 / (ms2 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                                  "note": "LVT_MATH=f32: the same GEMM launches on v_mfma_f32_32x32x2_f32, fraction of "
+        e2 = engine_summary(timer, n2, "f32")
+        out["strict_f32_mfma"] = {"engine_tflops": round(e2["achieved"], 2), "mfma_utilisation": round(e2["frac"], 4),
+                                  "note": "LVT_MATH=f32: the same launches on v_mfma_f32_32x32x2_f32, fraction of "
                                           "the 157.3 TFLOP/s fp32 MFMA peak"}
+    if rank == 0 and world == 1 and cpu_seconds > 0:
+        del model, optimizers, batches
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline_dsfvt(cpu_seconds)
     return out
 
 
@@ -273,6 +343,50 @@ def cpu_baseline(batch_clips, budget_s):
                       "calibration on %d logical CPUs)" % (clips, clips * CLIP_FRAMES, len(times), cores, ncpu)}
 
 
+def cpu_baseline_dsfvt(budget_s):
+    """CPU oracle's DSFVT train step (fwd + bwd + RMSprop as configs/vt/DSFVT.yaml sets it) on this host's cores."""
+    import seeded
+    from oracle import lvt_oracle as O
+    seed, b = 29871897, 4
+    p = {k: v.requires_grad_(True) for k, v in seeded.seeded_params(seeded.dsfvt_shapes(), seed).items()}
+    opt = torch.optim.RMSprop(list(p.values()), lr=2e-5, alpha=0.95, momentum=0.9)
+    block = ((1, 16, 16),) * 8
+    items = [O.prepare_slices(seeded.seeded_codes("cpu.vt%d" % i, (16, 4, 16, 16), seed), (5 + i, 0, 0), (16, 1, 1),
+                              (7, 1, 1), 1) for i in range(b)]
+    ctx, sl = torch.stack([d["context"] for d in items]), torch.stack([d["slice"] for d in items])
+    sidx, ign = torch.stack([d["slice_idx"] for d in items]), torch.stack([d["ignore_mask"] for d in items])
+
+    def step():
+        t0 = time.perf_counter()
+        loss, _ = O.vt_supervised_loss(p, ctx, sl, sidx, ign, block, block, (16, 1, 1))
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        return time.perf_counter() - t0
+
+    ncpu = os.cpu_count() or 1
+    t_start = time.perf_counter()
+    best, best_t = None, None
+    for nt in sorted({min(ncpu, c) for c in (16, 32, 64)}):
+        if time.perf_counter() - t_start > budget_s * 0.5 and best is not None:
+            break
+        torch.set_num_threads(nt)
+        step()
+        dt = step()
+        if best_t is None or dt < best_t:
+            best, best_t = nt, dt
+    torch.set_num_threads(best)
+    times = []
+    while len(times) < 8 and (time.perf_counter() - t_start < budget_s or len(times) < 3):
+        times.append(step())
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": b / med, "unit": "samples/s (= clips/s: one slice of one clip per sample)", "cores": best, "kind": "port",
+            "sample": "oracle (PyTorch-CPU fp32 restatement of the reference path) DSFVT train step, %d samples per step, "
+                      "median of %d steps, %d threads (best of a 16..64 thread calibration on %d logical CPUs)"
+                      % (b, len(times), best, ncpu)}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -291,35 +405,26 @@ def main():
     if world > 1:
         model.wrap_parallel(device_ids=[local_rank], broadcast_buffers=False)
 
-    # synthetic clips, resident in HBM before the timed region
+    # synthetic clips, resident in HBM before the timed region; `--batches` distinct batches are rotated
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    clips = torch.rand(args.batch_clips, CLIP_FRAMES, 3, 64, 64, generator=g).to(device)
-    data = [{"image_sequence": clips[i]} for i in range(args.batch_clips)]
+    batches = []
+    for _ in range(args.batches):
+        clips = torch.rand(args.batch_clips, CLIP_FRAMES, 3, 64, 64, generator=g).to(device)
+        batches.append([{"image_sequence": clips[i]} for i in range(args.batch_clips)])
+
+    def step(i):
+        return vqvae_step(model, optimizers, batches[i % args.batches], i)
 
     for i in range(args.warmup):
-        vqvae_step(model, optimizers, data, i)
+        step(i)
     torch.cuda.synchronize()
     # a full (generation-2) Python GC pass with torch loaded takes 60-70 ms of host time; right after a barrier the
     # host has no lead over the GPU, so one such pause would stall the device for 3 steps' worth of launches
     gc.collect()
     gc.freeze()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
 
     # Pass 1 -- the timed region: exactly K steps, nothing but the product path between the two barriers.
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        losses = vqvae_step(model, optimizers, data, args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed, stats, losses = timed_steps(step, args.steps, args.warmup, world, device)
 
     # Pass 2 -- the same K steps again with a HIP event pair around every engine launch (on the launch stream) for
     # the roofline block.  It is a separate pass because a timing event is a barrier packet: it serialises
@@ -328,7 +433,7 @@ def main():
     L.TIMER = L.KernelTimer()
     t1 = time.perf_counter()
     for i in range(args.steps):
-        vqvae_step(model, optimizers, data, args.warmup + args.steps + i)
+        step(args.warmup + args.steps + i)
     torch.cuda.synchronize()
     instrumented_ms = (time.perf_counter() - t1) / args.steps * 1e3
     timer, L.TIMER = L.TIMER, None
@@ -339,30 +444,20 @@ def main():
         # the same timed region on the plain fp32 MFMA instruction (v_mfma_f32_32x32x2_f32), for reference
         L.set_math_mode("f32")
         for i in range(2):
-            vqvae_step(model, optimizers, data, i)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t2 = time.perf_counter()
-        for i in range(args.steps):
-            vqvae_step(model, optimizers, data, i)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        e2 = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device=device)
-        if world > 1:
-            dist.all_reduce(e2, op=dist.ReduceOp.MAX)
-        strict = {"clips_per_s": round(args.batch_clips * world * args.steps / float(e2.item()), 3),
-                  "ms_per_step": round(float(e2.item()) / args.steps * 1e3, 3),
-                  "note": "LVT_MATH=f32: identical step on v_mfma_f32_32x32x2_f32 (peak 157.3 TFLOP/s)"}
+            step(i)
+        n2 = max(5, args.steps // 2)
+        e2, st2, _ = timed_steps(step, n2, 2, world, device)
+        strict = {"clips_per_s": round(args.batch_clips * world * n2 / e2, 3), "ms_per_step": round(e2 / n2 * 1e3, 3),
+                  "steps": n2, "note": "LVT_MATH=f32: identical step on v_mfma_f32_32x32x2_f32 (peak 157.3 TFLOP/s)"}
         L.set_math_mode(math_mode)
 
     extra = {}
     if not args.no_dsfvt:
-        del model, optimizers, clips, data
+        del model, optimizers, batches
         torch.cuda.empty_cache()
-        extra["dsfvt"] = bench_dsfvt(device, world, rank, max(3, args.steps // 4), 2, args.dsfvt_batch,
-                                     strict_f32=not args.no_strict_f32)
+        extra["dsfvt"] = bench_dsfvt(device, world, rank, max(10, args.steps // 2), 3, args.dsfvt_batch, args.batches,
+                                     strict_f32=not args.no_strict_f32,
+                                     cpu_seconds=0.0 if args.no_cpu_baseline else args.cpu_seconds * 0.75)
     if not args.no_generate and rank == 0 and world == 1:
         torch.cuda.empty_cache()
         extra["generate"] = bench_generate(device, args.generate_batch)
@@ -370,42 +465,40 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = args.batch_clips * world * args.steps / elapsed
-        summ = timer.summary()
-        eng = {k: v for k, v in summ.items() if k.startswith("conv_") or k.startswith("gemm_")}
-        tot_ms = sum(v["ms"] for v in eng.values())
-        tot_fl = sum(v["flops"] for v in eng.values())
-        launches = sum(v["launches"] for v in eng.values())
-        achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-        per_kind = {k: {"launches": v["launches"], "avg_us": round(v["ms"] / v["launches"] * 1e3, 1),
-                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in sorted(eng.items())}
-        traffic = None
-        try:      # HBM bytes per engine launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate runs)
-            with open(os.path.join(ROOT, "profiles", "r01_vqvae_pmc_hbm_traffic_bf16x3.json")) as f:
-                traffic = round(json.load(f)["hbm_bytes_per_launch"])
-        except Exception:
-            pass
+        es = engine_summary(timer, args.steps, math_mode)
         out = {
             "metric": "video-clips/sec/node (VQ-VAE PR-DVQVAE2 train step, BAIR 64x64x16)",
             "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "math": MATH_NOTE[math_mode],
+            "step_ms": stats,
             "config": {"workload": "PR-DVQVAE2 train step (fwd+bwd+Adam), %d clips x 16 frames x 3x64x64 per GPU, "
-                                   "4x512 EMA codebooks" % args.batch_clips,
+                                   "4x512 EMA codebooks; %d distinct batches rotated" % (args.batch_clips, args.batches),
                        "global_batch_clips": args.batch_clips * world, "parallelism": "dp%d" % world,
                        "loss": {k: round(float(v.detach()), 6) for k, v in losses.items()}},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(engine_peak(math_mode), 1),
-                         "unit": "TFLOP/s", "frac": round(achieved / engine_peak(math_mode), 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, "
-                                         "profiles/r01_vqvae_pmc_hbm_traffic_bf16x3.txt); algorithmic flops per launch = %.3e" % (tot_fl / max(launches, 1)),
+            "roofline": {"bound": "mfma", "achieved": round(es["achieved"], 2), "peak": round(engine_peak(math_mode), 1),
+                         "unit": "TFLOP/s", "frac": round(es["frac"], 4),
+                         "traffic": traffic_from_profile("r02_vqvae_pmc_hbm_traffic.json"),
+                         "traffic_unit": "HBM bytes per engine launch (rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + "
+                                         "WRITE_SIZE in separate passes of this command, profiles/r02_vqvae_pmc_hbm_traffic.txt); "
+                                         "algorithmic flops per launch = %.3e" % es["flops_per_launch"],
                          "kernel": "lvt_gemm_kernel<*> (implicit-GEMM engine: conv fwd / bwd-data / bwd-weight), %d "
                                    "launches per step; event-timed in a second pass of the same %d steps: %.2f ms of "
                                    "engine time in a %.2f ms instrumented step (unperturbed step: %.2f ms)"
-                                   % (launches // args.steps, args.steps, tot_ms / args.steps, instrumented_ms, ms),
+                                   % (es["launches_per_step"], args.steps, es["ms_per_step"], instrumented_ms, ms),
                          "peak_note": PEAK_NOTE[math_mode],
-                         "per_kind": per_kind},
+                         "per_kind": es["per_kind"]},
         }
         if strict is not None:
             extra["strict_f32_mfma"] = strict
+        if "dsfvt" in extra:
+            # BASELINE.json words the metric as "VQVAE+DSFVT train step": a clip that takes one VQ-VAE train step AND one
+            # DSFVT train step (one slice of it per step, as the reference trains) on the same GPUs, one after the other
+            v1, v2 = value, extra["dsfvt"]["samples_per_s"]
+            extra["combined_vqvae_dsfvt"] = {
+                "clips_per_s": round(1.0 / (1.0 / v1 + 1.0 / v2), 3),
+                "note": "harmonic combination 1/(1/vqvae + 1/dsfvt) of the two measured train-step rates: clips/s when "
+                        "every clip gets one VQ-VAE step and one DSFVT step on the same %d GPU(s)" % world}
         out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch_clips, args.cpu_seconds)

@@ -121,6 +121,13 @@ typedef struct {
 /* w: [Co_real][Ci_real][Kt][Kh][Kw] (torch layout)  ->  wp: [taps][Ci][Co], zero padded.            */
 int lvt_conv3d_pack_weight(const lvt_conv_geom *g, const float *w, int Ci_real, int Co_real,
                            float *wp, void *stream);
+/* Packed weights of the convolution that IS the backward-data pass of a stride-1 convolution: channels swapped, taps
+ * reversed: wt[taps-1-tap][co][ci] = w[co][ci][tap].  `lvt_conv3d_fwd` on the swapped geometry (Ci <-> Co, same kernel
+ * and padding k-1-p) with these weights computes dx; for 3x3 / pad 1 layers of 16x16 frames that launch runs on the
+ * frame-resident kernel (lvt_conv3d_uses_patch_kernel), which stages every input element once instead of once per tap. */
+int lvt_conv3d_pack_weight_t(const lvt_conv_geom *g, const float *w, int Ci_real, int Co_real,
+                             float *wt, void *stream);
+int lvt_conv3d_uses_patch_kernel(const lvt_conv_geom *g);
 /* y = epi( conv(x, wp) ); bias[Co]; res / y are (N,To,Ho,Wo,Co).  flags: BIAS|RESIDUAL|RELU|TANH|MASK */
 int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias,
                    const float *res, const float *mask, float *y, int flags, void *stream);

@@ -19,6 +19,7 @@
 //     weight gradients are bit-reproducible run to run (no float atomics).
 #include "lvt_common.h"
 #include <string.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -32,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 #define NTHREADS 256
 
-enum { A_KPLAIN = 0, A_MPLAIN = 1, A_CONV_K = 2, A_CONVT_K = 3, A_CONV_M = 4, A_ONEHOT_M = 5 };
+enum { A_KPLAIN = 0, A_MPLAIN = 1, A_CONV_K = 2, A_CONVT_K = 3, A_CONV_M = 4, A_ONEHOT_M = 5, A_PATCH = 6 };
 enum { B_KPLAIN = 0, B_NPLAIN = 1, B_CONVT_W = 2 };
 
 struct KParams {
@@ -90,7 +91,18 @@ template <int ROWS> struct HPlane { static constexpr int SIZE = ROWS * HLD + (RO
 // 4 consecutive k of one row -> one 8-byte store per plane
 template <int ROWS> __device__ __forceinline__ void store_split_k(unsigned short *lds, int row, int k4, const float4 v) {
     uint2 p1, p2, p3;
+#if defined(LVT_EXP_PART) && (LVT_EXP_PART & 2)
+    p1.x = __float_as_uint(v.x); p1.y = __float_as_uint(v.y); p2.x = __float_as_uint(v.z); p2.y = __float_as_uint(v.w);
+    p3.x = p1.x; p3.y = p2.y;                      // timing experiment: no split arithmetic
+#else
     split3(v, p1, p2, p3);
+#endif
+#if defined(LVT_EXP_PART) && (LVT_EXP_PART & 4)
+    if (lds == nullptr) {                          // timing experiment: split computed, LDS stores skipped
+        asm volatile("" :: "v"(p1.x), "v"(p1.y), "v"(p2.x), "v"(p2.y), "v"(p3.x), "v"(p3.y));
+        return;
+    }
+#endif
     unsigned short *d = lds + hrow<ROWS>(row) + k4;
     *reinterpret_cast<uint2 *>(d) = p1;
     *reinterpret_cast<uint2 *>(d + HPlane<ROWS>::SIZE) = p2;
@@ -572,6 +584,17 @@ template <int BN, int MATH> struct BLoader<B_NPLAIN, BN, MATH> {
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// A_PATCH (frame-resident 3x3 convolution, below): GEMM row r of a 256-row frame tile is NOT pixel r.  The 32 rows of an
+// MFMA tile t32 are the pixels of image rows 2*t32 and 2*t32+1, lane quad q (4 consecutive lanes) holding 4 consecutive
+// x of image row 2*t32 + (popcount(q) & 1) starting at x = 4*(q >> 1): the lane groups a ds_read_b128 is serviced in
+// ({0-3,12-15,20-27} / {4-11,16-19,28-31}) then each cover 16 consecutive pixels of ONE image row, which is what makes the
+// shifted operand reads from the pixel-major patch bank-conflict free for every tap.
+__device__ __forceinline__ long long patch_orow(int row) {
+    const int f = row & 255, t32 = f >> 5, q = (f >> 2) & 7, e = f & 3;
+    const int y = 2 * t32 + (__popc(q) & 1), x = 4 * (q >> 1) + e;
+    return (long long)(row & ~255) + y * 16 + x;
+}
+
 // ------------------------------------------------------------------------------------------------
 // epilogue shared by the kernels: alpha / bias / residual / ReLU / tanh / mask / accumulate, or split-K partials
 // ------------------------------------------------------------------------------------------------
@@ -596,6 +619,7 @@ __device__ __forceinline__ void lvt_epilogue(const KParams &p, f32x16 (&acc)[BM 
             const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (row >= p.M) continue;
             long long orow = row;
+            if (AMODE == A_PATCH) orow = patch_orow(row);
             if (AMODE == A_CONVT_K) {
                 const lvt_conv_geom &g = p.g;
                 int m = row;
@@ -703,6 +727,7 @@ __device__ __forceinline__ void lvt_epilogue_vec(const KParams &p, f32x16 (&acc)
             if (row < p.M && col < p.N) {
                 float4 v = *reinterpret_cast<const float4 *>(&tile[rowl * SW + 4 * c4]);
                 long long orow = row;
+                if (AMODE == A_PATCH) orow = patch_orow(row);
                 if (AMODE == A_CONVT_K) {
                     const lvt_conv_geom &g = p.g;
                     int m = row;
@@ -763,6 +788,12 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
     const float *A = tc.A, *B = tc.B;
     const long long coff = tc.coff;
 
+#ifdef LVT_EXP_STAGGER
+    // experiment: the two workgroups resident on a CU start half an iteration apart (odd hardware wave slots sleep)
+    if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1) {
+        for (int i_ = 0; i_ < LVT_EXP_STAGGER; ++i_) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     AL al; BL bl;
     al.init(p, tid, m0, A, cls);
     bl.init(p, tid, n0, B, cls);
@@ -790,9 +821,27 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
     const float *Ard = As + half * LDA + wm * (TM * 32) + l31;
     const float *Brd = Bs + half * LDB + wn * (TN * 32) + l31;
 
+#if defined(LVT_EXP_SKIP) || defined(LVT_EXP_PART)
+    int exp_it = 0;
+#endif
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool has_next = k0 + BK < kend;
+#ifdef LVT_EXP_SKIP
+        // timing experiment only (results are wrong): stage the A / B side on every 8th k-tile only
+        ++exp_it;
+#ifndef LVT_EXP_MA
+#define LVT_EXP_MA 7
+#define LVT_EXP_MB 7
+#endif
+        const bool exp_a = !(LVT_EXP_SKIP & 1) || (exp_it & LVT_EXP_MA) == 0, exp_b = !(LVT_EXP_SKIP & 2) || (exp_it & LVT_EXP_MB) == 0;
+        if (has_next) { if (exp_a) al.fetch(kend); if (exp_b) bl.fetch(kend); }
+#elif defined(LVT_EXP_PART)
+        ++exp_it;
+        const bool exp_full = (exp_it & 7) == 0;
+        if (has_next && (!(LVT_EXP_PART & 1) || exp_full)) { al.fetch(kend); bl.fetch(kend); }
+#else
         if (has_next) { al.fetch(kend); bl.fetch(kend); }
+#endif
         if (MATH == 0) {
             // operand fragments are double-buffered in registers: the ds_reads of step kk+2 are in flight
             // while the MFMAs of step kk issue, so the LDS latency is not exposed once per step
@@ -853,10 +902,23 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
         }
         __syncthreads();
         if (has_next) {
+#ifdef LVT_EXP_SKIP
+            if (MATH == 0) { al.store(As); bl.store(Bs); }
+            else { if (exp_a) al.store_split(Ah); if (exp_b) bl.store_split(Bh); }
+#elif defined(LVT_EXP_PART)
+            if (MATH == 0) { al.store(As); bl.store(Bs); }
+            else if ((LVT_EXP_PART & 4) && !exp_full) { al.store_split(nullptr); bl.store_split(nullptr); }
+            else { al.store_split(Ah); bl.store_split(Bh); }
+#else
             if (MATH == 0) { al.store(As); bl.store(Bs); }
             else { al.store_split(Ah); bl.store_split(Bh); }
+#endif
         }
+#if defined(LVT_EXP_PART) && (LVT_EXP_PART & 8)
+        if (exp_full) __syncthreads();
+#else
         __syncthreads();
+#endif
     }
 
     if constexpr (COLSUM) {
@@ -867,6 +929,151 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
     }
     if (p.vec_epi) lvt_epilogue_vec<AMODE, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, cls, coff, z, split);
     else lvt_epilogue<AMODE, BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, l31, half, cls, coff, z, split);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Frame-resident 3x3 convolution (stride 1, pad 1, 16x16 frames): the implicit GEMM above re-stages every input
+// element once per tap and per n-tile -- 9 x 2 trips global -> registers -> split -> LDS for the 256-channel layers, which
+// is where a third of the engine time goes (staging A on every 8th k-tile only: +17 %, A on every 8th and B on every
+// 2nd: +28 %, profiles/r02_engine_staging_experiments.txt).  Here one workgroup (8 waves) owns one whole FRAME x 128
+// output channels: per 32-channel chunk the 18x18 input patch (frame + zero halo) is split and staged ONCE, pixel-major,
+// and the nine taps read their A operands from it at a pixel offset; only the 32 x 128 weight tile of each (chunk, tap)
+// step is staged (double-buffered, one barrier per step).  Data staged per MFMA: 1/3.5 of the implicit GEMM's.
+// GEMM k order is (chunk, tap, channel-in-chunk); rows are pixels in the patch_orow order.
+// ------------------------------------------------------------------------------------------------
+#define PT_PW 18
+#define PT_PIX (PT_PW * PT_PW)
+#define PT_PLANE (PT_PIX * HLD)                 // bf16 per patch plane
+#define PT_THREADS 512
+__global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParams p) {
+    constexpr int BM = 256, BN = 128, WM = 4, WN = 2, TM = 2, TN = 2;
+    constexpr int PSB = HPlane<BN>::SIZE;
+    constexpr int A_BYTES = 3 * PT_PLANE * 2, B_BYTES = 3 * PSB * 2;
+    constexpr int STAGE_FLOATS = (A_BYTES + 2 * B_BYTES) / 4 + 8;
+    constexpr int TURN_FLOATS = WM * WN * 32 * (TN * 32);
+    constexpr int LDS_FLOATS = STAGE_FLOATS > TURN_FLOATS ? STAGE_FLOATS : TURN_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    unsigned short *Ah = reinterpret_cast<unsigned short *>(lds);
+    unsigned short *Bh0 = Ah + 3 * PT_PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int Ci = p.g.Ci;
+    const int ntn = p.N / BN;
+    int wg = blockIdx.x;
+    {   // XCD-contiguous tile order (see lvt_tile_ctx): the n-tiles of a frame share its patch in one L2
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = wg & 7, slot = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int n0 = (wg % ntn) * BN, frame = wg / ntn, m0 = frame * BM;
+    const float *xf = p.A + (long long)frame * 256 * Ci;
+
+    // ---- patch staging: unit u = pixel * 8 + channel quad; 2592 units over 512 threads -> 6 passes
+    constexpr int PUNITS = PT_PIX * 8, PPASS = (PUNITS + PT_THREADS - 1) / PT_THREADS;
+    float4 pv[PPASS];
+    auto patch_fetch = [&](int cc) {
+#pragma unroll
+        for (int j = 0; j < PPASS; ++j) {
+            const int u = tid + PT_THREADS * j;
+            const int pp = u >> 3, q = u & 7;
+            const int py = pp / PT_PW, px = pp - py * PT_PW;
+            const bool ok = u < PUNITS && (unsigned)(py - 1) < 16u && (unsigned)(px - 1) < 16u;
+            const float *src = xf + ((py - 1) * 16 + (px - 1)) * Ci + cc * 32 + q * 4;
+            pv[j] = ok ? ldg4(src) : zero4();
+        }
+    };
+    auto patch_store = [&]() {
+#pragma unroll
+        for (int j = 0; j < PPASS; ++j) {
+            const int u = tid + PT_THREADS * j;
+            if (u < PUNITS) {
+                uint2 p1, p2, p3;
+                split3(pv[j], p1, p2, p3);
+                unsigned short *d = Ah + (u >> 3) * HLD + (u & 7) * 4;
+                *reinterpret_cast<uint2 *>(d) = p1;
+                *reinterpret_cast<uint2 *>(d + PT_PLANE) = p2;
+                *reinterpret_cast<uint2 *>(d + 2 * PT_PLANE) = p3;
+            }
+        }
+    };
+    // ---- weight tile of a step: 32 k rows x 128 columns, staged by the first 256 threads (4 k rows x 4 columns each,
+    // transposed in registers into k-contiguous 8-byte LDS rows, as BLoader<B_NPLAIN> does)
+    const bool bact = tid < 256;
+    const int bkk0 = (tid >> 5) & 7, bnq = tid & 31;
+    const float *bcol = p.B + n0 + bnq * 4;
+    float4 bv[4];
+    auto b_fetch = [&](int step) {
+        const int cc = step / 9, tap = step - cc * 9;
+        const float *src = bcol + (long long)(tap * Ci + cc * 32 + bkk0 * 4) * p.ldb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = ldg4(src + (long long)i * p.ldb);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // A operand rows of this lane: MFMA tile i of the wave covers image rows 2*(2*wm + i) + {0, 1}
+    int arow[TM];
+    {
+        const int q = l31 >> 2, e = l31 & 3;
+        const int yy = __popc(q) & 1, x = 4 * (q >> 1) + e;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) arow[i] = ((2 * (2 * wm + i) + yy) * PT_PW + x) * HLD + 8 * half;
+    }
+    int brow[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) brow[j] = hrow<BN>(wn * (TN * 32) + j * 32 + l31) + 8 * half;
+
+    const int nchunks = Ci / 32, nsteps = nchunks * 9;
+    patch_fetch(0);
+    if (bact) b_fetch(0);
+    patch_store();
+    if (bact) store_split_block<BN>(Bh0, bnq * 4, bkk0 * 4, bv);
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int cc = step / 9, tap = step - cc * 9;
+        const bool has_next = step + 1 < nsteps;
+        const bool new_chunk = has_next && tap == 8;
+        if (has_next && bact) b_fetch(step + 1);
+        if (new_chunk) patch_fetch(cc + 1);
+        const unsigned short *Bh = Bh0 + (step & 1) * (3 * PSB);
+        const unsigned short *Ap = Ah + ((tap / 3) * PT_PW + (tap % 3)) * HLD;
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 16) {
+            bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const bf16x8 *>(Ap + arow[i] + q * PT_PLANE + ks);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const bf16x8 *>(Bh + brow[j] + q * PSB + ks);
+            }
+            constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]][i], b[TB[t]][j], acc[i][j], 0, 0, 0);
+        }
+        // the other weight buffer was last read in the previous step, which every wave has left (barrier below)
+        if (has_next && bact) store_split_block<BN>(Bh0 + ((step + 1) & 1) * (3 * PSB), bnq * 4, bkk0 * 4, bv);
+        if (new_chunk) {
+            __syncthreads();              // every wave is done with the old patch
+            patch_store();
+        }
+        __syncthreads();
+    }
+    lvt_epilogue_vec<A_PATCH, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, 0, 0, 0, 0);
 }
 
 // deterministic split-K reduction: out[i] (+)= sum_s partial[s][i]
@@ -911,6 +1118,20 @@ __global__ void lvt_pack_weight_kernel(const float *__restrict__ w, float *__res
         float v = 0.f;
         if (co < Co_real && ci < Ci_real) v = w[((long long)co * Ci_real + ci) * taps + tap];
         wp[i] = v;
+    }
+}
+// w[co][ci][tap] -> wt[taps-1-tap][co_pad][ci_pad]: the packed weights of the convolution that IS the backward-data pass of a
+// stride-1 convolution (input / output channels swapped, taps reversed)
+__global__ void lvt_pack_weight_t_kernel(const float *__restrict__ w, float *__restrict__ wt, int taps, int Ci,
+                                         int Co, int Ci_real, int Co_real) {
+    const long long total = (long long)taps * Co * Ci;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ci = i % Ci; long long t = i / Ci;
+        const int co = t % Co; const int tr = t / Co;
+        float v = 0.f;
+        if (co < Co_real && ci < Ci_real) v = w[((long long)co * Ci_real + ci) * taps + (taps - 1 - tr)];
+        wt[i] = v;
     }
 }
 // partial[split][(tap,ci)][co] -> dw[co][ci][tap]   (fixed summation order over splits).
@@ -1143,6 +1364,29 @@ extern "C" int lvt_conv3d_pack_weight(const lvt_conv_geom *g, const float *w, in
     return LVT_OK;
 }
 
+extern "C" int lvt_conv3d_pack_weight_t(const lvt_conv_geom *g, const float *w, int Ci_real, int Co_real,
+                                        float *wt, void *stream) {
+    int rc = check_geom(g, "pack_weight_t"); if (rc) return rc;
+    LVT_REQUIRE(w && wt && Ci_real <= g->Ci && Co_real <= g->Co, "pack_weight_t: bad args");
+    LVT_REQUIRE(g->st == 1 && g->sh == 1 && g->sw == 1, "pack_weight_t: stride-1 convolutions only");
+    const int taps = g->Kt * g->Kh * g->Kw;
+    const long long total = (long long)taps * g->Ci * g->Co;
+    const int blocks = (int)(lvt_cdiv(total, 256) < 4096 ? lvt_cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(lvt_pack_weight_t_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wt, taps,
+                       g->Ci, g->Co, Ci_real, Co_real);
+    LVT_CHECK_LAUNCH("lvt_pack_weight_t_kernel");
+    return LVT_OK;
+}
+
+// the frame-resident kernel serves 3x3 / stride 1 / pad 1 convolutions of 16x16 frames with Ci % 32 == 0, Co % 128 == 0
+static bool patch_conv_eligible(const lvt_conv_geom *g) {
+    static const int off = getenv("LVT_NO_PATCH_CONV") ? 1 : 0;
+    return !off && g_math_mode == 1 && BK == 32 && g->Kt == 1 && g->Kh == 3 && g->Kw == 3 && g->st == 1 && g->sh == 1 &&
+           g->sw == 1 && g->pt == 0 && g->ph == 1 && g->pw == 1 && g->Ti == 1 && g->Hi == 16 && g->Wi == 16 && g->To == 1 &&
+           g->Ho == 16 && g->Wo == 16 && g->Ci % 32 == 0 && g->Co % 128 == 0;
+}
+extern "C" int lvt_conv3d_uses_patch_kernel(const lvt_conv_geom *g) { return g && patch_conv_eligible(g) ? 1 : 0; }
+
 extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias,
                               const float *res, const float *mask, float *y, int flags, void *stream) {
     int rc = check_geom(g, "conv3d_fwd"); if (rc) return rc;
@@ -1158,6 +1402,20 @@ extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const floa
     p.A = x; p.B = wp; p.ldb = g->Co; p.C = y; p.ldc = g->Co; p.batch_inner = 1;
     p.alpha = 1.f; p.flags = flags; p.bias = bias; p.res = res; p.ldr = g->Co; p.mask = mask; p.ldm = g->Co;
     p.splits = 1; p.g = *g;
+    {
+        auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
+        bool ok = patch_conv_eligible(g) && al16(x) && al16(wp) && al16(y);
+        if (flags & LVT_EPI_BIAS) ok = ok && al16(bias);
+        if (flags & LVT_EPI_RESIDUAL) ok = ok && al16(res);
+        if (flags & LVT_EPI_MASK) ok = ok && al16(mask);
+        if (ok) {
+            p.vec_epi = 1;
+            hipLaunchKernelGGL(lvt_conv_patch_kernel, dim3((unsigned)(g->N * (g->Co / 128))), dim3(PT_THREADS), 0,
+                               (hipStream_t)stream, p);
+            LVT_CHECK_LAUNCH("lvt_conv_patch_kernel");
+            return LVT_OK;
+        }
+    }
     if (g->Co <= 32) return launch_tile<A_CONV_K, B_NPLAIN, 128, 32, 4, 1>(p, 1, (hipStream_t)stream);
     return launch_tile<A_CONV_K, B_NPLAIN, 128, 128, 2, 2>(p, 1, (hipStream_t)stream);
 }

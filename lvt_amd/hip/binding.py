@@ -69,6 +69,8 @@ def _declare(lib):
         "lvt_gemm_smallm_partial_f32": (ci, [ci, ci, ci, ci, vp, cll, vp, cll, vp, sz, vp]),
         "lvt_splitsum_layernorm_fwd": (ci, [vp, ci, ci, ci, vp, vp, cll, vp, cf, vp, vp, vp, vp]),
         "lvt_conv3d_pack_weight": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
+        "lvt_conv3d_pack_weight_t": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
+        "lvt_conv3d_uses_patch_kernel": (ci, [P(ConvGeom)]),
         "lvt_conv3d_fwd": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
         "lvt_conv3d_bwd_data": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
         "lvt_conv3d_bwd_weight_workspace_bytes": (sz, [P(ConvGeom)]),

@@ -55,8 +55,9 @@ def _act_flag(act):
     return {"": 0, "relu": L.EPI_RELU, "tanh": L.EPI_TANH}[act]
 
 
-def stack_forward(layers, x, params):
-    """x: (N,T,H,W,C) channels-last.  params: [(weight, bias)] in torch layout.
+def stack_forward(layers, x, params, want_grad=True):
+    """x: (N,T,H,W,C) channels-last.  params: [(weight, bias)] in torch layout.  want_grad: a backward pass will follow
+    (the transposed weight packs it needs are made here, next to the forward ones).
     Returns (outs, saved) where outs[i] is the post-activation output of layer i."""
     outs, geoms, packed = [], [], []
     cur = x
@@ -77,7 +78,9 @@ def stack_forward(layers, x, params):
             y = G.conv_bwd_data(g, cur, wp, bias=bias, res=res, flags=_act_flag(ly.act))
         outs.append(y)
         geoms.append(g)
-        packed.append(wp)
+        # backward-data of the 3x3 layers runs as a forward convolution over transposed weights (frame-resident kernel)
+        wt = G.pack_weight_t(g, w, ly.cin, ly.cout) if (want_grad and ly.kind == "conv" and G.bwd_data_as_conv(g)) else None
+        packed.append((wp, wt))
         cur = y
     return outs, (geoms, packed)
 
@@ -100,7 +103,7 @@ def stack_backward(layers, x, outs, saved, grad_out, need_input_grad=False):
     gpres[n - 1] = gpre
     grads = [None] * n
     for i in range(n - 1, -1, -1):
-        ly, g, wp = layers[i], geoms[i], packed[i]
+        ly, g, (wp, wt) = layers[i], geoms[i], packed[i]
         inp = outs[i - 1] if i > 0 else x
         gp = gpres[i]
         # parameter gradients
@@ -122,7 +125,7 @@ def stack_backward(layers, x, outs, saved, grad_out, need_input_grad=False):
         if prev is not None and prev.act == "tanh":
             raise L.LvtError("tanh is only supported on the last layer of a stack")
         if ly.kind == "conv":
-            gin = G.conv_bwd_data(g, gp, wp, res=res, mask=mask)
+            gin = G.conv_bwd_data(g, gp, wp, res=res, mask=mask, wt=wt)
         else:
             gin = G.conv_fwd(g, gp, wp, res=res, mask=mask)
         if i > 0:

@@ -132,7 +132,30 @@ def pack_weight(g, w, Ci_real, Co_real):
     return wp
 
 
-def conv_fwd(g, x, wp, bias=None, res=None, mask=None, flags=0):
+def pack_weight_t(g, w, Ci_real, Co_real):
+    """(taps, Co, Ci) weights of the convolution that is the backward-data pass of the stride-1 convolution `g`."""
+    L.require(w)
+    wt = torch.empty(g.Kt * g.Kh * g.Kw, g.Co, g.Ci, dtype=torch.float32, device=w.device)
+    L.check(L.lib().lvt_conv3d_pack_weight_t(C.byref(g), L.ptr(w), Ci_real, Co_real, L.ptr(wt), L.stream_ptr()),
+            "lvt_conv3d_pack_weight_t")
+    return wt
+
+
+def swapped_geom(g):
+    """Geometry of the forward convolution that computes the backward-data pass of the stride-1 convolution `g`."""
+    return conv_geom(g.N, g.To, g.Ho, g.Wo, g.Co, g.Ci, (g.Kt, g.Kh, g.Kw), (1, 1, 1),
+                     (g.Kt - 1 - g.pt, g.Kh - 1 - g.ph, g.Kw - 1 - g.pw), out=(g.Ti, g.Hi, g.Wi))
+
+
+def bwd_data_as_conv(g):
+    """True when dx of `g` should run as a forward convolution over transposed weights: stride 1 and the swapped
+    geometry is served by the frame-resident kernel (3x3 / pad 1 on 16x16 frames)."""
+    if (g.st, g.sh, g.sw) != (1, 1, 1):
+        return False
+    return bool(L.lib().lvt_conv3d_uses_patch_kernel(C.byref(swapped_geom(g))))
+
+
+def conv_fwd(g, x, wp, bias=None, res=None, mask=None, flags=0, timer_key="conv_fwd"):
     L.require(x, wp, bias, res, mask)
     y = torch.empty(g.N, g.To, g.Ho, g.Wo, g.Co, dtype=torch.float32, device=x.device)
     if bias is not None:
@@ -145,11 +168,15 @@ def conv_fwd(g, x, wp, bias=None, res=None, mask=None, flags=0):
     L.check(L.lib().lvt_conv3d_fwd(C.byref(g), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(mask), L.ptr(y),
                                    flags, L.stream_ptr()), "lvt_conv3d_fwd")
     if t0 is not None:
-        L.TIMER.end("conv_fwd", conv_flops(g), t0)
+        L.TIMER.end(timer_key, conv_flops(g), t0)
     return y
 
 
-def conv_bwd_data(g, dy, wp, bias=None, res=None, mask=None, flags=0):
+def conv_bwd_data(g, dy, wp, bias=None, res=None, mask=None, flags=0, wt=None):
+    """dx of the convolution `g`.  With `wt` (pack_weight_t) the pass runs as a forward convolution on the swapped
+    geometry -- the frame-resident kernel for the 3x3 layers."""
+    if wt is not None:
+        return conv_fwd(swapped_geom(g), dy, wt, bias=bias, res=res, mask=mask, flags=flags, timer_key="conv_bwd_data")
     L.require(dy, wp, bias, res, mask)
     dx = torch.empty(g.N, g.Ti, g.Hi, g.Wi, g.Ci, dtype=torch.float32, device=dy.device)
     if bias is not None:

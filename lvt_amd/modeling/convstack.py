@@ -16,7 +16,7 @@ class _ConvStackFn(torch.autograd.Function):
     def forward(ctx, x, layers, *flat):
         params = [(flat[2 * i], flat[2 * i + 1]) for i in range(len(layers))]
         with torch.no_grad():
-            outs, saved = convnet.stack_forward(layers, x, params)
+            outs, saved = convnet.stack_forward(layers, x, params, want_grad=any(ctx.needs_input_grad))
         ctx.layers, ctx.saved, ctx.outs, ctx.x = layers, saved, outs, x
         ctx.shapes = [tuple(p.shape) for p in flat]
         return outs[-1]

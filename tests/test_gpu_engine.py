@@ -195,6 +195,35 @@ def test_conv_bwd_data_residual_and_mask():
     assert rel_err(_nchw(dx), ref) < TOL
 
 
+@pytest.mark.parametrize("Ci,Co,N", [(256, 256, 3), (256, 128, 5), (128, 256, 2), (32, 128, 1)])
+def test_frame_resident_conv_forward_and_backward_data(Ci, Co, N, math_mode):
+    """3x3 / pad 1 convolutions of 16x16 frames: forward (bias + residual + ReLU) and backward-data (as a forward
+    convolution over the transposed, tap-reversed weights, with residual and ReLU mask) against torch on the CPU.  In the
+    default math mode these launches run on the frame-resident kernel (one patch staging per 32-channel chunk)."""
+    from lvt_amd.hip import gemm as G, binding as L
+    H = 16
+    x, w, b = _rand(N, Ci, H, H), _rand(Co, Ci, 3, 3, seed=1) * 0.1, _rand(Co, seed=2)
+    res = _rand(N, Co, H, H, seed=4)
+    y = torch.relu(F.conv2d(x, w, b, padding=1) + res)
+    dev = _dev()
+    g = G.conv_geom(N, 1, H, H, Ci, Co, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    if math_mode == "bf16x3":
+        assert L.lib().lvt_conv3d_uses_patch_kernel(__import__("ctypes").byref(g)) == 1
+    wd = w.to(dev)
+    yd = G.conv_fwd(g, _nhwc(x).to(dev), G.pack_weight(g, wd, Ci, Co), bias=b.to(dev), res=_nhwc(res).to(dev), flags=L.EPI_RELU)
+    assert rel_err(_nchw(yd), y) < TOL
+    gy, rx, msrc = _rand(N, Co, H, H, seed=5), _rand(N, Ci, H, H, seed=6), _rand(N, Ci, H, H, seed=7)
+    ref = (F.conv_transpose2d(gy, w, stride=1, padding=1) + rx) * (msrc > 0)
+    if Co % 32 == 0 and Ci % 128 == 0:
+        assert G.bwd_data_as_conv(g) == (math_mode == "bf16x3")
+    wt = G.pack_weight_t(g, wd, Ci, Co)
+    dx = G.conv_bwd_data(g, _nhwc(gy).to(dev), None, res=_nhwc(rx).to(dev), mask=_nhwc(msrc).to(dev), wt=wt)
+    assert rel_err(_nchw(dx), ref) < TOL
+    # and the two routes agree with each other to rounding
+    dx2 = G.conv_bwd_data(g, _nhwc(gy).to(dev), G.pack_weight(g, wd, Ci, Co), res=_nhwc(rx).to(dev), mask=_nhwc(msrc).to(dev))
+    assert rel_err(dx, dx2) < TOL
+
+
 def test_conv3d_causal_geometry():
     """MaskedConv3d geometry (K16): kernel 3x3x3, front pads (2,2,1), T=2 to exercise the t taps."""
     from lvt_amd.hip import gemm as G
