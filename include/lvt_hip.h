@@ -140,6 +140,10 @@ int lvt_conv3d_bwd_data(const lvt_conv_geom *g, const float *dy, const float *wp
  * db (nullable, Co_real floats) = sum_pixels dy: the bias gradient, accumulated from the dy tiles the kernel streams
  * anyway (no second pass over dy).                                                                         */
 size_t lvt_conv3d_bwd_weight_workspace_bytes(const lvt_conv_geom *g);
+/* 1 when lvt_conv3d_bwd_weight can also produce db for this geometry.  The 3x3 / pad 1 layers of 16x16 frames with 256
+ * channels on one side run on the frame-resident weight-gradient kernel (csrc/conv_wgrad.hip: patch and dy row staged once
+ * per frame / image row, taps are row offsets of a transposing LDS read); pass db == NULL there and use lvt_colsum(dy). */
+int lvt_conv3d_bwd_weight_fuses_bias(const lvt_conv_geom *g);
 int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, float *db,
                           int Ci_real, int Co_real, void *workspace, size_t workspace_bytes,
                           void *stream);

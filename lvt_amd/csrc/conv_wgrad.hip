@@ -1,0 +1,243 @@
+// Frame-resident weight gradient of the 3x3 / stride 1 / pad 1 convolutions on 16x16 frames:
+//     dW[tap][ci][co] = sum over frames and pixels of  x[pixel + tap][ci] * dy[pixel][co]
+// The implicit-GEMM form (gemm_engine.hip, A_CONV_M) gathers a shifted copy of x for every tap and re-stages dy for
+// every 128-row tile of (tap, ci): staging, not the matrix cores, bounds it (skipping the A-side staging on 7 of 8 k-tiles:
+// +29 %, both sides: +48 %, profiles/r02_engine_staging_experiments.txt).  Here a workgroup (8 waves) owns a 32-channel
+// chunk of the "patch" operand for ALL nine taps and all 256 channels of the "slab" operand:
+//   * per frame the 18x18 patch chunk (frame + zero halo) is split into bf16x3 planes and staged ONCE, pixel-major;
+//   * per image row the 16 pixels x 256 channels of the slab operand are staged once (double-buffered);
+//   * the reduction index of the MFMAs is the pixel, i.e. the ROW index of both LDS images, so the operand fragments are
+//     fetched with the gfx950 transposing read (ds_read_b64_tr_b16: a 16-lane group turns a [4 rows][16 columns] block into
+//     per-column 4-vectors): a tap is a row offset into the patch, never a re-staging and never an unaligned access.
+// Wave w accumulates the nine [32 patch channels] x [slab channels 32w..32w+31] tiles (144 accumulator registers).
+// Frames are split over workgroups; the per-split partial sums go to the same [split][(tap, c_patch)][c_slab] buffer
+// layout as the implicit-GEMM path and are reduced in a fixed order (no atomics).
+// Roles: Co == 256 -> patch = x (chunks of ci), slab = dy; else Ci == 256 -> patch = dy (chunks of co), slab = x, taps reversed.
+#include "lvt_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define WG_THREADS 512
+#define WG_PW 18
+#define WG_PIX (WG_PW * WG_PW)
+#define WG_PP 32                         // patch pixel pitch (bf16): 64 B -> the 4 rows of a transposing read tile the 64 banks
+#define WG_PPL (WG_PIX * WG_PP)
+#define WG_CQ 256
+#define WG_QP (WG_CQ + 32)               // slab pixel pitch (bf16): 576 B = 16 dwords mod 64
+#define WG_QPL (16 * WG_QP)
+
+struct WgParams {
+    const float *P, *Q;
+    int Cp, N, frames_per_split, nchunks;
+    float *partial; long long partial_stride;
+};
+
+__device__ __forceinline__ unsigned wg_cvt_pk(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ void wg_split4(const float4 v, uint2 &p1, uint2 &p2, uint2 &p3) {
+    p1.x = wg_cvt_pk(v.x, v.y); p1.y = wg_cvt_pk(v.z, v.w);
+    const float r0 = v.x - __uint_as_float(p1.x << 16), r1 = v.y - __uint_as_float(p1.x & 0xffff0000u);
+    const float r2 = v.z - __uint_as_float(p1.y << 16), r3 = v.w - __uint_as_float(p1.y & 0xffff0000u);
+    p2.x = wg_cvt_pk(r0, r1); p2.y = wg_cvt_pk(r2, r3);
+    const float s0 = r0 - __uint_as_float(p2.x << 16), s1 = r1 - __uint_as_float(p2.x & 0xffff0000u);
+    const float s2 = r2 - __uint_as_float(p2.y << 16), s3 = r3 - __uint_as_float(p2.y & 0xffff0000u);
+    p3.x = wg_cvt_pk(s0, s1); p3.y = wg_cvt_pk(s2, s3);
+}
+// 8 reduction rows (4 + 4) of the lane's column: two transposing reads, `pitch4` = 4 rows further (bf16 elements)
+__device__ __forceinline__ bf16x8 wg_frag(const unsigned short *p, int pitch4) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(p + pitch4));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+}
+
+__global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const WgParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[3 * WG_PPL + 2 * 3 * WG_QPL];
+    unsigned short *patch = lds, *slab0 = lds + 3 * WG_PPL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pc = blockIdx.x % p.nchunks, split = blockIdx.x / p.nchunks;
+    const int f0 = split * p.frames_per_split, f1 = min(p.N, f0 + p.frames_per_split);
+    const int Cp = p.Cp;
+
+    constexpr int PUNITS = WG_PIX * 8, PPASS = (PUNITS + WG_THREADS - 1) / WG_THREADS;
+    float4 pv[PPASS], qv[2];
+    auto patch_fetch = [&](int f) {
+        const float *xf = p.P + (long long)f * 256 * Cp + pc * 32;
+#pragma unroll
+        for (int j = 0; j < PPASS; ++j) {
+            const int u = tid + WG_THREADS * j;
+            const int pp = u >> 3, q = u & 7;
+            const int py = pp / WG_PW, px = pp - py * WG_PW;
+            const bool ok = u < PUNITS && (unsigned)(py - 1) < 16u && (unsigned)(px - 1) < 16u;
+            pv[j] = ok ? *reinterpret_cast<const float4 *>(xf + ((py - 1) * 16 + (px - 1)) * Cp + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto patch_store = [&]() {
+#pragma unroll
+        for (int j = 0; j < PPASS; ++j) {
+            const int u = tid + WG_THREADS * j;
+            if (u < PUNITS) {
+                uint2 p1, p2, p3;
+                wg_split4(pv[j], p1, p2, p3);
+                unsigned short *d = patch + (u >> 3) * WG_PP + (u & 7) * 4;
+                *reinterpret_cast<uint2 *>(d) = p1;
+                *reinterpret_cast<uint2 *>(d + WG_PPL) = p2;
+                *reinterpret_cast<uint2 *>(d + 2 * WG_PPL) = p3;
+            }
+        }
+    };
+    auto slab_fetch = [&](int f, int y) {          // 16 pixels x 256 channels = 16 KB contiguous
+        const float *src = p.Q + ((long long)f * 256 + y * 16) * WG_CQ;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) qv[j] = *reinterpret_cast<const float4 *>(src + (tid + WG_THREADS * j) * 4);
+    };
+    auto slab_store = [&](unsigned short *slab) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int u = tid + WG_THREADS * j;
+            uint2 p1, p2, p3;
+            wg_split4(qv[j], p1, p2, p3);
+            unsigned short *d = slab + (u >> 6) * WG_QP + (u & 63) * 4;
+            *reinterpret_cast<uint2 *>(d) = p1;
+            *reinterpret_cast<uint2 *>(d + WG_QPL) = p2;
+            *reinterpret_cast<uint2 *>(d + 2 * WG_QPL) = p3;
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // fragment addressing of the transposing read: lane i of a 16-lane group supplies the address of row (i >> 2),
+    // columns 4 * (i & 3) .. +3 of its group's [4][16] block and receives column i, rows 0..3 (scratch/ubench/tr_probe.hip)
+    const int li = lane & 15, g1 = (lane >> 4) & 1, half = lane >> 5;
+    const int rowoff = 8 * half + (li >> 2), coloff = 16 * g1 + 4 * (li & 3);
+    const int boff = rowoff * WG_QP + wave * 32 + coloff;
+    const int aoff = rowoff * WG_PP + coloff;
+
+    if (f0 < f1) {
+        patch_fetch(f0); slab_fetch(f0, 0);
+        patch_store(); slab_store(slab0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int f = f0; f < f1; ++f) {
+        const bool next_frame = f + 1 < f1;
+        for (int y = 0; y < 16; ++y) {
+            const bool last_row = y == 15;
+            if (!last_row) slab_fetch(f, y + 1);
+            else if (next_frame) { slab_fetch(f + 1, 0); patch_fetch(f + 1); }
+            const unsigned short *slab = slab0 + buf * (3 * WG_QPL);
+            bf16x8 b[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b[q] = wg_frag(slab + boff + q * WG_QPL, 4 * WG_QP);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                // three taps at a time: consecutive MFMAs go to three different accumulators
+                bf16x8 a[3][3];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        a[dx][q] = wg_frag(patch + ((y + dy) * WG_PW + dx) * WG_PP + aoff + q * WG_PPL, 4 * WG_PP);
+                constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};      // smallest terms first
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+                        acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dx][TA[t]], b[TB[t]], acc[dy * 3 + dx], 0, 0, 0);
+            }
+            if (!last_row || next_frame) slab_store(slab0 + (buf ^ 1) * (3 * WG_QPL));
+            if (last_row && next_frame) {
+                __syncthreads();             // every wave is done with this frame's patch
+                patch_store();
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // partial[split][tap * Cp + pc * 32 + m][32 * wave + n]: lane = column n, 16 rows m per register file
+    float *out = p.partial + (long long)split * p.partial_stride + (long long)(pc * 32) * WG_CQ + wave * 32 + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+            out[((long long)t * Cp + m) * WG_CQ] = acc[t][r];
+        }
+}
+
+// swapped roles: partial[split][(t', co)][ci] -> dw[co][ci][8 - t'], fixed summation order over the splits
+__global__ void lvt_unpack_wgrad_swapped_kernel(const float *__restrict__ partial, long long stride, int splits,
+                                                float *__restrict__ dw, int Ci, int Co, int Ci_real, int Co_real) {
+    const long long total = 9LL * Co * Ci;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = 0;
+        for (; k + 3 < splits; k += 4) {
+            s0 += partial[k * stride + i]; s1 += partial[(k + 1) * stride + i];
+            s2 += partial[(k + 2) * stride + i]; s3 += partial[(k + 3) * stride + i];
+        }
+        for (; k < splits; ++k) s0 += partial[k * stride + i];
+        const int ci = i % Ci; long long t = i / Ci;
+        const int co = t % Co; const int tr = t / Co;
+        if (co < Co_real && ci < Ci_real) dw[((long long)co * Ci_real + ci) * 9 + (8 - tr)] = (s0 + s1) + (s2 + s3);
+    }
+}
+
+// ---- host side (called from lvt_conv3d_bwd_weight in gemm_engine.hip) -----------------------------------------------
+extern "C" int lvt_get_math_mode(void);
+static int wg_role(const lvt_conv_geom *g) {       // 0: not served, 1: patch = x / slab = dy, 2: swapped
+    static const int off = getenv("LVT_NO_FRAME_WGRAD") ? 1 : 0;
+    if (off || lvt_get_math_mode() != 1) return 0;
+    const bool shape = g->Kt == 1 && g->Kh == 3 && g->Kw == 3 && g->st == 1 && g->sh == 1 && g->sw == 1 && g->pt == 0 &&
+                       g->ph == 1 && g->pw == 1 && g->Ti == 1 && g->Hi == 16 && g->Wi == 16 && g->To == 1 && g->Ho == 16 &&
+                       g->Wo == 16;
+    if (!shape) return 0;
+    if (g->Co == WG_CQ && g->Ci % 32 == 0) return 1;
+    if (g->Ci == WG_CQ && g->Co % 32 == 0) return 2;
+    return 0;
+}
+static int wg_splits(const lvt_conv_geom *g, int role) {
+    const int nchunks = (role == 1 ? g->Ci : g->Co) / 32;
+    int s = 256 / nchunks;                         // one workgroup per CU (118 KB of LDS each): a single full wave
+    if (s > g->N) s = g->N;
+    return s < 1 ? 1 : s;
+}
+int lvt_wgrad_frames_role(const lvt_conv_geom *g) { return wg_role(g); }
+size_t lvt_wgrad_frames_workspace_bytes(const lvt_conv_geom *g) {
+    const int role = wg_role(g);
+    if (!role) return 0;
+    return (size_t)wg_splits(g, role) * 9 * g->Ci * g->Co * sizeof(float);
+}
+int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, int Ci_real, int Co_real,
+                            void *workspace, hipStream_t s, void (*unpack_plain)(const float *, long long, int, float *,
+                                                                                 const lvt_conv_geom *, int, int, hipStream_t)) {
+    const int role = wg_role(g);
+    WgParams p;
+    p.P = role == 1 ? x : dy; p.Q = role == 1 ? dy : x;
+    p.Cp = role == 1 ? g->Ci : g->Co; p.N = g->N; p.nchunks = p.Cp / 32;
+    const int splits = wg_splits(g, role);
+    p.frames_per_split = (g->N + splits - 1) / splits;
+    p.partial = (float *)workspace; p.partial_stride = 9LL * g->Ci * g->Co;
+    hipLaunchKernelGGL(lvt_conv_wgrad_frames_kernel, dim3((unsigned)(p.nchunks * splits)), dim3(WG_THREADS), 0, s, p);
+    LVT_CHECK_LAUNCH("lvt_conv_wgrad_frames_kernel");
+    if (role == 1) {
+        unpack_plain(p.partial, p.partial_stride, splits, dw, g, Ci_real, Co_real, s);
+    } else {
+        const long long total = 9LL * g->Ci * g->Co;
+        hipLaunchKernelGGL(lvt_unpack_wgrad_swapped_kernel, dim3((unsigned)(lvt_cdiv(total, 256) < 4096 ? lvt_cdiv(total, 256) : 4096)),
+                           dim3(256), 0, s, (const float *)p.partial, p.partial_stride, splits, dw, g->Ci, g->Co, Ci_real, Co_real);
+    }
+    LVT_CHECK_LAUNCH("wgrad unpack");
+    return LVT_OK;
+}

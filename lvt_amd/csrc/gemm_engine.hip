@@ -1446,6 +1446,26 @@ extern "C" int lvt_conv3d_bwd_data(const lvt_conv_geom *g, const float *dy, cons
     return launch_tile<A_CONVT_K, B_CONVT_W, 128, 128, 2, 2>(p, ncls, (hipStream_t)stream);
 }
 
+// frame-resident weight gradient of the 3x3 layers (conv_wgrad.hip)
+int lvt_wgrad_frames_role(const lvt_conv_geom *g);
+size_t lvt_wgrad_frames_workspace_bytes(const lvt_conv_geom *g);
+int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, int Ci_real, int Co_real,
+                            void *workspace, hipStream_t s, void (*unpack_plain)(const float *, long long, int, float *,
+                                                                                 const lvt_conv_geom *, int, int, hipStream_t));
+static void unpack_plain_wgrad(const float *partial, long long stride, int splits, float *dw, const lvt_conv_geom *g,
+                               int Ci_real, int Co_real, hipStream_t s) {
+    const int taps = g->Kt * g->Kh * g->Kw;
+    const long long total = (long long)taps * g->Ci * g->Co;
+    int L = 1;
+    while (L < 64 && L * 4 <= splits) L <<= 1;
+    long long blocks = lvt_cdiv(total * L, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(lvt_unpack_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, partial, stride, splits, L, dw, taps,
+                       g->Ci, g->Co, Ci_real, Co_real, (const float *)nullptr, (float *)nullptr);
+}
+// 1 when lvt_conv3d_bwd_weight also produces the bias gradient (db) for this geometry; the frame-resident path does not
+extern "C" int lvt_conv3d_bwd_weight_fuses_bias(const lvt_conv_geom *g) { return g && lvt_wgrad_frames_role(g) == 0 ? 1 : 0; }
+
 static int bwd_weight_splits(const lvt_conv_geom *g) {
     const long long Mg = (long long)g->Kt * g->Kh * g->Kw * g->Ci;
     const long long tiles = lvt_cdiv(Mg, Mg <= 64 ? 64 : 128) * lvt_cdiv(g->Co, 128);
@@ -1457,7 +1477,9 @@ static int bwd_weight_splits(const lvt_conv_geom *g) {
 extern "C" size_t lvt_conv3d_bwd_weight_workspace_bytes(const lvt_conv_geom *g) {
     if (!g) return 0;
     const long long Mg = (long long)g->Kt * g->Kh * g->Kw * g->Ci;
-    return (size_t)bwd_weight_splits(g) * (Mg + 1) * g->Co * sizeof(float);      // + one row per split: column sums
+    const size_t generic = (size_t)bwd_weight_splits(g) * (Mg + 1) * g->Co * sizeof(float);      // + one row per split: column sums
+    const size_t frames = lvt_wgrad_frames_workspace_bytes(g);
+    return frames > generic ? frames : generic;
 }
 
 extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, float *db,
@@ -1472,6 +1494,11 @@ extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, con
     }
     const long long pix = (long long)g->N * g->To * g->Ho * g->Wo;
     LVT_REQUIRE(pix < 0x7fffffffLL, "conv3d_bwd_weight: too many positions");
+    if (lvt_wgrad_frames_role(g) && lvt_aligned16(x) && lvt_aligned16(dy)) {
+        LVT_REQUIRE(!db, "conv3d_bwd_weight: this geometry runs on the frame-resident kernel, which leaves the bias gradient "
+                         "to lvt_colsum (see lvt_conv3d_bwd_weight_fuses_bias)");
+        return lvt_wgrad_frames_launch(g, x, dy, dw, Ci_real, Co_real, workspace, (hipStream_t)stream, unpack_plain_wgrad);
+    }
     const int taps = g->Kt * g->Kh * g->Kw;
     KParams p; memset(&p, 0, sizeof(p));
     p.M = taps * g->Ci; p.N = g->Co; p.K = (int)pix;

@@ -74,6 +74,7 @@ def _declare(lib):
         "lvt_conv3d_fwd": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
         "lvt_conv3d_bwd_data": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
         "lvt_conv3d_bwd_weight_workspace_bytes": (sz, [P(ConvGeom)]),
+        "lvt_conv3d_bwd_weight_fuses_bias": (ci, [P(ConvGeom)]),
         "lvt_conv3d_bwd_weight": (ci, [P(ConvGeom), vp, vp, vp, vp, ci, ci, vp, sz, vp]),
         "lvt_convt4_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]),
         "lvt_colsum_workspace_bytes": (sz, [cll, ci]),

@@ -215,7 +215,9 @@ def conv_bwd_weight(g, x, dy, Ci_real, Co_real, want_bias=False):
     dw = torch.empty(Co_real, Ci_real, g.Kt, g.Kh, g.Kw, dtype=torch.float32, device=x.device)
     nws = lib.lvt_conv3d_bwd_weight_workspace_bytes(C.byref(g))
     ws = L.workspace(nws, x.device, "wgrad")
-    db = torch.empty(Co_real, dtype=torch.float32, device=x.device) if want_bias else None
+    # (the frame-resident kernel of the 3x3 layers leaves the bias gradient to a column-sum launch: db stays None)
+    fused_bias = want_bias and bool(lib.lvt_conv3d_bwd_weight_fuses_bias(C.byref(g)))
+    db = torch.empty(Co_real, dtype=torch.float32, device=x.device) if fused_bias else None
     t0 = L.TIMER.begin() if L.TIMER is not None else None
     L.check(lib.lvt_conv3d_bwd_weight(C.byref(g), L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), Ci_real, Co_real, L.ptr(ws),
                                       nws, L.stream_ptr()), "lvt_conv3d_bwd_weight")

@@ -135,9 +135,32 @@ def golden_vqvae():
     save("g4_decoder", seed=SEED, scale=zstd, z=z, x_tilde=xt)
 
     # G5 full supervised loss + grads, B=2 frames and B=1 clip of 16 frames ------------------------
+    # The clip input is chosen (first of a seeded family) so that EVERY one of its 16 x 1024 code searches has a clear
+    # margin between the nearest and the second-nearest code: the fixture then pins losses, gradients and EMA state
+    # for any correct fp32 implementation, independent of how sub-margin ties happen to round.
+    sys.path.insert(0, ROOT)
+    from oracle import lvt_oracle as O
+    clip_name = None
+    for v in range(400):
+        cand = seeded.seeded_input("g5.c%d" % v, (16, 3, 64, 64), SEED)
+        with torch.no_grad():
+            z = model.encoder(model.normalizer(cand))
+        worst = 1.0
+        for i in range(4):
+            rows = z[:, 64 * i:64 * (i + 1)].permute(0, 2, 3, 1).reshape(-1, 64)
+            cb = state0["ve.%d.embedding.weight" % i]
+            d0, d1, _ = O.vq_margin_fp64(rows, cb)
+            scale = (rows.double() ** 2).sum(-1) + (cb.double() ** 2).sum(-1).max()
+            worst = min(worst, float(((d1 - d0) / scale).min()))
+        print("  candidate %d: smallest relative margin %.2e" % (v, worst))
+        if worst > 8e-6:
+            clip_name = "g5.c%d" % v
+            print("G5 clip input: %s (smallest relative top-2 margin %.2e)" % (clip_name, worst))
+            break
+    assert clip_name is not None
     for tag, data in (("frames", [{"image": seeded.seeded_input("g5.f%d" % i, (3, 64, 64), SEED).numpy()}
                                   for i in range(2)]),
-                      ("clip", [{"image_sequence": seeded.seeded_input("g5.c", (16, 3, 64, 64), SEED).numpy()}])):
+                      ("clip", [{"image_sequence": seeded.seeded_input(clip_name, (16, 3, 64, 64), SEED).numpy()}])):
         dealias_codebook(model.codebook, state0)
         model.zero_grad()
         model.train()
@@ -147,7 +170,7 @@ def golden_vqvae():
         g = {n: p.grad.clone() for n, p in list(model.encoder.named_parameters()) +
              [("G." + n, p) for n, p in model.generator.named_parameters()]}
         st = cb_state_of(model.codebook)
-        save("g5_vqvae_loss_" + tag, seed=SEED, scale=zstd,
+        save("g5_vqvae_loss_" + tag, seed=SEED, scale=zstd, input_name=np.array(clip_name if tag == "clip" else "g5.f"),
              loss_reconstruction=losses["loss_reconstruction"], loss_commitment=losses["loss_commitment"],
              grad_enc_first=g["layers.0.weight"], grad_enc_first_bias=g["layers.0.bias"],
              grad_enc_last=g["layers.6.block.3.weight"], grad_enc_mid_rows=g["layers.4.weight"][:8],

@@ -224,6 +224,28 @@ def test_frame_resident_conv_forward_and_backward_data(Ci, Co, N, math_mode):
     assert rel_err(dx, dx2) < TOL
 
 
+@pytest.mark.parametrize("Ci,Co,N", [(256, 256, 37), (256, 128, 5), (64, 256, 2), (256, 32, 70)])
+def test_frame_resident_weight_gradient(Ci, Co, N, math_mode):
+    """Weight gradient of the 3x3 / pad 1 layers on 16x16 frames.  With 256 channels on one side and the default math mode
+    it runs on the frame-resident kernel (patch = x when Co == 256, else the roles are swapped and the taps reversed);
+    frame counts that do not divide into the workgroup splits included."""
+    from lvt_amd.hip import gemm as G, binding as L
+    import ctypes
+    H = 16
+    x, w = _rand(N, Ci, H, H), _rand(Co, Ci, 3, 3, seed=1) * 0.1
+    x.requires_grad_(True); w.requires_grad_(True)
+    y = F.conv2d(x, w, None, padding=1)
+    gy = _rand(*y.shape, seed=3) * (torch.arange(N).view(N, 1, 1, 1) % 3 + 1)        # frames carry different weights
+    y.backward(gy)
+    dev = _dev()
+    g = G.conv_geom(N, 1, H, H, Ci, Co, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    fused = L.lib().lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g))
+    assert fused == (0 if math_mode == "bf16x3" else 1)
+    dw, db = G.conv_bwd_weight(g, _nhwc(x.detach()).to(dev), _nhwc(gy).to(dev), Ci, Co, want_bias=True)
+    assert (db is None) == (fused == 0)
+    assert rel_err(dw.squeeze(2), w.grad) < 5e-5
+
+
 def test_conv3d_causal_geometry():
     """MaskedConv3d geometry (K16): kernel 3x3x3, front pads (2,2,1), T=2 to exercise the t taps."""
     from lvt_amd.hip import gemm as G

@@ -70,7 +70,7 @@ def test_g5_vqvae_loss_and_grads(golden, tag):
     if tag == "frames":
         x = torch.stack([seeded.seeded_input("g5.f%d" % i, (3, 64, 64), seed) for i in range(2)])
     else:
-        x = seeded.seeded_input("g5.c", (16, 3, 64, 64), seed)
+        x = seeded.seeded_input(str(g["input_name"]), (16, 3, 64, 64), seed)
     losses, new, _ = O.vqvae_supervised_loss(enc, dec, st0, O.normalize(x, MEAN, STD))
     sum(losses.values()).backward()
     assert abs(float(losses["loss_reconstruction"]) - float(g["loss_reconstruction"])) < 1e-6
