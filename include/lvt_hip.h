@@ -13,7 +13,9 @@
  *     nothing is allocated inside; scratch is a caller-provided workspace.
  *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*).
  *   - activations are CHANNELS-LAST: (N, T, H, W, C) with C fastest; a frame batch is T == 1.
- *   - arithmetic is fp32 with fp32 accumulation on the matrix cores (v_mfma_f32_32x32x2_f32).
+ *   - arithmetic is fp32 in / fp32 out with fp32 accumulation on the matrix cores: by default every product is formed
+ *     exactly from a 3-way bf16 split (six v_mfma_f32_32x32x16_bf16 per block), or on v_mfma_f32_32x32x2_f32 when a
+ *     call carries LVT_MATH_F32 (see below).
  */
 #ifndef LVT_HIP_H
 #define LVT_HIP_H
@@ -34,14 +36,15 @@ int lvt_version(void);
 /* Device probe: name, CU count, clock (kHz), HBM bytes.  Returns LVT_ENODEVICE without a GPU. */
 int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long long *hbm_bytes);
 
-/* Arithmetic of the GEMM / conv engine.  Operands, results and accumulators are fp32 in both modes.
- *   1 (default) "bf16x3": every fp32 operand is split exactly into three bf16 terms (24 mantissa bits) while it is
- *       staged in LDS, and each product block is six v_mfma_f32_32x32x16_bf16 (a1b1 a1b2 a2b1 a1b3 a3b1 a2b2, each
+/* Arithmetic of the GEMM / conv engine.  Operands, results and accumulators are fp32 in both modes; the mode is chosen
+ * PER CALL by LVT_MATH_F32 in the `flags` of an entry point -- the library holds no mutable state (thread-safe by
+ * construction: the thread that runs a backward pass is not the one that ran the forward).
+ *   flag clear (default) "bf16x3": every fp32 operand is split exactly into three bf16 terms (24 mantissa bits) while
+ *       it is staged in LDS, and each product block is six v_mfma_f32_32x32x16_bf16 (a1b1 a1b2 a2b1 a1b3 a3b1 a2b2, each
  *       bf16 x bf16 product exact in the fp32 accumulator; dropped terms are below 2^-24 |a||b|).  Measured error
- *       against fp64 is not larger than mode 0's (tests/test_gpu_engine.py::test_math_modes_accuracy).
- *   0 "f32": plain v_mfma_f32_32x32x2_f32.                                                                   */
-int lvt_set_math_mode(int mode);
-int lvt_get_math_mode(void);
+ *       against fp64 is not larger than the fp32 instruction's (tests/test_gpu_engine.py::test_math_modes_accuracy).
+ *   LVT_MATH_F32 "f32": plain v_mfma_f32_32x32x2_f32.                                                          */
+#define LVT_MATH_F32   (1 << 16)
 
 /* ---- epilogue flags shared by GEMM / conv ------------------------------------------------------ */
 #define LVT_EPI_BIAS        1   /* + bias[n]                                                  */
@@ -127,7 +130,7 @@ int lvt_conv3d_pack_weight(const lvt_conv_geom *g, const float *w, int Ci_real, 
  * frame-resident kernel (lvt_conv3d_uses_patch_kernel), which stages every input element once instead of once per tap. */
 int lvt_conv3d_pack_weight_t(const lvt_conv_geom *g, const float *w, int Ci_real, int Co_real,
                              float *wt, void *stream);
-int lvt_conv3d_uses_patch_kernel(const lvt_conv_geom *g);
+int lvt_conv3d_uses_patch_kernel(const lvt_conv_geom *g, int flags);
 /* y = epi( conv(x, wp) ); bias[Co]; res / y are (N,To,Ho,Wo,Co).  flags: BIAS|RESIDUAL|RELU|TANH|MASK */
 int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias,
                    const float *res, const float *mask, float *y, int flags, void *stream);
@@ -143,9 +146,10 @@ size_t lvt_conv3d_bwd_weight_workspace_bytes(const lvt_conv_geom *g);
 /* 1 when lvt_conv3d_bwd_weight can also produce db for this geometry.  The 3x3 / pad 1 layers of 16x16 frames with 256
  * channels on one side run on the frame-resident weight-gradient kernel (csrc/conv_wgrad.hip: patch and dy row staged once
  * per frame / image row, taps are row offsets of a transposing LDS read); pass db == NULL there and use lvt_colsum(dy). */
-int lvt_conv3d_bwd_weight_fuses_bias(const lvt_conv_geom *g);
+int lvt_conv3d_bwd_weight_fuses_bias(const lvt_conv_geom *g, int flags);
+/* flags: 0 or LVT_MATH_F32 */
 int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, float *db,
-                          int Ci_real, int Co_real, void *workspace, size_t workspace_bytes,
+                          int Ci_real, int Co_real, int flags, void *workspace, size_t workspace_bytes,
                           void *stream);
 /* Image-side layer (3 channels carried as 4): LDS-tiled fp32 FMA kernel that reads the 128-channel activation exactly
  * once instead of spending MFMA tiles on padding columns.
@@ -162,12 +166,12 @@ int lvt_colsum(const float *g, long long M, int N, long long ld, float *out, voi
  * z: [rows][ldz] channels-last activations, group g owns columns [g*D, (g+1)*D).  codebooks: [num][KC][D].
  * idx: int64 [rows/P][num][P]  (== the reference's (N, num, H, W) layout with P = H*W).
  * lvt_vq_nearest: idx = argmin_k |e_k|^2 + |x|^2 - 2 x.e_k in fp32, lowest k on ties (torch.min).  In the default
- * (bf16x3) math mode the product runs on the bf16 matrix cores, one workgroup per codebook half, and the per-half
+ * (bf16x3) math mode (flags without LVT_MATH_F32) the product runs on the bf16 matrix cores, one workgroup per codebook half, and the per-half
  * (distance, index) candidates go through `workspace`; without a workspace, or in f32 mode, the fp32-MFMA kernel
  * with the whole codebook LDS-resident is used.                                                           */
 size_t lvt_vq_nearest_workspace_bytes(long long rows, int num, int KC);
 int lvt_vq_nearest(const float *z, long long rows, int ldz, int num, int D, int KC,
-                   const float *codebooks, long long *idx, int P, void *workspace, size_t workspace_bytes,
+                   const float *codebooks, long long *idx, int P, int flags, void *workspace, size_t workspace_bytes,
                    void *stream);
 /* out[row][g*D+d] = codebooks[g][idx][d]   (index_select / embedding: z_q_st, z_q_bar, mode "emb")   */
 int lvt_vq_gather(const long long *idx, const float *codebooks, long long rows, int num, int D, int KC,
@@ -259,7 +263,7 @@ int lvt_embbag_fwd(const long long *idx, long long bstride, int P, long long row
 size_t lvt_onehot_tn_workspace_bytes(int nslots, int V, int N, long long rows);
 int lvt_onehot_tn_gemm(const long long *idx, int nslots, int V, const int *slot_off, long long bstride,
                        long long pstride, int P, long long rows, const float *dout, long long ldb, int N,
-                       float *out, void *workspace, size_t workspace_bytes, void *stream);
+                       float *out, int flags, void *workspace, size_t workspace_bytes, void *stream);
 /* out (n0,n1,n2) contiguous <- in[i0*s0 + i1*s1 + i2*s2]  (weight re-layouts)                         */
 int lvt_permute3(const float *in, long long s0, long long s1, long long s2, int n0, int n1, int n2,
                  float *out, void *stream);

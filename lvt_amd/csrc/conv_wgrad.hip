@@ -195,10 +195,9 @@ __global__ void lvt_unpack_wgrad_swapped_kernel(const float *__restrict__ partia
 }
 
 // ---- host side (called from lvt_conv3d_bwd_weight in gemm_engine.hip) -----------------------------------------------
-extern "C" int lvt_get_math_mode(void);
-static int wg_role(const lvt_conv_geom *g) {       // 0: not served, 1: patch = x / slab = dy, 2: swapped
+static int wg_role(const lvt_conv_geom *g, int flags = 0) {       // 0: not served, 1: patch = x / slab = dy, 2: swapped
     static const int off = getenv("LVT_NO_FRAME_WGRAD") ? 1 : 0;
-    if (off || lvt_get_math_mode() != 1) return 0;
+    if (off || (flags & LVT_MATH_F32)) return 0;
     const bool shape = g->Kt == 1 && g->Kh == 3 && g->Kw == 3 && g->st == 1 && g->sh == 1 && g->sw == 1 && g->pt == 0 &&
                        g->ph == 1 && g->pw == 1 && g->Ti == 1 && g->Hi == 16 && g->Wi == 16 && g->To == 1 && g->Ho == 16 &&
                        g->Wo == 16;
@@ -213,7 +212,7 @@ static int wg_splits(const lvt_conv_geom *g, int role) {
     if (s > g->N) s = g->N;
     return s < 1 ? 1 : s;
 }
-int lvt_wgrad_frames_role(const lvt_conv_geom *g) { return wg_role(g); }
+int lvt_wgrad_frames_role(const lvt_conv_geom *g, int flags) { return wg_role(g, flags); }
 size_t lvt_wgrad_frames_workspace_bytes(const lvt_conv_geom *g) {
     const int role = wg_role(g);
     if (!role) return 0;

@@ -1210,13 +1210,10 @@ __global__ __launch_bounds__(CS_THREADS) void lvt_colsum_kernel(const float *__r
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int g_math_mode = 1;     // 0: plain fp32 MFMA, 1: bf16x3 split MFMA (default)
-extern "C" int lvt_set_math_mode(int mode) {
-    LVT_REQUIRE(mode == 0 || mode == 1, "set_math_mode: unknown mode %d", mode);
-    g_math_mode = mode;
-    return LVT_OK;
-}
-extern "C" int lvt_get_math_mode(void) { return g_math_mode; }
+// The arithmetic of a launch is chosen PER CALL by LVT_MATH_F32 in its `flags` (clear: bf16x3, the default; set: plain
+// fp32 MFMA): the library keeps no mutable state, so concurrent callers (the autograd thread runs the backward launches
+// of a forward issued from another thread) cannot influence each other.
+static inline int math_of(int flags) { return (flags & LVT_MATH_F32) ? 0 : 1; }
 
 template <int AMODE, int BMODE, int BM, int BN, int WM, int WN>
 static int launch_tile(const KParams &p, int zcount, hipStream_t s) {
@@ -1239,7 +1236,7 @@ static int launch_tile(const KParams &p, int zcount, hipStream_t s) {
         }
         pv.vec_epi = ok ? 1 : 0;
     }
-    if (g_math_mode == 1 && BK == 32)
+    if (math_of(p.flags) == 1 && BK == 32)
         hipLaunchKernelGGL((lvt_gemm_kernel<AMODE, BMODE, BM, BN, WM, WN, 1>), grid, dim3(NTHREADS), 0, s, pv);
     else
         hipLaunchKernelGGL((lvt_gemm_kernel<AMODE, BMODE, BM, BN, WM, WN, 0>), grid, dim3(NTHREADS), 0, s, pv);
@@ -1300,7 +1297,7 @@ extern "C" int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t work
     KParams p; kparams_from_desc(d, p);
     const int zc = gemm_batch(d);
     if (p.splits > 1) {
-        LVT_REQUIRE((d->flags & ~LVT_EPI_ACCUM) == 0 && d->alpha == 1.0f, "gemm: split-K allows only ACCUM");
+        LVT_REQUIRE((d->flags & ~(LVT_EPI_ACCUM | LVT_MATH_F32)) == 0 && d->alpha == 1.0f, "gemm: split-K allows only ACCUM");
         LVT_REQUIRE(d->ldc == d->N && (zc == 1 || (d->sC_i == (long long)d->M * d->N)),
                     "gemm: split-K needs a dense C (ldc == N)");
         LVT_REQUIRE(((long long)d->M * d->N) % 4 == 0 && lvt_aligned16(d->C), "gemm: split-K C alignment");
@@ -1379,13 +1376,13 @@ extern "C" int lvt_conv3d_pack_weight_t(const lvt_conv_geom *g, const float *w, 
 }
 
 // the frame-resident kernel serves 3x3 / stride 1 / pad 1 convolutions of 16x16 frames with Ci % 32 == 0, Co % 128 == 0
-static bool patch_conv_eligible(const lvt_conv_geom *g) {
+static bool patch_conv_eligible(const lvt_conv_geom *g, int flags) {
     static const int off = getenv("LVT_NO_PATCH_CONV") ? 1 : 0;
-    return !off && g_math_mode == 1 && BK == 32 && g->Kt == 1 && g->Kh == 3 && g->Kw == 3 && g->st == 1 && g->sh == 1 &&
+    return !off && math_of(flags) == 1 && BK == 32 && g->Kt == 1 && g->Kh == 3 && g->Kw == 3 && g->st == 1 && g->sh == 1 &&
            g->sw == 1 && g->pt == 0 && g->ph == 1 && g->pw == 1 && g->Ti == 1 && g->Hi == 16 && g->Wi == 16 && g->To == 1 &&
            g->Ho == 16 && g->Wo == 16 && g->Ci % 32 == 0 && g->Co % 128 == 0;
 }
-extern "C" int lvt_conv3d_uses_patch_kernel(const lvt_conv_geom *g) { return g && patch_conv_eligible(g) ? 1 : 0; }
+extern "C" int lvt_conv3d_uses_patch_kernel(const lvt_conv_geom *g, int flags) { return g && patch_conv_eligible(g, flags) ? 1 : 0; }
 
 extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias,
                               const float *res, const float *mask, float *y, int flags, void *stream) {
@@ -1404,7 +1401,7 @@ extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const floa
     p.splits = 1; p.g = *g;
     {
         auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
-        bool ok = patch_conv_eligible(g) && al16(x) && al16(wp) && al16(y);
+        bool ok = patch_conv_eligible(g, flags) && al16(x) && al16(wp) && al16(y);
         if (flags & LVT_EPI_BIAS) ok = ok && al16(bias);
         if (flags & LVT_EPI_RESIDUAL) ok = ok && al16(res);
         if (flags & LVT_EPI_MASK) ok = ok && al16(mask);
@@ -1447,7 +1444,7 @@ extern "C" int lvt_conv3d_bwd_data(const lvt_conv_geom *g, const float *dy, cons
 }
 
 // frame-resident weight gradient of the 3x3 layers (conv_wgrad.hip)
-int lvt_wgrad_frames_role(const lvt_conv_geom *g);
+int lvt_wgrad_frames_role(const lvt_conv_geom *g, int flags);
 size_t lvt_wgrad_frames_workspace_bytes(const lvt_conv_geom *g);
 int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, int Ci_real, int Co_real,
                             void *workspace, hipStream_t s, void (*unpack_plain)(const float *, long long, int, float *,
@@ -1464,7 +1461,7 @@ static void unpack_plain_wgrad(const float *partial, long long stride, int split
                        g->Ci, g->Co, Ci_real, Co_real, (const float *)nullptr, (float *)nullptr);
 }
 // 1 when lvt_conv3d_bwd_weight also produces the bias gradient (db) for this geometry; the frame-resident path does not
-extern "C" int lvt_conv3d_bwd_weight_fuses_bias(const lvt_conv_geom *g) { return g && lvt_wgrad_frames_role(g) == 0 ? 1 : 0; }
+extern "C" int lvt_conv3d_bwd_weight_fuses_bias(const lvt_conv_geom *g, int flags) { return g && lvt_wgrad_frames_role(g, flags) == 0 ? 1 : 0; }
 
 static int bwd_weight_splits(const lvt_conv_geom *g) {
     const long long Mg = (long long)g->Kt * g->Kh * g->Kw * g->Ci;
@@ -1483,7 +1480,7 @@ extern "C" size_t lvt_conv3d_bwd_weight_workspace_bytes(const lvt_conv_geom *g) 
 }
 
 extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, float *db,
-                                     int Ci_real, int Co_real, void *workspace, size_t workspace_bytes,
+                                     int Ci_real, int Co_real, int flags, void *workspace, size_t workspace_bytes,
                                      void *stream) {
     int rc = check_geom(g, "conv3d_bwd_weight"); if (rc) return rc;
     LVT_REQUIRE(x && dy && dw && Ci_real <= g->Ci && Co_real <= g->Co, "conv3d_bwd_weight: bad args");
@@ -1494,7 +1491,8 @@ extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, con
     }
     const long long pix = (long long)g->N * g->To * g->Ho * g->Wo;
     LVT_REQUIRE(pix < 0x7fffffffLL, "conv3d_bwd_weight: too many positions");
-    if (lvt_wgrad_frames_role(g) && lvt_aligned16(x) && lvt_aligned16(dy)) {
+    LVT_REQUIRE((flags & ~LVT_MATH_F32) == 0, "conv3d_bwd_weight: only LVT_MATH_F32 is accepted in flags");
+    if (lvt_wgrad_frames_role(g, flags) && lvt_aligned16(x) && lvt_aligned16(dy)) {
         LVT_REQUIRE(!db, "conv3d_bwd_weight: this geometry runs on the frame-resident kernel, which leaves the bias gradient "
                          "to lvt_colsum (see lvt_conv3d_bwd_weight_fuses_bias)");
         return lvt_wgrad_frames_launch(g, x, dy, dw, Ci_real, Co_real, workspace, (hipStream_t)stream, unpack_plain_wgrad);
@@ -1502,7 +1500,7 @@ extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, con
     const int taps = g->Kt * g->Kh * g->Kw;
     KParams p; memset(&p, 0, sizeof(p));
     p.M = taps * g->Ci; p.N = g->Co; p.K = (int)pix;
-    p.A = x; p.B = dy; p.ldb = g->Co; p.batch_inner = 1; p.alpha = 1.f; p.g = *g;
+    p.A = x; p.B = dy; p.ldb = g->Co; p.batch_inner = 1; p.alpha = 1.f; p.g = *g; p.flags = flags;
     p.splits = bwd_weight_splits(g);
     p.k_per_split = (int)(lvt_cdiv(lvt_cdiv(p.K, p.splits), BK) * BK);
     p.partial = (float *)workspace;
@@ -1535,7 +1533,7 @@ extern "C" size_t lvt_onehot_tn_workspace_bytes(int nslots, int V, int N, long l
 }
 extern "C" int lvt_onehot_tn_gemm(const long long *idx, int nslots, int V, const int *slot_off, long long bstride,
                                   long long pstride, int P, long long rows, const float *dout, long long ldb, int N,
-                                  float *out, void *workspace, size_t workspace_bytes, void *stream) {
+                                  float *out, int flags, void *workspace, size_t workspace_bytes, void *stream) {
     LVT_REQUIRE(idx && slot_off && dout && out && nslots > 0 && nslots <= 32 && V > 0 && V % 4 == 0,
                 "onehot_tn_gemm: bad args");
     LVT_REQUIRE(rows > 0 && rows < 0x7fffffffLL && P > 0 && rows % P == 0 && N % 4 == 0 && ldb % 4 == 0,
@@ -1547,7 +1545,7 @@ extern "C" int lvt_onehot_tn_gemm(const long long *idx, int nslots, int V, const
     }
     KParams p; memset(&p, 0, sizeof(p));
     p.M = nslots * V; p.N = N; p.K = (int)rows;
-    p.B = dout; p.ldb = ldb; p.batch_inner = 1; p.alpha = 1.f;
+    p.B = dout; p.ldb = ldb; p.batch_inner = 1; p.alpha = 1.f; p.flags = flags & LVT_MATH_F32;
     p.oh_idx = idx; p.oh_bstride = bstride; p.oh_pstride = pstride; p.oh_P = P; p.oh_V = V;
     for (int i = 0; i < nslots; ++i) p.oh_off[i] = slot_off[i];
     p.splits = onehot_splits(p.M, N, rows);

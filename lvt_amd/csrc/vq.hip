@@ -430,15 +430,13 @@ __global__ __launch_bounds__(512) void lvt_vq_ema_finalize_kernel(const float *_
 // ------------------------------------------------------------------------------------------------
 static int vq_smem_bytes(int KC) { return (VQ_D * (KC + 1) + KC) * (int)sizeof(float); }
 
-extern "C" int lvt_get_math_mode(void);
-
 extern "C" size_t lvt_vq_nearest_workspace_bytes(long long rows, int num, int KC) {
     const int nparts = KC / VQH_CODES > 0 ? KC / VQH_CODES : 1;
     return (size_t)rows * num * nparts * (sizeof(float) + sizeof(int));
 }
 
 extern "C" int lvt_vq_nearest(const float *z, long long rows, int ldz, int num, int D, int KC,
-                              const float *codebooks, long long *idx_out, int P, void *workspace,
+                              const float *codebooks, long long *idx_out, int P, int flags, void *workspace,
                               size_t workspace_bytes, void *stream) {
     LVT_REQUIRE(z && codebooks && idx_out, "vq_nearest: null pointer");
     LVT_REQUIRE(D == VQ_D, "vq_nearest: only D=%d per codebook is instantiated (got %d)", VQ_D, D);
@@ -446,7 +444,7 @@ extern "C" int lvt_vq_nearest(const float *z, long long rows, int ldz, int num, 
     LVT_REQUIRE(rows > 0 && num > 0 && P > 0 && rows % P == 0, "vq_nearest: bad rows/P");
     LVT_REQUIRE(ldz % 4 == 0 && ldz >= num * D && lvt_aligned16(z) && lvt_aligned16(codebooks),
                 "vq_nearest: alignment / ldz");
-    if (lvt_get_math_mode() == 1 && KC % VQH_CODES == 0 && workspace &&
+    if (!(flags & LVT_MATH_F32) && KC % VQH_CODES == 0 && workspace &&
         workspace_bytes >= lvt_vq_nearest_workspace_bytes(rows, num, KC)) {
         const int nparts = KC / VQH_CODES;
         float *pbest = (float *)workspace;

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("LVT_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "liblvt_hip.so")
 
 EPI_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_TANH, EPI_MASK, EPI_ACCUM = 1, 2, 4, 8, 16, 32
+MATH_F32 = 1 << 16          # per-call arithmetic selector of the engine entry points (include/lvt_hip.h)
 
 
 class LvtError(RuntimeError):
@@ -59,8 +60,6 @@ def _declare(lib):
         "lvt_last_error": (C.c_char_p, []),
         "lvt_version": (ci, []),
         "lvt_device_info": (ci, [C.c_char_p, ci, P(ci), P(ci), P(cll)]),
-        "lvt_set_math_mode": (ci, [ci]),
-        "lvt_get_math_mode": (ci, []),
         "lvt_gemm_workspace_bytes": (sz, [P(GemmDesc)]),
         "lvt_gemm_f32": (ci, [P(GemmDesc), vp, sz, vp]),
         "lvt_gemm_smallm_f32": (ci, [ci, ci, ci, ci, vp, cll, vp, cll, vp, cll, ci, cll, cll, cf, ci, vp, vp, cll, vp]),
@@ -70,17 +69,17 @@ def _declare(lib):
         "lvt_splitsum_layernorm_fwd": (ci, [vp, ci, ci, ci, vp, vp, cll, vp, cf, vp, vp, vp, vp]),
         "lvt_conv3d_pack_weight": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
         "lvt_conv3d_pack_weight_t": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
-        "lvt_conv3d_uses_patch_kernel": (ci, [P(ConvGeom)]),
+        "lvt_conv3d_uses_patch_kernel": (ci, [P(ConvGeom), ci]),
         "lvt_conv3d_fwd": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
         "lvt_conv3d_bwd_data": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
         "lvt_conv3d_bwd_weight_workspace_bytes": (sz, [P(ConvGeom)]),
-        "lvt_conv3d_bwd_weight_fuses_bias": (ci, [P(ConvGeom)]),
-        "lvt_conv3d_bwd_weight": (ci, [P(ConvGeom), vp, vp, vp, vp, ci, ci, vp, sz, vp]),
+        "lvt_conv3d_bwd_weight_fuses_bias": (ci, [P(ConvGeom), ci]),
+        "lvt_conv3d_bwd_weight": (ci, [P(ConvGeom), vp, vp, vp, vp, ci, ci, ci, vp, sz, vp]),
         "lvt_convt4_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]),
         "lvt_colsum_workspace_bytes": (sz, [cll, ci]),
         "lvt_colsum": (ci, [vp, cll, ci, cll, vp, vp, sz, vp]),
         "lvt_vq_nearest_workspace_bytes": (sz, [cll, ci, ci]),
-        "lvt_vq_nearest": (ci, [vp, cll, ci, ci, ci, ci, vp, vp, ci, vp, sz, vp]),
+        "lvt_vq_nearest": (ci, [vp, cll, ci, ci, ci, ci, vp, vp, ci, ci, vp, sz, vp]),
         "lvt_vq_gather": (ci, [vp, vp, cll, ci, ci, ci, ci, vp, ci, vp]),
         "lvt_vq_ema_workspace_bytes": (sz, [cll, ci, ci, ci]),
         "lvt_vq_ema_accumulate": (ci, [vp, vp, cll, ci, ci, ci, ci, ci, vp, vp, sz, vp]),
@@ -103,7 +102,7 @@ def _declare(lib):
         "lvt_sample_categorical": (ci, [vp, cll, ci, cf, vp, vp, cll, vp, vp]),
         "lvt_embbag_fwd": (ci, [vp, cll, ci, cll, ci, P(ci), P(ci), vp, ci, vp, vp, vp, vp, vp]),
         "lvt_onehot_tn_workspace_bytes": (sz, [ci, ci, ci, cll]),
-        "lvt_onehot_tn_gemm": (ci, [vp, ci, ci, P(ci), cll, cll, ci, cll, vp, cll, ci, vp, vp, sz, vp]),
+        "lvt_onehot_tn_gemm": (ci, [vp, ci, ci, P(ci), cll, cll, ci, cll, vp, cll, ci, vp, ci, vp, sz, vp]),
         "lvt_permute3": (ci, [vp, cll, cll, cll, ci, ci, ci, vp, vp]),
         "lvt_slice_context": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci, cll, vp, vp, vp, vp, vp]),
         "lvt_xent_workspace_bytes": (sz, []),
@@ -133,21 +132,31 @@ def lib():
         handle = C.CDLL(_LIB_PATH)
         handle._lvt_sigs = _declare(handle)
         _lib = handle
-        mode = os.environ.get("LVT_MATH", "bf16x3")
-        if mode not in ("f32", "bf16x3"):
-            raise LvtError("LVT_MATH must be 'f32' or 'bf16x3' (got %r)" % mode)
-        handle.lvt_set_math_mode(1 if mode == "bf16x3" else 0)
     return _lib
+
+
+# The library itself is stateless: every engine call carries its arithmetic in `flags` (MATH_F32 or not).  The default the
+# Python wrappers pass is a host-side setting of this module (LVT_MATH environment variable, or set_math_mode()).
+_math_mode = os.environ.get("LVT_MATH", "bf16x3")
+if _math_mode not in ("f32", "bf16x3"):
+    raise LvtError("LVT_MATH must be 'f32' or 'bf16x3' (got %r)" % _math_mode)
 
 
 def set_math_mode(mode):
     """'bf16x3' (default: exact 3-way bf16 split of fp32 operands on the bf16 matrix cores, fp32 accumulation) or
-    'f32' (plain fp32 MFMA).  Process-wide; also selectable with the LVT_MATH environment variable."""
-    check(lib().lvt_set_math_mode({"f32": 0, "bf16x3": 1}[mode]), "lvt_set_math_mode")
+    'f32' (plain fp32 MFMA): what the wrappers of lvt_amd.hip put into the `flags` of the calls they issue from now on."""
+    global _math_mode
+    if mode not in ("f32", "bf16x3"):
+        raise LvtError("math mode must be 'f32' or 'bf16x3' (got %r)" % (mode,))
+    _math_mode = mode
 
 
 def get_math_mode():
-    return ("f32", "bf16x3")[lib().lvt_get_math_mode()]
+    return _math_mode
+
+
+def math_flag():
+    return MATH_F32 if _math_mode == "f32" else 0
 
 
 def declared_symbols():

@@ -20,7 +20,7 @@ def gemm(A, B, C_out, M, N, K, ta=0, tb=0, lda=None, ldb=None, ldc=None, a_kb=0,
     d.sA_o, d.sA_i = sA
     d.sB_o, d.sB_i = sB
     d.sC_o, d.sC_i = sC
-    d.alpha, d.flags = alpha, flags
+    d.alpha, d.flags = alpha, flags | L.math_flag()
     d.bias = bias.data_ptr() if bias is not None else None
     d.res = res.data_ptr() if res is not None else None
     d.ldr = ldr if res is not None and ldr else d.ldc
@@ -152,7 +152,7 @@ def bwd_data_as_conv(g):
     geometry is served by the frame-resident kernel (3x3 / pad 1 on 16x16 frames)."""
     if (g.st, g.sh, g.sw) != (1, 1, 1):
         return False
-    return bool(L.lib().lvt_conv3d_uses_patch_kernel(C.byref(swapped_geom(g))))
+    return bool(L.lib().lvt_conv3d_uses_patch_kernel(C.byref(swapped_geom(g)), L.math_flag()))
 
 
 def conv_fwd(g, x, wp, bias=None, res=None, mask=None, flags=0, timer_key="conv_fwd"):
@@ -166,7 +166,7 @@ def conv_fwd(g, x, wp, bias=None, res=None, mask=None, flags=0, timer_key="conv_
         flags |= L.EPI_MASK
     t0 = L.TIMER.begin() if L.TIMER is not None else None
     L.check(L.lib().lvt_conv3d_fwd(C.byref(g), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(mask), L.ptr(y),
-                                   flags, L.stream_ptr()), "lvt_conv3d_fwd")
+                                   flags | L.math_flag(), L.stream_ptr()), "lvt_conv3d_fwd")
     if t0 is not None:
         L.TIMER.end(timer_key, conv_flops(g), t0)
     return y
@@ -187,7 +187,7 @@ def conv_bwd_data(g, dy, wp, bias=None, res=None, mask=None, flags=0, wt=None):
         flags |= L.EPI_MASK
     t0 = L.TIMER.begin() if L.TIMER is not None else None
     L.check(L.lib().lvt_conv3d_bwd_data(C.byref(g), L.ptr(dy), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(mask),
-                                        L.ptr(dx), flags, L.stream_ptr()), "lvt_conv3d_bwd_data")
+                                        L.ptr(dx), flags | L.math_flag(), L.stream_ptr()), "lvt_conv3d_bwd_data")
     if t0 is not None:
         L.TIMER.end("conv_bwd_data", conv_flops(g), t0)
     return dx
@@ -216,11 +216,11 @@ def conv_bwd_weight(g, x, dy, Ci_real, Co_real, want_bias=False):
     nws = lib.lvt_conv3d_bwd_weight_workspace_bytes(C.byref(g))
     ws = L.workspace(nws, x.device, "wgrad")
     # (the frame-resident kernel of the 3x3 layers leaves the bias gradient to a column-sum launch: db stays None)
-    fused_bias = want_bias and bool(lib.lvt_conv3d_bwd_weight_fuses_bias(C.byref(g)))
+    fused_bias = want_bias and bool(lib.lvt_conv3d_bwd_weight_fuses_bias(C.byref(g), L.math_flag()))
     db = torch.empty(Co_real, dtype=torch.float32, device=x.device) if fused_bias else None
     t0 = L.TIMER.begin() if L.TIMER is not None else None
-    L.check(lib.lvt_conv3d_bwd_weight(C.byref(g), L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), Ci_real, Co_real, L.ptr(ws),
-                                      nws, L.stream_ptr()), "lvt_conv3d_bwd_weight")
+    L.check(lib.lvt_conv3d_bwd_weight(C.byref(g), L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), Ci_real, Co_real,
+                                      L.math_flag(), L.ptr(ws), nws, L.stream_ptr()), "lvt_conv3d_bwd_weight")
     if t0 is not None:
         L.TIMER.end("conv_bwd_weight", conv_flops(g), t0)
     return (dw, db) if want_bias else dw

@@ -82,7 +82,7 @@ def _onehot_once(idx, V, slot_off, bstride, pstride, P, rows, dout, N, ldb):
     ws = L.workspace(nws, dout.device, "onehot")
     t0 = L.TIMER.begin() if L.TIMER is not None else None
     L.check(lib.lvt_onehot_tn_gemm(L.ptr(idx), ns, V, _iarr(slot_off), bstride, pstride, P, rows, L.ptr(dout),
-                                   ldb if ldb is not None else N, N, L.ptr(out), L.ptr(ws), nws, L.stream_ptr()),
+                                   ldb if ldb is not None else N, N, L.ptr(out), L.math_flag(), L.ptr(ws), nws, L.stream_ptr()),
             "lvt_onehot_tn_gemm")
     if t0 is not None:
         L.TIMER.end("gemm_onehot_tn", 2.0 * ns * V * N * rows, t0)

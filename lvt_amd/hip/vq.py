@@ -13,8 +13,8 @@ def nearest(z, codebooks, P):
     lib = L.lib()
     nws = lib.lvt_vq_nearest_workspace_bytes(rows, num, K)
     ws = L.workspace(nws, z.device, "vq_nearest")
-    L.check(lib.lvt_vq_nearest(L.ptr(z), rows, ldz, num, D, K, L.ptr(codebooks), L.ptr(idx), P, L.ptr(ws), nws,
-                               L.stream_ptr()), "lvt_vq_nearest")
+    L.check(lib.lvt_vq_nearest(L.ptr(z), rows, ldz, num, D, K, L.ptr(codebooks), L.ptr(idx), P, L.math_flag(),
+                               L.ptr(ws), nws, L.stream_ptr()), "lvt_vq_nearest")
     return idx
 
 

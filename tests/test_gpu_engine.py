@@ -208,7 +208,7 @@ def test_frame_resident_conv_forward_and_backward_data(Ci, Co, N, math_mode):
     dev = _dev()
     g = G.conv_geom(N, 1, H, H, Ci, Co, (1, 3, 3), (1, 1, 1), (0, 1, 1))
     if math_mode == "bf16x3":
-        assert L.lib().lvt_conv3d_uses_patch_kernel(__import__("ctypes").byref(g)) == 1
+        assert L.lib().lvt_conv3d_uses_patch_kernel(__import__("ctypes").byref(g), L.math_flag()) == 1
     wd = w.to(dev)
     yd = G.conv_fwd(g, _nhwc(x).to(dev), G.pack_weight(g, wd, Ci, Co), bias=b.to(dev), res=_nhwc(res).to(dev), flags=L.EPI_RELU)
     assert rel_err(_nchw(yd), y) < TOL
@@ -239,7 +239,7 @@ def test_frame_resident_weight_gradient(Ci, Co, N, math_mode):
     y.backward(gy)
     dev = _dev()
     g = G.conv_geom(N, 1, H, H, Ci, Co, (1, 3, 3), (1, 1, 1), (0, 1, 1))
-    fused = L.lib().lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g))
+    fused = L.lib().lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g), L.math_flag())
     assert fused == (0 if math_mode == "bf16x3" else 1)
     dw, db = G.conv_bwd_weight(g, _nhwc(x.detach()).to(dev), _nhwc(gy).to(dev), Ci, Co, want_bias=True)
     assert (db is None) == (fused == 0)
