@@ -134,6 +134,14 @@ int lvt_conv3d_uses_patch_kernel(const lvt_conv_geom *g, int flags);
 /* y = epi( conv(x, wp) ); bias[Co]; res / y are (N,To,Ho,Wo,Co).  flags: BIAS|RESIDUAL|RELU|TANH|MASK */
 int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias,
                    const float *res, const float *mask, float *y, int flags, void *stream);
+/* The same pass for the 4x4 / stride 2 / pad 1 layers between 32x32 and 16x16 frames (Co % 32 == 0, Ci % 128 == 0) on the
+ * frame-resident kernel: every output phase (py, px) reads four taps of the ONE staged 18x18 patch of dy.  Weights packed
+ * per phase by lvt_conv3d_pack_weight_phases: wph[(py,px)][(a,b)][co][ci] = w[co][ci][3-py-2a][3-px-2b].               */
+int lvt_conv3d_bwd_data_uses_phase_kernel(const lvt_conv_geom *g, int flags);
+int lvt_conv3d_pack_weight_phases(const lvt_conv_geom *g, const float *w, int Ci_real, int Co_real,
+                                  float *wph, void *stream);
+int lvt_conv3d_bwd_data_phases(const lvt_conv_geom *g, const float *dy, const float *wph, const float *bias,
+                               const float *res, const float *mask, float *dx, int flags, void *stream);
 /* dx = epi( conv_transpose(dy, wp) ); res / mask / dx are (N,Ti,Hi,Wi,Ci).
  * flags: BIAS (bias[Ci], used when this IS a ConvTranspose forward) | RESIDUAL | RELU | TANH | MASK.
  * Requires Kt % st == 0 etc. and To*st == Ti-ish geometries produced by lvt_conv geometry helpers.  */

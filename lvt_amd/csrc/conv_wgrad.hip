@@ -62,7 +62,10 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
     __shared__ __attribute__((aligned(16))) unsigned short lds[3 * WG_PPL + 2 * 3 * WG_QPL];
     unsigned short *patch = lds, *slab0 = lds + 3 * WG_PPL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pc = blockIdx.x % p.nchunks, split = blockIdx.x / p.nchunks;
+    // workgroup b runs on XCD b % 8 and every XCD has its own L2: the chunks of one split read the same frames (all of
+    // the slab operand, the same patch pixels), so the split index is the fast one -- its low bits pick the XCD
+    const int nsplits = gridDim.x / p.nchunks;
+    const int split = blockIdx.x % nsplits, pc = blockIdx.x / nsplits;
     const int f0 = split * p.frames_per_split, f1 = min(p.N, f0 + p.frames_per_split);
     const int Cp = p.Cp;
 

@@ -33,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 #define NTHREADS 256
 
-enum { A_KPLAIN = 0, A_MPLAIN = 1, A_CONV_K = 2, A_CONVT_K = 3, A_CONV_M = 4, A_ONEHOT_M = 5, A_PATCH = 6 };
+enum { A_KPLAIN = 0, A_MPLAIN = 1, A_CONV_K = 2, A_CONVT_K = 3, A_CONV_M = 4, A_ONEHOT_M = 5, A_PATCH = 6, A_PATCHT = 7 };
 enum { B_KPLAIN = 0, B_NPLAIN = 1, B_CONVT_W = 2 };
 
 struct KParams {
@@ -595,6 +595,14 @@ __device__ __forceinline__ long long patch_orow(int row) {
     return (long long)(row & ~255) + y * 16 + x;
 }
 
+// A_PATCHT: the same row order on the half-resolution grid of ONE output phase (py, px) of a stride-2 transposed
+// convolution; the output pixel is (2y + py, 2x + px) of a 32x32 frame.
+__device__ __forceinline__ long long patcht_orow(int row, int cls) {
+    const int f = row & 255, t32 = f >> 5, q = (f >> 2) & 7, e = f & 3;
+    const int y = 2 * t32 + (__popc(q) & 1), x = 4 * (q >> 1) + e;
+    return (long long)(row >> 8) * 1024 + (2 * y + (cls >> 1)) * 32 + 2 * x + (cls & 1);
+}
+
 // ------------------------------------------------------------------------------------------------
 // epilogue shared by the kernels: alpha / bias / residual / ReLU / tanh / mask / accumulate, or split-K partials
 // ------------------------------------------------------------------------------------------------
@@ -620,6 +628,7 @@ __device__ __forceinline__ void lvt_epilogue(const KParams &p, f32x16 (&acc)[BM 
             if (row >= p.M) continue;
             long long orow = row;
             if (AMODE == A_PATCH) orow = patch_orow(row);
+            if (AMODE == A_PATCHT) orow = patcht_orow(row, cls);
             if (AMODE == A_CONVT_K) {
                 const lvt_conv_geom &g = p.g;
                 int m = row;
@@ -728,6 +737,7 @@ __device__ __forceinline__ void lvt_epilogue_vec(const KParams &p, f32x16 (&acc)
                 float4 v = *reinterpret_cast<const float4 *>(&tile[rowl * SW + 4 * c4]);
                 long long orow = row;
                 if (AMODE == A_PATCH) orow = patch_orow(row);
+                if (AMODE == A_PATCHT) orow = patcht_orow(row, cls);
                 if (AMODE == A_CONVT_K) {
                     const lvt_conv_geom &g = p.g;
                     int m = row;
@@ -945,8 +955,15 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
 #define PT_PIX (PT_PW * PT_PW)
 #define PT_PLANE (PT_PIX * HLD)                 // bf16 per patch plane
 #define PT_THREADS 512
+// MODE 0: 3x3 / pad 1 convolution, nine taps at patch offsets (dy, dx) in 0..2.
+// MODE 1: ONE output phase (py, px) of the 4x4 / stride 2 / pad 1 TRANSPOSED convolution of a 16x16 frame (ConvTranspose
+//         forward = backward-data of the strided convolution): four taps at patch offsets (py + a, px + b), a, b in 0..1,
+//         over the same 18x18 patch; weights packed [phase][tap][Cin][Cout] (lvt_conv3d_pack_weight_phases), rows written
+//         to pixels (2y + py, 2x + px) of the 32x32 output frame.  The implicit GEMM re-stages the input per tap AND phase.
+template <int MODE>
 __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParams p) {
     constexpr int BM = 256, BN = 128, WM = 4, WN = 2, TM = 2, TN = 2;
+    constexpr int NTAPS = MODE == 0 ? 9 : 4;
     constexpr int PSB = HPlane<BN>::SIZE;
     constexpr int A_BYTES = 3 * PT_PLANE * 2, B_BYTES = 3 * PSB * 2;
     constexpr int STAGE_FLOATS = (A_BYTES + 2 * B_BYTES) / 4 + 8;
@@ -967,7 +984,8 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
         const int xcd = wg & 7, slot = wg >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    const int n0 = (wg % ntn) * BN, frame = wg / ntn, m0 = frame * BM;
+    const int n0 = (wg % ntn) * BN;
+    const int frame = MODE == 0 ? wg / ntn : (wg / ntn) >> 2, phase = MODE == 0 ? 0 : (wg / ntn) & 3, m0 = frame * BM;
     const float *xf = p.A + (long long)frame * 256 * Ci;
 
     // ---- patch staging: unit u = pixel * 8 + channel quad; 2592 units over 512 threads -> 6 passes
@@ -1005,8 +1023,8 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
     const float *bcol = p.B + n0 + bnq * 4;
     float4 bv[4];
     auto b_fetch = [&](int step) {
-        const int cc = step / 9, tap = step - cc * 9;
-        const float *src = bcol + (long long)(tap * Ci + cc * 32 + bkk0 * 4) * p.ldb;
+        const int cc = step / NTAPS, tap = step - cc * NTAPS;
+        const float *src = bcol + (long long)((phase * NTAPS + tap) * Ci + cc * 32 + bkk0 * 4) * p.ldb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) bv[i] = ldg4(src + (long long)i * p.ldb);
     };
@@ -1031,7 +1049,7 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
 #pragma unroll
     for (int j = 0; j < TN; ++j) brow[j] = hrow<BN>(wn * (TN * 32) + j * 32 + l31) + 8 * half;
 
-    const int nchunks = Ci / 32, nsteps = nchunks * 9;
+    const int nchunks = Ci / 32, nsteps = nchunks * NTAPS;
     patch_fetch(0);
     if (bact) b_fetch(0);
     patch_store();
@@ -1039,13 +1057,14 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
     __syncthreads();
 
     for (int step = 0; step < nsteps; ++step) {
-        const int cc = step / 9, tap = step - cc * 9;
+        const int cc = step / NTAPS, tap = step - cc * NTAPS;
         const bool has_next = step + 1 < nsteps;
-        const bool new_chunk = has_next && tap == 8;
+        const bool new_chunk = has_next && tap == NTAPS - 1;
         if (has_next && bact) b_fetch(step + 1);
         if (new_chunk) patch_fetch(cc + 1);
         const unsigned short *Bh = Bh0 + (step & 1) * (3 * PSB);
-        const unsigned short *Ap = Ah + ((tap / 3) * PT_PW + (tap % 3)) * HLD;
+        const unsigned short *Ap = MODE == 0 ? Ah + ((tap / 3) * PT_PW + (tap % 3)) * HLD
+                                             : Ah + (((phase >> 1) + (tap >> 1)) * PT_PW + (phase & 1) + (tap & 1)) * HLD;
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 16) {
             bf16x8 a[3][TM], b[3][TN];
@@ -1073,7 +1092,8 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
         }
         __syncthreads();
     }
-    lvt_epilogue_vec<A_PATCH, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, 0, 0, 0, 0);
+    if (MODE == 0) lvt_epilogue_vec<A_PATCH, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, 0, 0, 0, 0);
+    else lvt_epilogue_vec<A_PATCHT, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, phase, 0, 0, 0);
 }
 
 // deterministic split-K reduction: out[i] (+)= sum_s partial[s][i]
@@ -1132,6 +1152,21 @@ __global__ void lvt_pack_weight_t_kernel(const float *__restrict__ w, float *__r
         float v = 0.f;
         if (co < Co_real && ci < Ci_real) v = w[((long long)co * Ci_real + ci) * taps + (taps - 1 - tr)];
         wt[i] = v;
+    }
+}
+// w[co][ci][ky][kx] (4x4) -> wph[phase (py,px)][tap (a,b)][co_pad][ci_pad] with ky = 3 - py - 2a, kx = 3 - px - 2b: the
+// four taps each output phase of the stride-2 transposed convolution uses, in the order the frame-resident kernel walks them
+__global__ void lvt_pack_weight_phases_kernel(const float *__restrict__ w, float *__restrict__ wph, int Ci, int Co,
+                                              int Ci_real, int Co_real) {
+    const long long total = 16LL * Co * Ci;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ci = i % Ci; long long t = i / Ci;
+        const int co = t % Co; const int pt = t / Co;         // pt = phase * 4 + tap
+        const int ph = pt >> 2, tap = pt & 3;
+        const int ky = 3 - (ph >> 1) - 2 * (tap >> 1), kx = 3 - (ph & 1) - 2 * (tap & 1);
+        float v = 0.f;
+        if (co < Co_real && ci < Ci_real) v = w[(((long long)co * Ci_real + ci) * 4 + ky) * 4 + kx];
+        wph[i] = v;
     }
 }
 // partial[split][(tap,ci)][co] -> dw[co][ci][tap]   (fixed summation order over splits).
@@ -1407,7 +1442,7 @@ extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const floa
         if (flags & LVT_EPI_MASK) ok = ok && al16(mask);
         if (ok) {
             p.vec_epi = 1;
-            hipLaunchKernelGGL(lvt_conv_patch_kernel, dim3((unsigned)(g->N * (g->Co / 128))), dim3(PT_THREADS), 0,
+            hipLaunchKernelGGL(lvt_conv_patch_kernel<0>, dim3((unsigned)(g->N * (g->Co / 128))), dim3(PT_THREADS), 0,
                                (hipStream_t)stream, p);
             LVT_CHECK_LAUNCH("lvt_conv_patch_kernel");
             return LVT_OK;
@@ -1415,6 +1450,49 @@ extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const floa
     }
     if (g->Co <= 32) return launch_tile<A_CONV_K, B_NPLAIN, 128, 32, 4, 1>(p, 1, (hipStream_t)stream);
     return launch_tile<A_CONV_K, B_NPLAIN, 128, 128, 2, 2>(p, 1, (hipStream_t)stream);
+}
+
+// ---- stride-2 transposed convolution of 16x16 frames on the frame-resident kernel -------------------------------------
+static bool convt2x_eligible(const lvt_conv_geom *g, int flags) {
+    static const int off = (getenv("LVT_NO_PATCH_CONV") || getenv("LVT_NO_PHASE_CONV")) ? 1 : 0;
+    // g is the geometry of the FORWARD strided convolution (Ci -> Co, 32x32 -> 16x16); the transposed pass maps Co -> Ci
+    return !off && math_of(flags) == 1 && BK == 32 && g->Kt == 1 && g->Kh == 4 && g->Kw == 4 && g->st == 1 && g->sh == 2 &&
+           g->sw == 2 && g->pt == 0 && g->ph == 1 && g->pw == 1 && g->Ti == 1 && g->Hi == 32 && g->Wi == 32 && g->To == 1 &&
+           g->Ho == 16 && g->Wo == 16 && g->Co % 32 == 0 && g->Ci % 128 == 0;
+}
+extern "C" int lvt_conv3d_bwd_data_uses_phase_kernel(const lvt_conv_geom *g, int flags) { return g && convt2x_eligible(g, flags) ? 1 : 0; }
+extern "C" int lvt_conv3d_pack_weight_phases(const lvt_conv_geom *g, const float *w, int Ci_real, int Co_real,
+                                             float *wph, void *stream) {
+    int rc = check_geom(g, "pack_weight_phases"); if (rc) return rc;
+    LVT_REQUIRE(w && wph && Ci_real <= g->Ci && Co_real <= g->Co && g->Kt == 1 && g->Kh == 4 && g->Kw == 4,
+                "pack_weight_phases: 4x4 kernels only");
+    const long long total = 16LL * g->Ci * g->Co;
+    hipLaunchKernelGGL(lvt_pack_weight_phases_kernel, dim3((unsigned)(lvt_cdiv(total, 256) < 4096 ? lvt_cdiv(total, 256) : 4096)),
+                       dim3(256), 0, (hipStream_t)stream, w, wph, g->Ci, g->Co, Ci_real, Co_real);
+    LVT_CHECK_LAUNCH("lvt_pack_weight_phases_kernel");
+    return LVT_OK;
+}
+extern "C" int lvt_conv3d_bwd_data_phases(const lvt_conv_geom *g, const float *dy, const float *wph, const float *bias,
+                                          const float *res, const float *mask, float *dx, int flags, void *stream) {
+    int rc = check_geom(g, "conv3d_bwd_data_phases"); if (rc) return rc;
+    LVT_REQUIRE(dy && wph && dx, "conv3d_bwd_data_phases: null pointer");
+    LVT_REQUIRE(convt2x_eligible(g, flags), "conv3d_bwd_data_phases: geometry not served (see lvt_conv3d_bwd_data_uses_phase_kernel)");
+    LVT_REQUIRE(!(flags & LVT_EPI_BIAS) || bias, "conv3d_bwd_data_phases: BIAS without bias");
+    LVT_REQUIRE(!(flags & LVT_EPI_RESIDUAL) || res, "conv3d_bwd_data_phases: RESIDUAL without res");
+    LVT_REQUIRE(!(flags & LVT_EPI_MASK) || mask, "conv3d_bwd_data_phases: MASK without mask");
+    LVT_REQUIRE(!(flags & LVT_EPI_ACCUM), "conv3d_bwd_data_phases: unsupported flag");
+    LVT_REQUIRE(lvt_aligned16(dy) && lvt_aligned16(wph) && lvt_aligned16(dx) && lvt_aligned16(bias) && lvt_aligned16(res) &&
+                lvt_aligned16(mask), "conv3d_bwd_data_phases: alignment");
+    KParams p; memset(&p, 0, sizeof(p));
+    p.M = g->N * 256; p.N = g->Ci; p.K = 4 * g->Co;            // per phase
+    p.A = dy; p.B = wph; p.ldb = g->Ci; p.C = dx; p.ldc = g->Ci; p.batch_inner = 1;
+    p.alpha = 1.f; p.flags = flags; p.bias = bias; p.res = res; p.ldr = g->Ci; p.mask = mask; p.ldm = g->Ci;
+    p.splits = 1; p.vec_epi = 1;
+    p.g = *g; p.g.Ci = g->Co;                                   // the kernel's input channel count
+    hipLaunchKernelGGL(lvt_conv_patch_kernel<1>, dim3((unsigned)(g->N * 4 * (g->Ci / 128))), dim3(PT_THREADS), 0,
+                       (hipStream_t)stream, p);
+    LVT_CHECK_LAUNCH("lvt_conv_patch_kernel<1>");
+    return LVT_OK;
 }
 
 extern "C" int lvt_conv3d_bwd_data(const lvt_conv_geom *g, const float *dy, const float *wp, const float *bias,

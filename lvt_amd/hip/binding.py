@@ -71,6 +71,9 @@ def _declare(lib):
         "lvt_conv3d_pack_weight_t": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
         "lvt_conv3d_uses_patch_kernel": (ci, [P(ConvGeom), ci]),
         "lvt_conv3d_fwd": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
+        "lvt_conv3d_bwd_data_uses_phase_kernel": (ci, [P(ConvGeom), ci]),
+        "lvt_conv3d_pack_weight_phases": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
+        "lvt_conv3d_bwd_data_phases": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
         "lvt_conv3d_bwd_data": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
         "lvt_conv3d_bwd_weight_workspace_bytes": (sz, [P(ConvGeom)]),
         "lvt_conv3d_bwd_weight_fuses_bias": (ci, [P(ConvGeom), ci]),

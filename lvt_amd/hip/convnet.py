@@ -63,10 +63,15 @@ def stack_forward(layers, x, params, want_grad=True):
     cur = x
     for i, (ly, (w, b)) in enumerate(zip(layers, params)):
         g = _geom(ly, cur.shape)
+        wph = None
         if ly.kind == "conv":
             wp = G.pack_weight(g, w, ly.cin, ly.cout)
+            if want_grad and i > 0 and G.bwd_data_by_phases(g):
+                wph = G.pack_weight_phases(g, w, ly.cin, ly.cout)          # for this layer's backward-data
         else:
             wp = G.pack_weight(g, w, ly.cout, ly.cin)   # ConvTranspose weight is (in, out, k..) == conv (Co, Ci)
+            if G.bwd_data_by_phases(g):
+                wph = G.pack_weight_phases(g, w, ly.cout, ly.cin)          # this layer's FORWARD is a transposed pass
         res = outs[ly.res_from] if ly.res_from >= 0 else None
         bias = _padded_bias(ly, b)
         if ly.kind == "conv":
@@ -75,12 +80,12 @@ def stack_forward(layers, x, params, want_grad=True):
               and ly.cin % 16 == 0 and res is None and ly.act in ("", "tanh")):
             y = G.convT4_fwd(cur, w, b, ly.act == "tanh")          # image-side layer: dedicated kernel
         else:
-            y = G.conv_bwd_data(g, cur, wp, bias=bias, res=res, flags=_act_flag(ly.act))
+            y = G.conv_bwd_data(g, cur, wp, bias=bias, res=res, flags=_act_flag(ly.act), wph=wph)
         outs.append(y)
         geoms.append(g)
         # backward-data of the 3x3 layers runs as a forward convolution over transposed weights (frame-resident kernel)
         wt = G.pack_weight_t(g, w, ly.cin, ly.cout) if (want_grad and ly.kind == "conv" and G.bwd_data_as_conv(g)) else None
-        packed.append((wp, wt))
+        packed.append((wp, wt, wph))
         cur = y
     return outs, (geoms, packed)
 
@@ -103,7 +108,7 @@ def stack_backward(layers, x, outs, saved, grad_out, need_input_grad=False):
     gpres[n - 1] = gpre
     grads = [None] * n
     for i in range(n - 1, -1, -1):
-        ly, g, (wp, wt) = layers[i], geoms[i], packed[i]
+        ly, g, (wp, wt, wph) = layers[i], geoms[i], packed[i]
         inp = outs[i - 1] if i > 0 else x
         gp = gpres[i]
         # parameter gradients
@@ -125,7 +130,7 @@ def stack_backward(layers, x, outs, saved, grad_out, need_input_grad=False):
         if prev is not None and prev.act == "tanh":
             raise L.LvtError("tanh is only supported on the last layer of a stack")
         if ly.kind == "conv":
-            gin = G.conv_bwd_data(g, gp, wp, res=res, mask=mask, wt=wt)
+            gin = G.conv_bwd_data(g, gp, wp, res=res, mask=mask, wt=wt, wph=wph)
         else:
             gin = G.conv_fwd(g, gp, wp, res=res, mask=mask)
         if i > 0:

@@ -172,11 +172,38 @@ def conv_fwd(g, x, wp, bias=None, res=None, mask=None, flags=0, timer_key="conv_
     return y
 
 
-def conv_bwd_data(g, dy, wp, bias=None, res=None, mask=None, flags=0, wt=None):
+def pack_weight_phases(g, w, Ci_real, Co_real):
+    """(4 phases, 4 taps, Co, Ci) weights of the stride-2 transposed pass of the 4x4 convolution `g`."""
+    L.require(w)
+    wph = torch.empty(4, 4, g.Co, g.Ci, dtype=torch.float32, device=w.device)
+    L.check(L.lib().lvt_conv3d_pack_weight_phases(C.byref(g), L.ptr(w), Ci_real, Co_real, L.ptr(wph), L.stream_ptr()),
+            "lvt_conv3d_pack_weight_phases")
+    return wph
+
+
+def bwd_data_by_phases(g):
+    """True when dx of `g` (4x4 / stride 2 between 32x32 and 16x16 frames) is served by the frame-resident kernel."""
+    return bool(L.lib().lvt_conv3d_bwd_data_uses_phase_kernel(C.byref(g), L.math_flag()))
+
+
+def conv_bwd_data(g, dy, wp, bias=None, res=None, mask=None, flags=0, wt=None, wph=None):
     """dx of the convolution `g`.  With `wt` (pack_weight_t) the pass runs as a forward convolution on the swapped
-    geometry -- the frame-resident kernel for the 3x3 layers."""
+    geometry -- the frame-resident kernel for the 3x3 layers; with `wph` (pack_weight_phases) phase by phase on the same
+    kernel (4x4 / stride 2 layers)."""
     if wt is not None:
         return conv_fwd(swapped_geom(g), dy, wt, bias=bias, res=res, mask=mask, flags=flags, timer_key="conv_bwd_data")
+    if wph is not None:
+        L.require(dy, wph, bias, res, mask)
+        dx = torch.empty(g.N, g.Ti, g.Hi, g.Wi, g.Ci, dtype=torch.float32, device=dy.device)
+        flags |= (L.EPI_BIAS if bias is not None else 0) | (L.EPI_RESIDUAL if res is not None else 0) | \
+            (L.EPI_MASK if mask is not None else 0)
+        t0 = L.TIMER.begin() if L.TIMER is not None else None
+        L.check(L.lib().lvt_conv3d_bwd_data_phases(C.byref(g), L.ptr(dy), L.ptr(wph), L.ptr(bias), L.ptr(res), L.ptr(mask),
+                                                   L.ptr(dx), flags | L.math_flag(), L.stream_ptr()),
+                "lvt_conv3d_bwd_data_phases")
+        if t0 is not None:
+            L.TIMER.end("conv_bwd_data", conv_flops(g), t0)
+        return dx
     L.require(dy, wp, bias, res, mask)
     dx = torch.empty(g.N, g.Ti, g.Hi, g.Wi, g.Ci, dtype=torch.float32, device=dy.device)
     if bias is not None:

@@ -27,7 +27,9 @@ for name, Ci, Co, k, s, p, H in [("K2 4x4s2 128->256", 128, 256, 4, 2, 1, 32), (
     dy = torch.randn_like(y)
     fl = G.conv_flops(g)
     t1 = timeit(lambda: G.conv_fwd(g, x, wp))
-    t2 = timeit(lambda: G.conv_bwd_data(g, dy, wp))
+    wph = G.pack_weight_phases(g, w, Ci, Co) if G.bwd_data_by_phases(g) else None
+    wt = G.pack_weight_t(g, w, Ci, Co) if G.bwd_data_as_conv(g) else None
+    t2 = timeit(lambda: G.conv_bwd_data(g, dy, wp, wt=wt, wph=wph))
     t3 = timeit(lambda: G.conv_bwd_weight(g, x, dy, Ci, Co))
     print("%-20s fwd %7.1f us %6.1f TF | bwd_data %7.1f us %6.1f TF | bwd_w %7.1f us %6.1f TF" %
           (name, t1 * 1e3, fl / t1 / 1e9, t2 * 1e3, fl / t2 / 1e9, t3 * 1e3, fl / t3 / 1e9))

@@ -246,6 +246,28 @@ def test_frame_resident_weight_gradient(Ci, Co, N, math_mode):
     assert rel_err(dw.squeeze(2), w.grad) < 5e-5
 
 
+@pytest.mark.parametrize("Cin,Cout,N", [(256, 128, 3), (32, 128, 1), (64, 256, 5)])
+def test_transposed_conv_by_phases(Cin, Cout, N, math_mode):
+    """ConvTranspose2d(Cin -> Cout, k4 s2 p1) of 16x16 frames == backward-data of the strided convolution, run phase by
+    phase on the frame-resident kernel (default math mode) with bias + residual + ReLU mask, against torch on the CPU and
+    against the implicit-GEMM route."""
+    from lvt_amd.hip import gemm as G, binding as L
+    H = 16
+    x, w, b = _rand(N, Cin, H, H), _rand(Cin, Cout, 4, 4, seed=1) * 0.1, _rand(Cout, seed=2)
+    res, msrc = _rand(N, Cout, 2 * H, 2 * H, seed=4), _rand(N, Cout, 2 * H, 2 * H, seed=5)
+    ref = (F.conv_transpose2d(x, w, b, stride=2, padding=1) + res) * (msrc > 0)
+    dev = _dev()
+    g = G.conv_geom(N, 1, 2 * H, 2 * H, Cout, Cin, (1, 4, 4), (1, 2, 2), (0, 1, 1))
+    assert G.bwd_data_by_phases(g) == (math_mode == "bf16x3")
+    args = dict(bias=b.to(dev), res=_nhwc(res).to(dev), mask=_nhwc(msrc).to(dev))
+    y2 = G.conv_bwd_data(g, _nhwc(x).to(dev), G.pack_weight(g, w.to(dev), Cout, Cin), **args)
+    assert rel_err(_nchw(y2), ref) < TOL
+    if math_mode == "bf16x3":
+        y1 = G.conv_bwd_data(g, _nhwc(x).to(dev), None, wph=G.pack_weight_phases(g, w.to(dev), Cout, Cin), **args)
+        assert rel_err(_nchw(y1), ref) < TOL
+        assert rel_err(y1, y2) < TOL
+
+
 def test_conv3d_causal_geometry():
     """MaskedConv3d geometry (K16): kernel 3x3x3, front pads (2,2,1), T=2 to exercise the t taps."""
     from lvt_amd.hip import gemm as G
