@@ -131,6 +131,14 @@ int lvt_conv3d_pack_weight(const lvt_conv_geom *g, const float *w, int Ci_real, 
 int lvt_conv3d_pack_weight_t(const lvt_conv_geom *g, const float *w, int Ci_real, int Co_real,
                              float *wt, void *stream);
 int lvt_conv3d_uses_patch_kernel(const lvt_conv_geom *g, int flags);
+/* The 4x4 / stride 2 / pad 1 convolution 32x32 -> 16x16 (Ci % 32 == 0, Co % 128 == 0) on the frame-resident kernel: the 16
+ * taps are 4 parity classes x 4 taps, each class a 2x2 / stride 1 convolution on a 17x17 sub-image that is staged once per
+ * 32-channel chunk.  Weights: lvt_conv3d_pack_weight_parity, wq[(py,px)][(a,b)][ci][co] = w[co][ci][2a+py][2b+px].        */
+int lvt_conv3d_fwd_uses_parity_kernel(const lvt_conv_geom *g, int flags);
+int lvt_conv3d_pack_weight_parity(const lvt_conv_geom *g, const float *w, int Ci_real, int Co_real,
+                                  float *wq, void *stream);
+int lvt_conv3d_fwd_parity(const lvt_conv_geom *g, const float *x, const float *wq, const float *bias,
+                          const float *res, const float *mask, float *y, int flags, void *stream);
 /* y = epi( conv(x, wp) ); bias[Co]; res / y are (N,To,Ho,Wo,Co).  flags: BIAS|RESIDUAL|RELU|TANH|MASK */
 int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias,
                    const float *res, const float *mask, float *y, int flags, void *stream);

@@ -960,6 +960,11 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
 //         forward = backward-data of the strided convolution): four taps at patch offsets (py + a, px + b), a, b in 0..1,
 //         over the same 18x18 patch; weights packed [phase][tap][Cin][Cout] (lvt_conv3d_pack_weight_phases), rows written
 //         to pixels (2y + py, 2x + px) of the 32x32 output frame.  The implicit GEMM re-stages the input per tap AND phase.
+// MODE 2: the 4x4 / stride 2 / pad 1 convolution of a 32x32 frame (-> 16x16): the sixteen taps are four PARITY classes
+//         (ky & 1, kx & 1) x four taps (ky >> 1, kx >> 1); the input pixels of one class, in[2r + py - 1][2c + px - 1], form
+//         a 17x17 sub-image on which the class is a 2x2 / stride 1 convolution.  The "patch" is that sub-image, re-staged per
+//         (chunk, class): one staging per four tap steps.  Weights packed [class][tap][Cin][Cout]
+//         (lvt_conv3d_pack_weight_parity).
 template <int MODE>
 __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParams p) {
     constexpr int BM = 256, BN = 128, WM = 4, WN = 2, TM = 2, TN = 2;
@@ -985,21 +990,28 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
     const int n0 = (wg % ntn) * BN;
-    const int frame = MODE == 0 ? wg / ntn : (wg / ntn) >> 2, phase = MODE == 0 ? 0 : (wg / ntn) & 3, m0 = frame * BM;
-    const float *xf = p.A + (long long)frame * 256 * Ci;
+    const int frame = MODE == 1 ? (wg / ntn) >> 2 : wg / ntn, phase = MODE == 1 ? (wg / ntn) & 3 : 0, m0 = frame * BM;
+    const float *xf = p.A + (long long)frame * (MODE == 2 ? 1024 : 256) * Ci;
 
     // ---- patch staging: unit u = pixel * 8 + channel quad; 2592 units over 512 threads -> 6 passes
     constexpr int PUNITS = PT_PIX * 8, PPASS = (PUNITS + PT_THREADS - 1) / PT_THREADS;
     float4 pv[PPASS];
-    auto patch_fetch = [&](int cc) {
+    // `chunk`: the 32-channel chunk (MODE 0 / 1), or chunk * 4 + parity class (MODE 2)
+    auto patch_fetch = [&](int chunk) {
 #pragma unroll
         for (int j = 0; j < PPASS; ++j) {
             const int u = tid + PT_THREADS * j;
             const int pp = u >> 3, q = u & 7;
             const int py = pp / PT_PW, px = pp - py * PT_PW;
-            const bool ok = u < PUNITS && (unsigned)(py - 1) < 16u && (unsigned)(px - 1) < 16u;
-            const float *src = xf + ((py - 1) * 16 + (px - 1)) * Ci + cc * 32 + q * 4;
-            pv[j] = ok ? ldg4(src) : zero4();
+            if (MODE == 2) {
+                const int iy = 2 * py + ((chunk >> 1) & 1) - 1, ix = 2 * px + (chunk & 1) - 1;      // sub-image pixel -> input pixel
+                const bool ok = u < PUNITS && (unsigned)iy < 32u && (unsigned)ix < 32u && py < 17 && px < 17;
+                pv[j] = ok ? ldg4(xf + (iy * 32 + ix) * Ci + (chunk >> 2) * 32 + q * 4) : zero4();
+            } else {
+                const bool ok = u < PUNITS && (unsigned)(py - 1) < 16u && (unsigned)(px - 1) < 16u;
+                const float *src = xf + ((py - 1) * 16 + (px - 1)) * Ci + chunk * 32 + q * 4;
+                pv[j] = ok ? ldg4(src) : zero4();
+            }
         }
     };
     auto patch_store = [&]() {
@@ -1024,7 +1036,9 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
     float4 bv[4];
     auto b_fetch = [&](int step) {
         const int cc = step / NTAPS, tap = step - cc * NTAPS;
-        const float *src = bcol + (long long)((phase * NTAPS + tap) * Ci + cc * 32 + bkk0 * 4) * p.ldb;
+        // MODE 2: cc = chunk * 4 + class -> weight rows ((class * 4 + tap) * Ci + chunk * 32 ...)
+        const int wrow = MODE == 2 ? ((cc & 3) * NTAPS + tap) * Ci + (cc >> 2) * 32 : (phase * NTAPS + tap) * Ci + cc * 32;
+        const float *src = bcol + (long long)(wrow + bkk0 * 4) * p.ldb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) bv[i] = ldg4(src + (long long)i * p.ldb);
     };
@@ -1049,7 +1063,7 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
 #pragma unroll
     for (int j = 0; j < TN; ++j) brow[j] = hrow<BN>(wn * (TN * 32) + j * 32 + l31) + 8 * half;
 
-    const int nchunks = Ci / 32, nsteps = nchunks * NTAPS;
+    const int nchunks = (Ci / 32) * (MODE == 2 ? 4 : 1), nsteps = nchunks * NTAPS;
     patch_fetch(0);
     if (bact) b_fetch(0);
     patch_store();
@@ -1064,7 +1078,7 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
         if (new_chunk) patch_fetch(cc + 1);
         const unsigned short *Bh = Bh0 + (step & 1) * (3 * PSB);
         const unsigned short *Ap = MODE == 0 ? Ah + ((tap / 3) * PT_PW + (tap % 3)) * HLD
-                                             : Ah + (((phase >> 1) + (tap >> 1)) * PT_PW + (phase & 1) + (tap & 1)) * HLD;
+                                             : Ah + (((phase >> 1) + (tap >> 1)) * PT_PW + (phase & 1) + (tap & 1)) * HLD;   // (phase 0 in MODE 2)
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 16) {
             bf16x8 a[3][TM], b[3][TN];
@@ -1092,7 +1106,7 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
         }
         __syncthreads();
     }
-    if (MODE == 0) lvt_epilogue_vec<A_PATCH, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, 0, 0, 0, 0);
+    if (MODE != 1) lvt_epilogue_vec<A_PATCH, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, 0, 0, 0, 0);
     else lvt_epilogue_vec<A_PATCHT, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, phase, 0, 0, 0);
 }
 
@@ -1167,6 +1181,20 @@ __global__ void lvt_pack_weight_phases_kernel(const float *__restrict__ w, float
         float v = 0.f;
         if (co < Co_real && ci < Ci_real) v = w[(((long long)co * Ci_real + ci) * 4 + ky) * 4 + kx];
         wph[i] = v;
+    }
+}
+// w[co][ci][ky][kx] (4x4) -> wq[class (py,px)][tap (a,b)][ci_pad][co_pad] with ky = 2a + py, kx = 2b + px (MODE 2 above)
+__global__ void lvt_pack_weight_parity_kernel(const float *__restrict__ w, float *__restrict__ wq, int Ci, int Co,
+                                              int Ci_real, int Co_real) {
+    const long long total = 16LL * Ci * Co;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int co = i % Co; long long t = i / Co;
+        const int ci = t % Ci; const int ct = t / Ci;         // ct = class * 4 + tap
+        const int cls = ct >> 2, tap = ct & 3;
+        const int ky = 2 * (tap >> 1) + (cls >> 1), kx = 2 * (tap & 1) + (cls & 1);
+        float v = 0.f;
+        if (co < Co_real && ci < Ci_real) v = w[(((long long)co * Ci_real + ci) * 4 + ky) * 4 + kx];
+        wq[i] = v;
     }
 }
 // partial[split][(tap,ci)][co] -> dw[co][ci][tap]   (fixed summation order over splits).
@@ -1418,6 +1446,47 @@ static bool patch_conv_eligible(const lvt_conv_geom *g, int flags) {
            g->Ho == 16 && g->Wo == 16 && g->Ci % 32 == 0 && g->Co % 128 == 0;
 }
 extern "C" int lvt_conv3d_uses_patch_kernel(const lvt_conv_geom *g, int flags) { return g && patch_conv_eligible(g, flags) ? 1 : 0; }
+
+// 4x4 / stride 2 / pad 1 convolution 32x32 -> 16x16 on the frame-resident kernel (parity classes)
+static bool conv2x_eligible(const lvt_conv_geom *g, int flags) {
+    static const int off = (getenv("LVT_NO_PATCH_CONV") || getenv("LVT_NO_PARITY_CONV")) ? 1 : 0;
+    return !off && math_of(flags) == 1 && BK == 32 && g->Kt == 1 && g->Kh == 4 && g->Kw == 4 && g->st == 1 && g->sh == 2 &&
+           g->sw == 2 && g->pt == 0 && g->ph == 1 && g->pw == 1 && g->Ti == 1 && g->Hi == 32 && g->Wi == 32 && g->To == 1 &&
+           g->Ho == 16 && g->Wo == 16 && g->Ci % 32 == 0 && g->Co % 128 == 0;
+}
+extern "C" int lvt_conv3d_fwd_uses_parity_kernel(const lvt_conv_geom *g, int flags) { return g && conv2x_eligible(g, flags) ? 1 : 0; }
+extern "C" int lvt_conv3d_pack_weight_parity(const lvt_conv_geom *g, const float *w, int Ci_real, int Co_real,
+                                             float *wq, void *stream) {
+    int rc = check_geom(g, "pack_weight_parity"); if (rc) return rc;
+    LVT_REQUIRE(w && wq && Ci_real <= g->Ci && Co_real <= g->Co && g->Kt == 1 && g->Kh == 4 && g->Kw == 4,
+                "pack_weight_parity: 4x4 kernels only");
+    const long long total = 16LL * g->Ci * g->Co;
+    hipLaunchKernelGGL(lvt_pack_weight_parity_kernel, dim3((unsigned)(lvt_cdiv(total, 256) < 4096 ? lvt_cdiv(total, 256) : 4096)),
+                       dim3(256), 0, (hipStream_t)stream, w, wq, g->Ci, g->Co, Ci_real, Co_real);
+    LVT_CHECK_LAUNCH("lvt_pack_weight_parity_kernel");
+    return LVT_OK;
+}
+extern "C" int lvt_conv3d_fwd_parity(const lvt_conv_geom *g, const float *x, const float *wq, const float *bias,
+                                     const float *res, const float *mask, float *y, int flags, void *stream) {
+    int rc = check_geom(g, "conv3d_fwd_parity"); if (rc) return rc;
+    LVT_REQUIRE(x && wq && y, "conv3d_fwd_parity: null pointer");
+    LVT_REQUIRE(conv2x_eligible(g, flags), "conv3d_fwd_parity: geometry not served (see lvt_conv3d_fwd_uses_parity_kernel)");
+    LVT_REQUIRE(!(flags & LVT_EPI_BIAS) || bias, "conv3d_fwd_parity: BIAS without bias");
+    LVT_REQUIRE(!(flags & LVT_EPI_RESIDUAL) || res, "conv3d_fwd_parity: RESIDUAL without res");
+    LVT_REQUIRE(!(flags & LVT_EPI_MASK) || mask, "conv3d_fwd_parity: MASK without mask");
+    LVT_REQUIRE(!(flags & LVT_EPI_ACCUM), "conv3d_fwd_parity: unsupported flag");
+    LVT_REQUIRE(lvt_aligned16(x) && lvt_aligned16(wq) && lvt_aligned16(y) && lvt_aligned16(bias) && lvt_aligned16(res) &&
+                lvt_aligned16(mask), "conv3d_fwd_parity: alignment");
+    KParams p; memset(&p, 0, sizeof(p));
+    p.M = g->N * 256; p.N = g->Co; p.K = 16 * g->Ci;
+    p.A = x; p.B = wq; p.ldb = g->Co; p.C = y; p.ldc = g->Co; p.batch_inner = 1;
+    p.alpha = 1.f; p.flags = flags; p.bias = bias; p.res = res; p.ldr = g->Co; p.mask = mask; p.ldm = g->Co;
+    p.splits = 1; p.vec_epi = 1; p.g = *g;
+    hipLaunchKernelGGL(lvt_conv_patch_kernel<2>, dim3((unsigned)(g->N * (g->Co / 128))), dim3(PT_THREADS), 0,
+                       (hipStream_t)stream, p);
+    LVT_CHECK_LAUNCH("lvt_conv_patch_kernel<2>");
+    return LVT_OK;
+}
 
 extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias,
                               const float *res, const float *mask, float *y, int flags, void *stream) {

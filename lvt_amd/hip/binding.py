@@ -70,6 +70,9 @@ def _declare(lib):
         "lvt_conv3d_pack_weight": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
         "lvt_conv3d_pack_weight_t": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
         "lvt_conv3d_uses_patch_kernel": (ci, [P(ConvGeom), ci]),
+        "lvt_conv3d_fwd_uses_parity_kernel": (ci, [P(ConvGeom), ci]),
+        "lvt_conv3d_pack_weight_parity": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
+        "lvt_conv3d_fwd_parity": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
         "lvt_conv3d_fwd": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
         "lvt_conv3d_bwd_data_uses_phase_kernel": (ci, [P(ConvGeom), ci]),
         "lvt_conv3d_pack_weight_phases": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),

@@ -63,19 +63,23 @@ def stack_forward(layers, x, params, want_grad=True):
     cur = x
     for i, (ly, (w, b)) in enumerate(zip(layers, params)):
         g = _geom(ly, cur.shape)
-        wph = None
+        wph = wq = None
         if ly.kind == "conv":
             wp = G.pack_weight(g, w, ly.cin, ly.cout)
             if want_grad and i > 0 and G.bwd_data_by_phases(g):
                 wph = G.pack_weight_phases(g, w, ly.cin, ly.cout)          # for this layer's backward-data
+            if G.fwd_by_parity(g):
+                wq = G.pack_weight_parity(g, w, ly.cin, ly.cout)           # this layer's forward (4x4 / stride 2)
         else:
             wp = G.pack_weight(g, w, ly.cout, ly.cin)   # ConvTranspose weight is (in, out, k..) == conv (Co, Ci)
             if G.bwd_data_by_phases(g):
                 wph = G.pack_weight_phases(g, w, ly.cout, ly.cin)          # this layer's FORWARD is a transposed pass
+            if want_grad and G.fwd_by_parity(g):
+                wq = G.pack_weight_parity(g, w, ly.cout, ly.cin)           # its backward-data is the strided convolution
         res = outs[ly.res_from] if ly.res_from >= 0 else None
         bias = _padded_bias(ly, b)
         if ly.kind == "conv":
-            y = G.conv_fwd(g, cur, wp, bias=bias, res=res, flags=_act_flag(ly.act))
+            y = G.conv_fwd(g, cur, wp, bias=bias, res=res, flags=_act_flag(ly.act), wq=wq)
         elif (ly.cout <= 3 and ly.kernel == (1, 4, 4) and ly.stride == (1, 2, 2) and ly.pad == (0, 1, 1)
               and ly.cin % 16 == 0 and res is None and ly.act in ("", "tanh")):
             y = G.convT4_fwd(cur, w, b, ly.act == "tanh")          # image-side layer: dedicated kernel
@@ -85,7 +89,7 @@ def stack_forward(layers, x, params, want_grad=True):
         geoms.append(g)
         # backward-data of the 3x3 layers runs as a forward convolution over transposed weights (frame-resident kernel)
         wt = G.pack_weight_t(g, w, ly.cin, ly.cout) if (want_grad and ly.kind == "conv" and G.bwd_data_as_conv(g)) else None
-        packed.append((wp, wt, wph))
+        packed.append((wp, wt, wph, wq))
         cur = y
     return outs, (geoms, packed)
 
@@ -108,7 +112,7 @@ def stack_backward(layers, x, outs, saved, grad_out, need_input_grad=False):
     gpres[n - 1] = gpre
     grads = [None] * n
     for i in range(n - 1, -1, -1):
-        ly, g, (wp, wt, wph) = layers[i], geoms[i], packed[i]
+        ly, g, (wp, wt, wph, wq) = layers[i], geoms[i], packed[i]
         inp = outs[i - 1] if i > 0 else x
         gp = gpres[i]
         # parameter gradients
@@ -132,7 +136,7 @@ def stack_backward(layers, x, outs, saved, grad_out, need_input_grad=False):
         if ly.kind == "conv":
             gin = G.conv_bwd_data(g, gp, wp, res=res, mask=mask, wt=wt, wph=wph)
         else:
-            gin = G.conv_fwd(g, gp, wp, res=res, mask=mask)
+            gin = G.conv_fwd(g, gp, wp, res=res, mask=mask, wq=wq)
         if i > 0:
             gpres[i - 1] = gin
         else:

@@ -155,8 +155,22 @@ def bwd_data_as_conv(g):
     return bool(L.lib().lvt_conv3d_uses_patch_kernel(C.byref(swapped_geom(g)), L.math_flag()))
 
 
-def conv_fwd(g, x, wp, bias=None, res=None, mask=None, flags=0, timer_key="conv_fwd"):
-    L.require(x, wp, bias, res, mask)
+def pack_weight_parity(g, w, Ci_real, Co_real):
+    """(4 parity classes, 4 taps, Ci, Co) weights of the 4x4 / stride 2 convolution `g` for the frame-resident kernel."""
+    L.require(w)
+    wq = torch.empty(4, 4, g.Ci, g.Co, dtype=torch.float32, device=w.device)
+    L.check(L.lib().lvt_conv3d_pack_weight_parity(C.byref(g), L.ptr(w), Ci_real, Co_real, L.ptr(wq), L.stream_ptr()),
+            "lvt_conv3d_pack_weight_parity")
+    return wq
+
+
+def fwd_by_parity(g):
+    """True when the forward pass of `g` (4x4 / stride 2, 32x32 -> 16x16 frames) is served by the frame-resident kernel."""
+    return bool(L.lib().lvt_conv3d_fwd_uses_parity_kernel(C.byref(g), L.math_flag()))
+
+
+def conv_fwd(g, x, wp, bias=None, res=None, mask=None, flags=0, timer_key="conv_fwd", wq=None):
+    L.require(x, wp if wq is None else wq, bias, res, mask)
     y = torch.empty(g.N, g.To, g.Ho, g.Wo, g.Co, dtype=torch.float32, device=x.device)
     if bias is not None:
         flags |= L.EPI_BIAS
@@ -165,8 +179,12 @@ def conv_fwd(g, x, wp, bias=None, res=None, mask=None, flags=0, timer_key="conv_
     if mask is not None:
         flags |= L.EPI_MASK
     t0 = L.TIMER.begin() if L.TIMER is not None else None
-    L.check(L.lib().lvt_conv3d_fwd(C.byref(g), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(mask), L.ptr(y),
-                                   flags | L.math_flag(), L.stream_ptr()), "lvt_conv3d_fwd")
+    if wq is not None:
+        L.check(L.lib().lvt_conv3d_fwd_parity(C.byref(g), L.ptr(x), L.ptr(wq), L.ptr(bias), L.ptr(res), L.ptr(mask), L.ptr(y),
+                                              flags | L.math_flag(), L.stream_ptr()), "lvt_conv3d_fwd_parity")
+    else:
+        L.check(L.lib().lvt_conv3d_fwd(C.byref(g), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(mask), L.ptr(y),
+                                       flags | L.math_flag(), L.stream_ptr()), "lvt_conv3d_fwd")
     if t0 is not None:
         L.TIMER.end(timer_key, conv_flops(g), t0)
     return y

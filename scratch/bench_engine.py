@@ -26,7 +26,8 @@ for name, Ci, Co, k, s, p, H in [("K2 4x4s2 128->256", 128, 256, 4, 2, 1, 32), (
     y = G.conv_fwd(g, x, wp)
     dy = torch.randn_like(y)
     fl = G.conv_flops(g)
-    t1 = timeit(lambda: G.conv_fwd(g, x, wp))
+    wq = G.pack_weight_parity(g, w, Ci, Co) if G.fwd_by_parity(g) else None
+    t1 = timeit(lambda: G.conv_fwd(g, x, wp, wq=wq))
     wph = G.pack_weight_phases(g, w, Ci, Co) if G.bwd_data_by_phases(g) else None
     wt = G.pack_weight_t(g, w, Ci, Co) if G.bwd_data_as_conv(g) else None
     t2 = timeit(lambda: G.conv_bwd_data(g, dy, wp, wt=wt, wph=wph))

@@ -268,6 +268,26 @@ def test_transposed_conv_by_phases(Cin, Cout, N, math_mode):
         assert rel_err(y1, y2) < TOL
 
 
+@pytest.mark.parametrize("Ci,Co,N", [(128, 256, 3), (32, 128, 1), (64, 128, 5)])
+def test_strided_conv_by_parity_classes(Ci, Co, N, math_mode):
+    """Conv2d(Ci -> Co, k4 s2 p1) of 32x32 frames on the frame-resident kernel (four parity classes x four taps on 17x17
+    sub-images), with bias + residual + ReLU, against torch on the CPU and the implicit-GEMM route."""
+    from lvt_amd.hip import gemm as G, binding as L
+    x, w, b = _rand(N, Ci, 32, 32), _rand(Co, Ci, 4, 4, seed=1) * 0.1, _rand(Co, seed=2)
+    res = _rand(N, Co, 16, 16, seed=4)
+    ref = torch.relu(F.conv2d(x, w, b, stride=2, padding=1) + res)
+    dev = _dev()
+    g = G.conv_geom(N, 1, 32, 32, Ci, Co, (1, 4, 4), (1, 2, 2), (0, 1, 1))
+    assert G.fwd_by_parity(g) == (math_mode == "bf16x3")
+    args = dict(bias=b.to(dev), res=_nhwc(res).to(dev), flags=L.EPI_RELU)
+    y2 = G.conv_fwd(g, _nhwc(x).to(dev), G.pack_weight(g, w.to(dev), Ci, Co), **args)
+    assert rel_err(_nchw(y2), ref) < TOL
+    if math_mode == "bf16x3":
+        y1 = G.conv_fwd(g, _nhwc(x).to(dev), None, wq=G.pack_weight_parity(g, w.to(dev), Ci, Co), **args)
+        assert rel_err(_nchw(y1), ref) < TOL
+        assert rel_err(y1, y2) < TOL
+
+
 def test_conv3d_causal_geometry():
     """MaskedConv3d geometry (K16): kernel 3x3x3, front pads (2,2,1), T=2 to exercise the t taps."""
     from lvt_amd.hip import gemm as G
