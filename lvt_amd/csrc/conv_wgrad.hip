@@ -33,6 +33,11 @@ struct WgParams {
     int Cp, N, frames_per_split, nchunks;
     float *partial; long long partial_stride;
 };
+// MODE 0: 3x3 / stride 1 / pad 1 on 16x16 frames: nine taps over the 18x18 patch, as described above.
+// MODE 1: 4x4 / stride 2 / pad 1 between a 32x32 frame (patch operand, Cp channels) and a 16x16 frame (slab operand, 256
+//         channels): a workgroup owns ONE parity class (ky & 1, kx & 1) of the sixteen taps -- its four taps (ky >> 1, kx >> 1)
+//         are row / column offsets 0..1 into the 17x17 sub-image in[2r + py - 1][2c + px - 1] of the big frame, which is the
+//         patch here.  blockIdx decodes to (class, chunk, split); partial rows are (tap16 = ky * 4 + kx, c_patch).
 
 __device__ __forceinline__ unsigned wg_cvt_pk(float lo, float hi) {
     unsigned r;
@@ -58,28 +63,38 @@ __device__ __forceinline__ bf16x8 wg_frag(const unsigned short *p, int pitch4) {
     return u.v;
 }
 
+template <int MODE>
 __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const WgParams p) {
+    constexpr int NTAPS = MODE == 0 ? 9 : 4;
     __shared__ __attribute__((aligned(16))) unsigned short lds[3 * WG_PPL + 2 * 3 * WG_QPL];
     unsigned short *patch = lds, *slab0 = lds + 3 * WG_PPL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // workgroup b runs on XCD b % 8 and every XCD has its own L2: the chunks of one split read the same frames (all of
     // the slab operand, the same patch pixels), so the split index is the fast one -- its low bits pick the XCD
-    const int nsplits = gridDim.x / p.nchunks;
-    const int split = blockIdx.x % nsplits, pc = blockIdx.x / nsplits;
+    const int nsplits = gridDim.x / (p.nchunks * (MODE == 1 ? 4 : 1));
+    const int split = blockIdx.x % nsplits;
+    const int pc = MODE == 1 ? (blockIdx.x / nsplits) >> 2 : blockIdx.x / nsplits;       // 32-channel chunk of the patch operand
+    const int cls = MODE == 1 ? (blockIdx.x / nsplits) & 3 : 0;                          // parity class (py, px)
     const int f0 = split * p.frames_per_split, f1 = min(p.N, f0 + p.frames_per_split);
     const int Cp = p.Cp;
 
     constexpr int PUNITS = WG_PIX * 8, PPASS = (PUNITS + WG_THREADS - 1) / WG_THREADS;
     float4 pv[PPASS], qv[2];
     auto patch_fetch = [&](int f) {
-        const float *xf = p.P + (long long)f * 256 * Cp + pc * 32;
+        const float *xf = p.P + (long long)f * (MODE == 1 ? 1024 : 256) * Cp + pc * 32;
 #pragma unroll
         for (int j = 0; j < PPASS; ++j) {
             const int u = tid + WG_THREADS * j;
             const int pp = u >> 3, q = u & 7;
             const int py = pp / WG_PW, px = pp - py * WG_PW;
-            const bool ok = u < PUNITS && (unsigned)(py - 1) < 16u && (unsigned)(px - 1) < 16u;
-            pv[j] = ok ? *reinterpret_cast<const float4 *>(xf + ((py - 1) * 16 + (px - 1)) * Cp + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE == 1) {
+                const int iy = 2 * py + (cls >> 1) - 1, ix = 2 * px + (cls & 1) - 1;
+                const bool ok = u < PUNITS && py < 17 && px < 17 && (unsigned)iy < 32u && (unsigned)ix < 32u;
+                pv[j] = ok ? *reinterpret_cast<const float4 *>(xf + (iy * 32 + ix) * Cp + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const bool ok = u < PUNITS && (unsigned)(py - 1) < 16u && (unsigned)(px - 1) < 16u;
+                pv[j] = ok ? *reinterpret_cast<const float4 *>(xf + ((py - 1) * 16 + (px - 1)) * Cp + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     auto patch_store = [&]() {
@@ -114,9 +129,9 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
         }
     };
 
-    f32x16 acc[9];
+    f32x16 acc[NTAPS];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -143,12 +158,13 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
             bf16x8 b[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) b[q] = wg_frag(slab + boff + q * WG_QPL, 4 * WG_QP);
+            constexpr int TD = MODE == 0 ? 3 : 2;                                         // taps per dimension
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                // three taps at a time: consecutive MFMAs go to three different accumulators
-                bf16x8 a[3][3];
+            for (int dy = 0; dy < TD; ++dy) {
+                // one tap row at a time: consecutive MFMAs go to different accumulators
+                bf16x8 a[TD][3];
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
+                for (int dx = 0; dx < TD; ++dx)
 #pragma unroll
                     for (int q = 0; q < 3; ++q)
                         a[dx][q] = wg_frag(patch + ((y + dy) * WG_PW + dx) * WG_PP + aoff + q * WG_PPL, 4 * WG_PP);
@@ -156,8 +172,8 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
 #pragma unroll
                 for (int t = 0; t < 6; ++t)
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx)
-                        acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dx][TA[t]], b[TB[t]], acc[dy * 3 + dx], 0, 0, 0);
+                    for (int dx = 0; dx < TD; ++dx)
+                        acc[dy * TD + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dx][TA[t]], b[TB[t]], acc[dy * TD + dx], 0, 0, 0);
             }
             if (!last_row || next_frame) slab_store(slab0 + (buf ^ 1) * (3 * WG_QPL));
             if (last_row && next_frame) {
@@ -171,12 +187,15 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
     // partial[split][tap * Cp + pc * 32 + m][32 * wave + n]: lane = column n, 16 rows m per register file
     float *out = p.partial + (long long)split * p.partial_stride + (long long)(pc * 32) * WG_CQ + wave * 32 + (lane & 31);
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTAPS; ++t) {
+        // MODE 1: accumulator (a, b) of class (py, px) is tap (ky, kx) = (2a + py, 2b + px) of the 4x4 kernel
+        const int trow = MODE == 0 ? t : (2 * (t >> 1) + (cls >> 1)) * 4 + 2 * (t & 1) + (cls & 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-            out[((long long)t * Cp + m) * WG_CQ] = acc[t][r];
+            out[((long long)trow * Cp + m) * WG_CQ] = acc[t][r];
         }
+    }
 }
 
 // swapped roles: partial[split][(t', co)][ci] -> dw[co][ci][8 - t'], fixed summation order over the splits
@@ -198,20 +217,24 @@ __global__ void lvt_unpack_wgrad_swapped_kernel(const float *__restrict__ partia
 }
 
 // ---- host side (called from lvt_conv3d_bwd_weight in gemm_engine.hip) -----------------------------------------------
-static int wg_role(const lvt_conv_geom *g, int flags = 0) {       // 0: not served, 1: patch = x / slab = dy, 2: swapped
+// 0: not served; 1: 3x3, patch = x / slab = dy; 2: 3x3 swapped; 3: 4x4 stride 2, patch = x (32x32 frames) / slab = dy (256 ch)
+static int wg_role(const lvt_conv_geom *g, int flags = 0) {
     static const int off = getenv("LVT_NO_FRAME_WGRAD") ? 1 : 0;
+    static const int off2 = getenv("LVT_NO_FRAME_WGRAD_S2") ? 1 : 0;
     if (off || (flags & LVT_MATH_F32)) return 0;
-    const bool shape = g->Kt == 1 && g->Kh == 3 && g->Kw == 3 && g->st == 1 && g->sh == 1 && g->sw == 1 && g->pt == 0 &&
-                       g->ph == 1 && g->pw == 1 && g->Ti == 1 && g->Hi == 16 && g->Wi == 16 && g->To == 1 && g->Ho == 16 &&
-                       g->Wo == 16;
-    if (!shape) return 0;
-    if (g->Co == WG_CQ && g->Ci % 32 == 0) return 1;
-    if (g->Ci == WG_CQ && g->Co % 32 == 0) return 2;
+    if (g->Kt != 1 || g->pt != 0 || g->Ti != 1 || g->To != 1 || g->st != 1 || g->Ho != 16 || g->Wo != 16) return 0;
+    if (g->Kh == 3 && g->Kw == 3 && g->sh == 1 && g->sw == 1 && g->ph == 1 && g->pw == 1 && g->Hi == 16 && g->Wi == 16) {
+        if (g->Co == WG_CQ && g->Ci % 32 == 0) return 1;
+        if (g->Ci == WG_CQ && g->Co % 32 == 0) return 2;
+    }
+    if (!off2 && g->Kh == 4 && g->Kw == 4 && g->sh == 2 && g->sw == 2 && g->ph == 1 && g->pw == 1 && g->Hi == 32 && g->Wi == 32 &&
+        g->Co == WG_CQ && g->Ci % 32 == 0)
+        return 3;
     return 0;
 }
 static int wg_splits(const lvt_conv_geom *g, int role) {
-    const int nchunks = (role == 1 ? g->Ci : g->Co) / 32;
-    int s = 256 / nchunks;                         // one workgroup per CU (118 KB of LDS each): a single full wave
+    const int jobs = role == 3 ? 4 * (g->Ci / 32) : (role == 1 ? g->Ci : g->Co) / 32;
+    int s = 256 / jobs;                            // one workgroup per CU (118 KB of LDS each): a single full wave
     if (s > g->N) s = g->N;
     return s < 1 ? 1 : s;
 }
@@ -219,21 +242,24 @@ int lvt_wgrad_frames_role(const lvt_conv_geom *g, int flags) { return wg_role(g,
 size_t lvt_wgrad_frames_workspace_bytes(const lvt_conv_geom *g) {
     const int role = wg_role(g);
     if (!role) return 0;
-    return (size_t)wg_splits(g, role) * 9 * g->Ci * g->Co * sizeof(float);
+    return (size_t)wg_splits(g, role) * g->Kh * g->Kw * g->Ci * g->Co * sizeof(float);
 }
 int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, int Ci_real, int Co_real,
                             void *workspace, hipStream_t s, void (*unpack_plain)(const float *, long long, int, float *,
                                                                                  const lvt_conv_geom *, int, int, hipStream_t)) {
     const int role = wg_role(g);
     WgParams p;
-    p.P = role == 1 ? x : dy; p.Q = role == 1 ? dy : x;
-    p.Cp = role == 1 ? g->Ci : g->Co; p.N = g->N; p.nchunks = p.Cp / 32;
+    p.P = role == 2 ? dy : x; p.Q = role == 2 ? x : dy;
+    p.Cp = role == 2 ? g->Co : g->Ci; p.N = g->N; p.nchunks = p.Cp / 32;
     const int splits = wg_splits(g, role);
     p.frames_per_split = (g->N + splits - 1) / splits;
-    p.partial = (float *)workspace; p.partial_stride = 9LL * g->Ci * g->Co;
-    hipLaunchKernelGGL(lvt_conv_wgrad_frames_kernel, dim3((unsigned)(p.nchunks * splits)), dim3(WG_THREADS), 0, s, p);
+    p.partial = (float *)workspace; p.partial_stride = (long long)g->Kh * g->Kw * g->Ci * g->Co;
+    if (role == 3)
+        hipLaunchKernelGGL(lvt_conv_wgrad_frames_kernel<1>, dim3((unsigned)(4 * p.nchunks * splits)), dim3(WG_THREADS), 0, s, p);
+    else
+        hipLaunchKernelGGL(lvt_conv_wgrad_frames_kernel<0>, dim3((unsigned)(p.nchunks * splits)), dim3(WG_THREADS), 0, s, p);
     LVT_CHECK_LAUNCH("lvt_conv_wgrad_frames_kernel");
-    if (role == 1) {
+    if (role != 2) {
         unpack_plain(p.partial, p.partial_stride, splits, dw, g, Ci_real, Co_real, s);
     } else {
         const long long total = 9LL * g->Ci * g->Co;

@@ -288,6 +288,25 @@ def test_strided_conv_by_parity_classes(Ci, Co, N, math_mode):
         assert rel_err(y1, y2) < TOL
 
 
+@pytest.mark.parametrize("Ci,N", [(128, 37), (32, 3), (64, 70)])
+def test_frame_resident_weight_gradient_stride2(Ci, N, math_mode):
+    """Weight gradient of the 4x4 / stride 2 / pad 1 layers between 32x32 and 16x16 frames with 256 output channels: one
+    workgroup per parity class of the taps on the frame-resident kernel (default math mode), against torch on the CPU."""
+    from lvt_amd.hip import gemm as G, binding as L
+    import ctypes
+    Co = 256
+    x, w = _rand(N, Ci, 32, 32), _rand(Co, Ci, 4, 4, seed=1) * 0.1
+    x.requires_grad_(True); w.requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=2, padding=1)
+    gy = _rand(*y.shape, seed=3) * (torch.arange(N).view(N, 1, 1, 1) % 3 + 1)
+    y.backward(gy)
+    dev = _dev()
+    g = G.conv_geom(N, 1, 32, 32, Ci, Co, (1, 4, 4), (1, 2, 2), (0, 1, 1))
+    assert L.lib().lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g), L.math_flag()) == (0 if math_mode == "bf16x3" else 1)
+    dw = G.conv_bwd_weight(g, _nhwc(x.detach()).to(dev), _nhwc(gy).to(dev), Ci, Co)
+    assert rel_err(dw.squeeze(2), w.grad) < 5e-5
+
+
 def test_conv3d_causal_geometry():
     """MaskedConv3d geometry (K16): kernel 3x3x3, front pads (2,2,1), T=2 to exercise the t taps."""
     from lvt_amd.hip import gemm as G
