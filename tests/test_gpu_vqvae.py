@@ -175,7 +175,9 @@ def test_g5_supervised_loss_and_grads(golden, tag):
             # 1e-4 .. 3e-4 and up to 1.2e-3 of the largest element of ONE resblock weight gradient, in all three kernel
             # configurations alike; the CPU fp32 oracle showed 9e-4 (l2) on the round-1 clip input.  A systematic error
             # would show in the 2-frame fixture above, which has no such unit.
-            assert e_mine < 5e-3 and l2_mine < 1e-3, (n, e_mine, l2_mine, e_cpu)
+            # Allowance: one such unit (1e-3 in l2) on top of 4x the CPU fp32 oracle's own distance from fp64 on this tensor.
+            l2_cpu = float((g32[n].double() - ref).norm() / ref.norm())
+            assert e_mine < 5e-3 and l2_mine < 1e-3 + 4 * l2_cpu, (n, e_mine, l2_mine, e_cpu, l2_cpu)
     # ---- and against the golden vectors captured from the reference (same indices only) ---------------
     for got, key in ((E["layers.0.weight"], "grad_enc_first"), (E["layers.0.bias"], "grad_enc_first_bias"),
                      (E["layers.6.block.3.weight"], "grad_enc_last"), (G["layers.6.weight"], "grad_dec_last"),
