@@ -284,6 +284,10 @@ int lvt_onehot_tn_gemm(const long long *idx, int nslots, int V, const int *slot_
 int lvt_permute3(const float *in, long long s0, long long s1, long long s2, int n0, int n1, int n2,
                  float *out, void *stream);
 
+/* out[b][i][:] = x[b][perm[i]][:] for (B, S, d) tokens, perm (S) int64 on the device: the block-split regrouping of
+ * BlockLocalAttention (vt_attention.py:189-200) and, with the inverse permutation, its backward.  d % 4 == 0.        */
+int lvt_row_gather(const float *x, const long long *perm, long long B, int S, int d, float *out, void *stream);
+
 /* ---- subscale slice / context builder for a batch of code clips (DatasetMapper.prepare_slices,
  * vidgen/data/dataset_mapper.py:113-149 with vt_utils.py:24-57,104-128; the reference runs it per sample in CPU
  * data-loader workers).  video (B,T,nc,H,W) int64, abc (B,3) int32 slice offsets on the device.  Outputs:

@@ -465,3 +465,27 @@ extern "C" int lvt_slice_context(const long long *video, int B, int T, int nc, i
     LVT_CHECK_LAUNCH("lvt_slice_context_kernel");
     return LVT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Per-sample row gather of a token matrix: out[b][i][:] = x[b][perm[i]][:] for (B, S, d) float32, d % 4 == 0.
+// The block-split branch of BlockLocalAttention (vt_attention.py:189-200: view / permute / contiguous between the
+// raster token order and the block-by-block order) is this gather; its inverse permutation is its own backward.
+// ------------------------------------------------------------------------------------------------
+__global__ void lvt_row_gather_kernel(const float *__restrict__ x, const long long *__restrict__ perm, long long B, int S,
+                                      int d4, float *__restrict__ out) {
+    const long long total = B * S * d4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = i % d4; const long long r = i / d4;
+        const int s = r % S; const long long b = r / S;
+        reinterpret_cast<float4 *>(out)[i] = reinterpret_cast<const float4 *>(x)[(b * S + perm[s]) * d4 + c];
+    }
+}
+extern "C" int lvt_row_gather(const float *x, const long long *perm, long long B, int S, int d, float *out, void *stream) {
+    LVT_REQUIRE(x && perm && out && B > 0 && S > 0 && d > 0 && d % 4 == 0 && lvt_aligned16(x) && lvt_aligned16(out),
+                "row_gather: bad args");
+    const long long total = B * S * (d / 4);
+    const int blocks = (int)(lvt_cdiv(total, 256) < 8192 ? lvt_cdiv(total, 256) : 8192);
+    hipLaunchKernelGGL(lvt_row_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, perm, B, S, d / 4, out);
+    LVT_CHECK_LAUNCH("lvt_row_gather_kernel");
+    return LVT_OK;
+}

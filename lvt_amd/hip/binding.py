@@ -110,6 +110,7 @@ def _declare(lib):
         "lvt_onehot_tn_workspace_bytes": (sz, [ci, ci, ci, cll]),
         "lvt_onehot_tn_gemm": (ci, [vp, ci, ci, P(ci), cll, cll, ci, cll, vp, cll, ci, vp, ci, vp, sz, vp]),
         "lvt_permute3": (ci, [vp, cll, cll, cll, ci, ci, ci, vp, vp]),
+        "lvt_row_gather": (ci, [vp, vp, cll, ci, ci, vp, vp]),
         "lvt_slice_context": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci, cll, vp, vp, vp, vp, vp]),
         "lvt_xent_workspace_bytes": (sz, []),
         "lvt_xent_fwd": (ci, [vp, vp, cll, cll, ci, cll, ci, cll, cf, vp, vp, vp, vp, vp, sz, vp]),

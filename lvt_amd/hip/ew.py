@@ -99,3 +99,13 @@ def layernorm_bwd(dy, x, mean, rstd, w, add=None):
                                       L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws), n, L.stream_ptr()),
             "lvt_layernorm_bwd")
     return dx, dw, db
+
+
+def row_gather(x, perm, S):
+    """x (b*S, d) token matrix -> rows regrouped per sample: out[b*S + i] = x[b*S + perm[i]]."""
+    L.require(x, perm)
+    d = x.shape[-1]
+    out = torch.empty_like(x)
+    L.check(L.lib().lvt_row_gather(L.ptr(x), L.ptr(perm), x.numel() // (S * d), S, d, L.ptr(out), L.stream_ptr()),
+            "lvt_row_gather")
+    return out

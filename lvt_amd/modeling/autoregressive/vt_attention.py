@@ -299,11 +299,9 @@ class _RowPermuteFn(torch.autograd.Function):
     def forward(ctx, x, perm, inv, S):
         ctx.save_for_backward(perm, inv)
         ctx.S = S
-        d = x.shape[-1]
-        return x.view(-1, S, d).index_select(1, perm).view(-1, d)
+        return ew.row_gather(x.contiguous(), perm, S)
 
     @staticmethod
     def backward(ctx, g):
         perm, inv = ctx.saved_tensors
-        d = g.shape[-1]
-        return g.contiguous().view(-1, ctx.S, d).index_select(1, inv).view(-1, d), None, None, None
+        return ew.row_gather(g.contiguous(), inv, ctx.S), None, None, None
