@@ -32,10 +32,16 @@ from torch.optim.optimizer import register_optimizer_step_pre_hook
 
 
 class BucketedGradReducer:
-    def __init__(self, params, bucket_bytes=16 << 20, group=None, broadcast_params=True):
+    def __init__(self, params, bucket_bytes=16 << 20, group=None, broadcast_params=True, reduce_single_rank=False):
+        """reduce_single_rank: run the collectives also in a process group of ONE rank (they are identities there);
+        tests use it to drive the RCCL code path -- AVG reduction, asynchronous work on the side stream, the joins -- on
+        a single-GPU box."""
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self._div = self.world
+        if reduce_single_rank and self.world == 1 and dist.is_available() and dist.is_initialized():
+            self.world = 2          # "active"; the divisor of the SUM path stays the true group size
         if broadcast_params and self.world > 1:
             # like torch DDP at construction: every replica starts from rank 0's weights
             with torch.no_grad():
@@ -143,7 +149,7 @@ class BucketedGradReducer:
         if cs is not None:
             torch.cuda.current_stream(cs.device).wait_stream(cs)
         if not self._avg:
-            b["flat"].div_(self.world)
+            b["flat"].div_(self._div)
         b["work"] = None
         b["pending"] = len(b["params"])
 

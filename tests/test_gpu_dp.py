@@ -187,3 +187,71 @@ def test_kdsfvt_two_ranks_reference_loop_equals_one_big_batch(acc):
         # +-lr/0.22 in either direction, so the weights are compared in the l2 sense, not element by element
         assert float((wa[k] - one[k]).norm() / one[k].norm()) < 2e-3, k
     assert abs(0.5 * (la + lb) - l1) < 2e-3 * abs(l1)
+
+
+def _rccl_single_rank_worker(port, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        from lvt_amd.engine.grad_reducer import BucketedGradReducer
+        from lvt_amd.modeling import build_model
+        from lvt_amd.utils.events import EventStorage
+        cfg = _vt_cfg(2)
+        torch.manual_seed(5)
+        model = build_model(cfg)
+        model.train()
+        optimizers, _ = model.configure_optimizers_and_checkpointers()
+        # what wrap_parallel installs, forced active in the 1-rank RCCL group, with small buckets (many collectives)
+        model._reducers = [BucketedGradReducer(model.model.parameters(), bucket_bytes=4 << 20, reduce_single_rank=True)]
+        red = model._reducers[0]
+        assert red._avg and len(red.buckets) > 10
+        batches = list(_vt_batches(cfg, [0], 2, 4))
+        ref = None
+        for it, batch in enumerate(batches):
+            with EventStorage(it):
+                loss = model(batch, mode="supervised")["loss_cross_entropy"]
+            loss.backward()
+            if it == 0:
+                model.finish_gradient_sync()
+                ref = {n: p.grad.detach().clone() for n, p in model.model.named_parameters() if p.grad is not None}
+            if (it + 1) % 2 == 0:
+                for o in optimizers:
+                    o["optimizer"].step()          # joins through the pre-step hook
+                for o in optimizers:
+                    o["optimizer"].zero_grad()
+        torch.cuda.synchronize()
+        views = sum(int(p.grad is not None and p.grad.data_ptr() == red._slot[p][1].data_ptr()) for p in red.params)
+        # the same first backward without any reducer
+        torch.manual_seed(5)
+        plain = build_model(cfg)
+        plain.train()
+        with EventStorage(0):
+            plain(batches[0], mode="supervised")["loss_cross_entropy"].backward()
+        worst = max(float((ref[n] - p.grad).abs().max() / (p.grad.abs().max() + 1e-30))
+                    for n, p in plain.model.named_parameters() if p.grad is not None and n in ref)
+        ret["out"] = (views, len(red.params), worst, float(loss.detach()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reducer_on_rccl_backend_single_rank():
+    """The RCCL-specific code of the gradient reducer (ReduceOp.AVG, asynchronous all-reduce per bucket on the side stream
+    launched from gradient hooks, joins by the optimizer pre-step hook and at the next forward, in-place zero_grad with the
+    gradients staying bucket views) in a one-rank `nccl` group: a single-GPU box cannot host two RCCL ranks, and with one
+    rank every collective is an identity, so the averaged gradients must equal the plain ones."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_rccl_single_rank_worker, args=(_free_port(), ret))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    views, nparams, worst, loss = ret["out"]
+    assert views > 0.9 * nparams                  # after zero_grad the gradients are views of the buckets again
+    assert worst < 1e-6 and loss == loss
