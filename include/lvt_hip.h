@@ -53,6 +53,10 @@ int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long lon
 #define LVT_EPI_TANH        8   /* tanhf(.)                                                    */
 #define LVT_EPI_MASK       16   /* * (mask[m][n] > 0)   (ReLU backward with the saved output)  */
 #define LVT_EPI_ACCUM      32   /* C += result                                                 */
+/* causal structure of the batched attention products of a masked layer (M, N, K token positions of one block):          */
+#define LVT_CAUSAL_KMAX   (1 << 8)    /* A(m,k) == 0 for k > m: a tile reduces over k < m0 + 128 only  (dQ = dS K)        */
+#define LVT_CAUSAL_KMIN   (1 << 9)    /* A(m,k) == 0 for k < m: a tile starts its reduction at k = m0  (dV = P^T dO, dK)  */
+#define LVT_CAUSAL_TILE   (1 << 10)   /* C(m,n) is only consumed for n <= m: tiles above the diagonal are written as 0   */
 
 /* ---- general batched fp32 GEMM  (torch addmm / bmm / matmul / linear: K14,K18,K20,K22-K25) -------
  * C[z][m][n] = epilogue( alpha * sum_k A[z](m,k) * B[z](k,n) ),  z = zo*batch_inner + zi.

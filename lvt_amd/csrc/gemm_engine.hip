@@ -693,6 +693,11 @@ __device__ __forceinline__ TileCtx lvt_tile_ctx(const KParams &p) {
         t.kbeg = t.split * p.k_per_split;
         t.kend = min(p.K, t.kbeg + p.k_per_split);
     }
+    // Causal attention products (square per-batch problems whose index k, m or n is a token position and whose operand is
+    // known to vanish above / below the diagonal): the structurally-zero part of the reduction is not walked.
+    if (p.flags & LVT_CAUSAL_KMAX) t.kend = min(t.kend, t.m0 + BM);             // A(m, k) == 0 for k > m   (dQ = dS K)
+    if (p.flags & LVT_CAUSAL_KMIN) t.kbeg = max(t.kbeg, (t.m0 / BK) * BK);      // A(m, k) == 0 for k < m   (dV = P^T dO, dK = dS^T Q)
+    if ((p.flags & LVT_CAUSAL_TILE) && t.n0 > t.m0 + BM - 1) t.kend = t.kbeg;   // C(m, n) is not needed for n > m: written as 0
     return t;
 }
 

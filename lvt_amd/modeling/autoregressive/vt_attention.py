@@ -7,6 +7,7 @@ proj + residual -> LN -> Linear -> ReLU -> Linear + residual) as a single autogr
 fp32-MFMA GEMM launches and fused HBM-bound kernels on token-major (b*S, d) activations.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -120,6 +121,7 @@ def linear_wgrad(dy, x, n_out, k_in, rows, want_bias=False):
     return dw, db
 
 
+CAUSAL_SKIP = not os.environ.get("LVT_NO_CAUSAL_SKIP")      # A/B switch of the causal reductions in the backward products
 FUSED_ATTENTION = True      # scores + bias + mask + softmax + P.V in one launch when the block is 256 tokens x 128 dims
 
 
@@ -160,7 +162,7 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         G.gemm(h1, f3w, y2, M, d, f3w.shape[1], flags=L.EPI_BIAS | L.EPI_RESIDUAL, bias=f3b, res=y1)
         ctx.save_for_backward(x, mean1, rstd1, xn, qkv, P, o, y1, mean2, rstd2, fn, h1,
                               ln_w, wqkv, proj_w, f0w, f1w, f3w)
-        ctx.block, ctx.dims = block, (M, d, S, b, na, da)
+        ctx.block, ctx.dims, ctx.masked = block, (M, d, S, b, na, da), bool(masked)
         return y2
 
     @staticmethod
@@ -190,16 +192,19 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         bh = dict(batch_outer=b, batch_inner=na)
         dqkv = torch.empty(3, M, hd, dtype=torch.float32, device=dev)
         dq, dk, dv = dqkv[0], dqkv[1], dqkv[2]
+        # masked (causal) layers: P and dS vanish above the diagonal (the forward kernel writes exact zeros there), so the
+        # products below skip the structurally-zero part of their reductions / tiles
+        cz = ctx.masked and CAUSAL_SKIP
         G.gemm(P, do, dv, S, da, S, ta=1, tb=1, lda=S, ldb=hd, ldc=hd, sA=(na * S * S, S * S), sB=(S * hd, da),
-               sC=(S * hd, da), **bh)
+               sC=(S * hd, da), flags=L.CAUSAL_KMIN if cz else 0, **bh)              # dV[j] = sum_{i >= j} P[i][j] dO[i]
         dP = torch.empty(b, na, S, S, dtype=torch.float32, device=dev)
         G.gemm(do, v, dP, S, S, da, ta=0, tb=0, lda=hd, ldb=hd, ldc=S, sA=(S * hd, da), sB=(S * hd, da),
-               sC=(na * S * S, S * S), **bh)
+               sC=(na * S * S, S * S), flags=L.CAUSAL_TILE if cz else 0, **bh)       # dP[i][j] only matters for j <= i
         ddt, ddh, ddw = tx.attn_softmax_bwd_(P, dP, temper, ctx.block)       # dP now holds dS
         G.gemm(dP, k, dq, S, da, S, ta=0, tb=1, lda=S, ldb=hd, ldc=hd, sA=(na * S * S, S * S), sB=(S * hd, da),
-               sC=(S * hd, da), **bh)
+               sC=(S * hd, da), flags=L.CAUSAL_KMAX if cz else 0, **bh)              # dQ[i] = sum_{j <= i} dS[i][j] K[j]
         G.gemm(dP, q, dk, S, da, S, ta=1, tb=1, lda=S, ldb=hd, ldc=hd, sA=(na * S * S, S * S), sB=(S * hd, da),
-               sC=(S * hd, da), **bh)
+               sC=(S * hd, da), flags=L.CAUSAL_KMIN if cz else 0, **bh)              # dK[j] = sum_{i >= j} dS[i][j] Q[i]
         del dP
         # per-head projections q = xn w_q[h] (k, v alike), all three at once: the data gradient is one GEMM whose
         # reduction runs over (projection, head, da) = 3*hd -- A walks the (3, M, hd) gradient with a 2-level k,
