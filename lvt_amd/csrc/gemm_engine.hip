@@ -202,7 +202,11 @@ template <int BM, int MATH> struct ALoader<A_KPLAIN, BM, MATH> : AKLoaderBase<A_
     }
     __device__ __forceinline__ void fetch(int kend) {
         const bool kok = kcur < kend;
+#ifdef LVT_EXP_L1
+        const long long koff = (kbase + kin) & 31;     // timing experiment: same loads, but every k-tile re-reads the first one (L1 hits)
+#else
         const long long koff = kbase + kin;
+#endif
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i)
             this->v[i] = (kok && rowok[i]) ? ldg4(rowp[i] + koff) : zero4();
@@ -480,7 +484,11 @@ template <int BN, int MATH> struct BLoader<B_KPLAIN, BN, MATH> : BKLoaderBase<BN
     }
     __device__ __forceinline__ void fetch(int kend) {
         const bool kok = kcur < kend;
+#ifdef LVT_EXP_L1
+        const long long koff = (kbase + kin) & 31;
+#else
         const long long koff = kbase + kin;
+#endif
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i)
             this->v[i] = (kok && rowok[i]) ? ldg4(rowp[i] + koff) : zero4();
