@@ -290,11 +290,56 @@ def bench_generate(device, batch):
     rec = run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # roofline of the phase that dominates (the single-token decode steps are bound by the K/V-cache reads of the decode
+    # attention): algorithmic bytes = for every generated position i of a slice, keys 0..i of K and V (hd fp32 each) in each
+    # of the decoder layers -- per video 11 slices x 8 layers x (256 * 257 / 2) key rows x 2 x 4 KiB
+    v = cfgs[0].MODEL.AUTOREGRESSIVE.VT
+    hd = v.N_HEAD_D * v.DA
+    kv_bytes = batch * (16 - n_prime) * len(v.BLOCKS_D) * (256 * 257 // 2) * 2 * hd * 4
     return {"frames_per_s": round(16 * batch / dt, 2), "videos_per_s": round(batch / dt, 3), "batch_videos": batch,
             "seconds": round(dt, 3), "decoder_steps": 11 * 256,
+            "roofline": {"bound": "hbm", "achieved": round(kv_bytes / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(kv_bytes / dt / 8e12, 4), "traffic": None,
+                         "kernel": "lvt_attn_decode_kernel (K/V-cache reads of the single-token decode attention); "
+                                   "`achieved` = algorithmic K/V bytes of the whole run / END-TO-END wall time (encode, "
+                                   "%d decode steps of ~90 launches each, decode of 16 frames); the kernel alone streams "
+                                   "the caches at 6.0 TB/s (profiles/r01_generation_kernel_mix.txt)" % (11 * 256)},
             "note": "5 priming + 11 generated frames per video; random-init weights; sampling is sequential "
                     "(2816 single-token decoder steps per group of <= 256 videos; the groups of a batch run on separate "
                     "streams), videos are replicas across GPUs"}
+
+
+def cpu_baseline_generate(budget_s):
+    """The reference's sampling schedule on the host cores: one FULL decoder pass per generated pixel (vt.py:121-131),
+    one encoder pass per slice.  A bounded sample is timed (a few decoder passes and one encoder pass of the CPU oracle,
+    one video) and extrapolated: seconds per video = 11 x (t_encoder + 256 x t_decoder_pass)."""
+    import seeded
+    from oracle import lvt_oracle as O
+    seed = 29871897
+    p = seeded.seeded_params(seeded.dsfvt_shapes(), seed)
+    block = ((1, 16, 16),) * 8
+    d = O.prepare_slices(seeded.seeded_codes("cpu.gen", (16, 4, 16, 16), seed), (7, 0, 0), (16, 1, 1), (7, 1, 1), 5)
+    ctx, sl, sidx = d["context"][None], d["slice"][None], d["slice_idx"][None]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        O.vt_encoder(p, ctx, sidx, block, (16, 1, 1))            # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        zl = O.vt_encoder(p, ctx, sidx, block, (16, 1, 1))
+        t_enc = time.perf_counter() - t0
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < 12 and (time.perf_counter() - t_start < budget_s or len(times) < 3):
+            t0 = time.perf_counter()
+            yl = O.vt_decoder(p, sl, zl, block)
+            O.channel_predictor_pixel_probs(p, yl, (0, 3, 5), torch.full((1, 4), 0.5))
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    t_dec = times[len(times) // 2]
+    per_video = 11 * (t_enc + 256 * t_dec)
+    return {"value": 16.0 / per_video, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle (PyTorch-CPU restatement of the reference's schedule): 1 encoder pass (%.2f s) and the median "
+                      "of %d full decoder + channel-predictor passes (%.3f s) for one video, extrapolated to "
+                      "11 x (1 + 256 passes) = %.0f s per 16-frame video" % (t_enc, len(times), t_dec, per_video)}
 
 
 def cpu_baseline(batch_clips, budget_s):
@@ -461,6 +506,8 @@ def main():
     if not args.no_generate and rank == 0 and world == 1:
         torch.cuda.empty_cache()
         extra["generate"] = bench_generate(device, args.generate_batch)
+        if not args.no_cpu_baseline:
+            extra["generate"]["cpu_baseline"] = cpu_baseline_generate(args.cpu_seconds * 0.5)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
