@@ -320,7 +320,7 @@ def cpu_baseline_generate(budget_s):
     block = ((1, 16, 16),) * 8
     d = O.prepare_slices(seeded.seeded_codes("cpu.gen", (16, 4, 16, 16), seed), (7, 0, 0), (16, 1, 1), (7, 1, 1), 5)
     ctx, sl, sidx = d["context"][None], d["slice"][None], d["slice_idx"][None]
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
     with torch.no_grad():
         O.vt_encoder(p, ctx, sidx, block, (16, 1, 1))            # warm-up (thread pool, allocator)
         t0 = time.perf_counter()
@@ -328,7 +328,7 @@ def cpu_baseline_generate(budget_s):
         t_enc = time.perf_counter() - t0
         times = []
         t_start = time.perf_counter()
-        while len(times) < 12 and (time.perf_counter() - t_start < budget_s or len(times) < 3):
+        while len(times) < 8 and (time.perf_counter() - t_start < budget_s or len(times) < 3):
             t0 = time.perf_counter()
             yl = O.vt_decoder(p, sl, zl, block)
             O.channel_predictor_pixel_probs(p, yl, (0, 3, 5), torch.full((1, 4), 0.5))
