@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--no-generate", action="store_true", help="skip the secondary generation figure")
     ap.add_argument("--generate-batch", type=int, default=768, help="videos generated at once (decoded as groups of <= 256 on separate streams)")
     ap.add_argument("--no-strict-f32", action="store_true", help="skip the secondary LVT_MATH=f32 figure")
+    ap.add_argument("--generate-cpu-baseline", action="store_true",
+                    help="also time the reference's sampling schedule on the host cores (bounded sample, extrapolated)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
@@ -506,7 +508,7 @@ def main():
     if not args.no_generate and rank == 0 and world == 1:
         torch.cuda.empty_cache()
         extra["generate"] = bench_generate(device, args.generate_batch)
-        if not args.no_cpu_baseline:
+        if args.generate_cpu_baseline:
             extra["generate"]["cpu_baseline"] = cpu_baseline_generate(args.cpu_seconds * 0.5)
 
     if rank == 0:
