@@ -1,22 +1,23 @@
-// fp32 MFMA tile engine for gfx950: one LDS-tiled kernel template that serves
+// MFMA tile engine for gfx950.
+//
+// (1) lvt_gemm_kernel: one LDS-tiled kernel template (128x128 output tile, 4 waves, BK = 32) that serves
 //   * plain / batched GEMMs in NT, NN and TN form            (linear layers, QKV, attention matmuls)
 //   * implicit-GEMM 3-D convolution forward                  (im2col gather in the A loader)
 //   * convolution backward-data / ConvTranspose forward      (stride-phase decomposed gather)
 //   * convolution backward-weight                            (gather on the M side, split-K over pixels)
+//   in two arithmetic modes chosen per call (LVT_MATH_F32 in `flags`):
+//   - bf16x3 (default): every fp32 operand is split exactly into three bf16 planes while it is staged in LDS and each
+//     32x32x16 block is six v_mfma_f32_32x32x16_bf16 (fp32-class accuracy, ~1.6x the fp32 instruction's rate);
+//   - f32: v_mfma_f32_32x32x2_f32, both operands k-major in LDS ([k][m], m contiguous) so that the per-MFMA operand
+//     fetch is one conflict-free ds_read_b32 per lane; row pads keep the transposing stores conflict-free.
+//   Global -> register -> LDS staging with the next tile's global loads issued before the MFMA block of the current tile;
+//   16-byte loads along the contiguous dimension; two workgroups resident per CU; split-K writes per-split partial tiles
+//   that a second kernel reduces in a fixed order (no float atomics: weight gradients are bit-reproducible).
 //
-// Design (MI355X, wave64):
-//   - 256 threads = 4 waves per workgroup, 128x128 (or 128x32) output tile, BK = 32.
-//   - matrix core: v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles / SIMD).  A wave owns a 64x64
-//     sub-tile = 2x2 MFMA tiles = 64 accumulator registers.
-//   - both operands live in LDS "k-major" ([k][m], m contiguous) so that the per-MFMA operand
-//     fetch is one conflict-free ds_read_b32 per lane (lanes 0-31 -> 32 consecutive floats of row k,
-//     lanes 32-63 -> row k+1).  Row pads (+1 / +4 floats) make the transposing stores of the
-//     k-contiguous loaders conflict-free as well (cdna_hip_programming.md section 2).
-//   - global -> register -> LDS staging with the next tile's global loads issued before the MFMA
-//     block of the current tile (register prefetch); 16-byte loads along the contiguous dimension.
-//   - ~4 workgroups / CU resident (<=128 VGPR, 33 KiB LDS) hide the remaining latency.
-//   - split-K writes per-split partial tiles that a second kernel reduces in a fixed order, so
-//     weight gradients are bit-reproducible run to run (no float atomics).
+// (2) lvt_conv_patch_kernel<MODE> (round 2): frame-resident convolutions of the 16x16 / 32x32 VQ-VAE frames -- the input
+//   patch of a frame is staged ONCE per 32-channel chunk and the taps read it in place (3x3; the phases of the stride-2
+//   transposed convolution; the parity classes of the stride-2 convolution).  Staging, not the matrix pipe, bounds (1):
+//   profiles/r02_engine_staging_experiments.txt.  The matching weight-gradient kernel lives in conv_wgrad.hip.
 #include "lvt_common.h"
 #include <string.h>
 #include <stdlib.h>

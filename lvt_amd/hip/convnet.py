@@ -3,8 +3,15 @@ residual epilogues on the implicit-GEMM engine, and its hand-scheduled backward.
 
 Every activation is stored once, post-activation and channels-last.  ReLU backward is folded into
 the epilogue of the kernel that produces the upstream gradient (mask = saved post-ReLU output) and
-residual gradients are added in the same epilogue, so the backward chain is exactly three engine
-launches per layer (bwd-data, bwd-weight, bias column-sum) with no stand-alone elementwise pass.
+residual gradients are added in the same epilogue, so the backward chain is two or three engine
+launches per layer (bwd-data, bwd-weight [+ bias column-sum where the weight-gradient kernel does not
+produce it]) with no stand-alone elementwise pass.
+
+Routing (round 2): the 3x3 and 4x4/stride-2 layers between 16x16 and 32x32 frames run on the
+frame-resident kernels -- forward through `conv_fwd` (3x3) / `conv_fwd(wq=...)` (strided, parity classes),
+transposed passes through `conv_bwd_data(wt=...)` (3x3, as a forward convolution over transposed weights) /
+`conv_bwd_data(wph=...)` (stride 2, phase by phase), weight gradients inside `conv_bwd_weight`.  The extra
+weight packs are made next to the forward one; every other geometry takes the implicit-GEMM engine.
 """
 import torch
 
