@@ -213,3 +213,38 @@ def test_mapper_general_strides_match_reference_contexts(golden, tag, stride, ke
     assert torch.equal(ctx, g["context"]) and torch.equal(sidx, g["slice_idx"])
     assert torch.equal(sl, torch.stack([torch.as_tensor(d["slice"]) for d in ds]))
     assert torch.equal(ign, torch.stack([torch.as_tensor(d["ignore_mask"]) for d in ds]))
+
+
+def test_frame_resident_kernel_routing_of_the_vqvae_layers():
+    """Host-side queries of the C ABI (no GPU needed): which kernel family serves the layers of PR-DVQVAE2 / K-DVQVAE.
+    A refactor that silently drops a layer back to the implicit-GEMM engine would cost 20-30 % on it without failing
+    any numerics test."""
+    import ctypes
+    from lvt_amd.hip import binding as L, gemm as G
+    lib, F32 = L.lib(), L.MATH_F32
+
+    def geom(ci, co, k, s, p, h):
+        return G.conv_geom(512, 1, h, h, ci, co, (1, k, k), (1, s, s), (0, p, p))
+
+    k3, k4a = geom(256, 256, 3, 1, 1, 16), geom(256, 128, 3, 1, 1, 16)
+    for g in (k3, k4a):
+        assert lib.lvt_conv3d_uses_patch_kernel(ctypes.byref(g), 0) == 1                    # forward
+        assert lib.lvt_conv3d_uses_patch_kernel(ctypes.byref(G.swapped_geom(g)), 0) == 1    # backward-data as a forward conv
+        assert lib.lvt_conv3d_uses_patch_kernel(ctypes.byref(g), F32) == 0                  # f32 mode: implicit GEMM
+        assert lib.lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g), 0) == 0                # frame-resident weight gradient
+        assert lib.lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g), F32) == 1
+    sg = G.swapped_geom(k4a)
+    assert (sg.Ci, sg.Co, sg.ph, sg.pw, sg.Ho, sg.Wo) == (128, 256, 1, 1, 16, 16)
+    k2 = geom(128, 256, 4, 2, 1, 32)                    # Conv 128->256 k4 s2 and, mirrored, ConvTranspose 256->128
+    assert lib.lvt_conv3d_fwd_uses_parity_kernel(ctypes.byref(k2), 0) == 1
+    assert lib.lvt_conv3d_bwd_data_uses_phase_kernel(ctypes.byref(k2), 0) == 1
+    assert lib.lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(k2), 0) == 0
+    assert lib.lvt_conv3d_fwd_uses_parity_kernel(ctypes.byref(k2), F32) == 0
+    # layers that stay on the engine: 1x1, the image-side 4 -> 128 layer, other frame sizes
+    for g in (geom(128, 256, 1, 1, 0, 16), geom(4, 128, 4, 2, 1, 64), geom(256, 256, 3, 1, 1, 32)):
+        assert lib.lvt_conv3d_uses_patch_kernel(ctypes.byref(g), 0) == 0
+        assert lib.lvt_conv3d_fwd_uses_parity_kernel(ctypes.byref(g), 0) == 0
+        assert lib.lvt_conv3d_bwd_data_uses_phase_kernel(ctypes.byref(g), 0) == 0
+        assert lib.lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g), 0) == 1
+    # workspace of the weight gradient covers both routes
+    assert lib.lvt_conv3d_bwd_weight_workspace_bytes(ctypes.byref(k3)) >= 32 * 9 * 256 * 256 * 4
