@@ -7,11 +7,16 @@ per GPU, fp32, on N MI355X of one node (BASELINE.json `configs[1]`, metric video
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = forward + backward + Adam step of the whole VQ-VAE (encoder, 4x512 EMA codebooks, decoder) on
-one batch that is already resident in HBM.  One process per GPU; gradients are averaged with a bucketed
-RCCL all-reduce overlapped with backward, EMA statistics with one fused all-reduce.  Weak scaling.
-Rank 0 prints ONE JSON line; `roofline` describes the dominant kernel (the fp32-MFMA implicit-GEMM engine,
-timed per launch with HIP events on the launch stream inside the timed region) and `cpu_baseline` is the
-CPU oracle (a port of the reference's PyTorch-CPU path) timed on the host cores of the same box.
+one of `--batches` synthetic batches that are already resident in HBM (rotated step by step).  One process per GPU;
+gradients are averaged with a bucketed RCCL all-reduce overlapped with backward (it joins itself before
+`optimizer.step()`), EMA statistics with one fused all-reduce.  Weak scaling.
+Rank 0 prints ONE JSON line: `value` / `ms_per_step` from exactly K steps between two barriers (+ per-step median / p10 / p90
+from one HIP event per step); `roofline` describes the dominant kernels (the matrix-core conv / GEMM engine: implicit-GEMM
+and frame-resident kernels), event-timed per launch on the launch stream in a SECOND pass of the same K steps (a timing
+event is a barrier packet: inside the timed region it would cost ~15 % of the step); `cpu_baseline` is the CPU oracle (a
+port of the reference's PyTorch-CPU path) timed on the host cores of the same box.  `extra` holds the same for the DSFVT
+train step (own roofline block and CPU baseline), the LVT_MATH=f32 variants, the combined VQVAE+DSFVT clips/s and -- with
+`--generate` -- the end-to-end generation figure.
 """
 import argparse
 import gc
