@@ -42,7 +42,7 @@ class _XentFn(torch.autograd.Function):
 
 # groups of a large sampling batch run on their own streams (False: one after the other on the caller's stream;
 # the results are identical -- tests/test_gpu_sampling.py)
-DECODE_GROUP_STREAMS = True
+DECODE_GROUP_STREAMS = os.environ.get("LVT_DECODE_GROUP_STREAMS", "1") != "0"      # "0": groups one after the other
 MAX_CONCURRENT_GROUPS = 3
 DECODE_GROUP_ROWS = 256          # videos per decode group (rows of every decode-step launch)
 
