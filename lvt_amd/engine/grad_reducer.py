@@ -71,9 +71,15 @@ class BucketedGradReducer:
         self._hooks.append(register_optimizer_step_pre_hook(_before_step))
 
     def remove(self):
+        """Detach from the parameters and the optimizers (gradients stay where they are)."""
+        self.wait()
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for p in self.params:
+            ref = getattr(p, "_lvt_reducer", None)
+            if ref is not None and ref() is self:
+                del p._lvt_reducer
 
     def _make_bucket(self, plist):
         dev, dt = plist[0].device, plist[0].dtype
