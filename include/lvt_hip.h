@@ -32,7 +32,7 @@ extern "C" {
 #define LVT_ENODEVICE   (-4)   /* no gfx950 device visible                             */
 
 const char *lvt_last_error(void);
-int lvt_version(void);
+int lvt_version(void);          /* 300 = round 3 (ABI changes are listed in INTEGRATION.md) */
 /* Device probe: name, CU count, clock (kHz), HBM bytes.  Returns LVT_ENODEVICE without a GPU. */
 int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long long *hbm_bytes);
 
@@ -94,7 +94,10 @@ int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t workspace_bytes
 int lvt_gemm_smallm_f32(int M, int N, int K, int tb, const float *A, long long lda, const float *B,
                         long long ldb, float *C, long long ldc, int batch, long long sB, long long sC,
                         float alpha, int flags, const float *bias, const float *res, long long ldr,
-                        void *stream);
+                        const int *pos, long long c_pos, long long r_pos, void *stream);
+/* `pos` (NULL, or a device int) is a row cursor read by the kernel: C += pos[0]*c_pos and res += pos[0]*r_pos.  With it
+ * the launch arguments of a decode step do not depend on the position being decoded, so ONE captured hipGraph is
+ * replayed for every position (autoregressive/incremental.py); the same three arguments on the split-K form below. */
 /* Split-K form of the small-M product for long reductions (K >= 1024: the FFN down-projection, the attention output
  * projection and the wide predictor layers of a decode step).  K is cut into `splits` equal ranges (each a multiple
  * of 8) that run as independent workgroups; the partial tiles go through `workspace` and are added in split order by
@@ -102,7 +105,8 @@ int lvt_gemm_smallm_f32(int M, int N, int K, int tb, const float *A, long long l
 size_t lvt_gemm_smallm_splitk_workspace_bytes(int M, int N, int splits);
 int lvt_gemm_smallm_splitk_f32(int M, int N, int K, int splits, const float *A, long long lda, const float *B,
                                long long ldb, float *C, long long ldc, float alpha, int flags, const float *bias,
-                               const float *res, long long ldr, void *workspace, size_t workspace_bytes, void *stream);
+                               const float *res, long long ldr, const int *pos, long long c_pos, long long r_pos,
+                               void *workspace, size_t workspace_bytes, void *stream);
 /* The same partial products without the reduction launch (workspace = [splits][M][N] raw partial tiles), and the
  * LayerNorm that consumes them:  x = sum_s partials[s] (+ bias) (+ res);  x_out = x;  y = LN(x) * w + b.
  * In a decoder layer both products that end in a residual feed a LayerNorm (vt_attention.py:121,138), so the split-K
@@ -260,16 +264,29 @@ int lvt_attn_fwd(const float *q, const float *k, const float *v, int B, int H, i
 
 /* single-query attention against a token-major K/V cache (incremental sampling: the reference re-runs the
  * whole causal decoder for every generated pixel, vt.py:121-131).  q (B rows of H*da, row stride ldq), o (B, H*da), caches (B, S, H*da);
- * attends keys 0..qi with the same scale / bias-bank rule as lvt_attn_softmax_fwd.  da == 128.        */
+ * attends keys 0..qi with the same scale / bias-bank rule as lvt_attn_softmax_fwd.  da == 128.
+ * With `pos` != NULL the query position is the device int pos[0] (clamped to [0, S)) instead of `qi`, and the query
+ * rows start at q + pos[0]*q_pos: position-independent launch arguments for hipGraph replay.            */
 int lvt_attn_decode(const float *q, long long ldq, const float *Kc, const float *Vc, int B, int H, int S, int da, int qi,
                     float temper, const float *dt, const float *dh, const float *dw, int bt, int bh, int bw,
-                    float *o, void *stream);
+                    float *o, const int *pos, long long q_pos, void *stream);
+
+/* integer plumbing of a decode step driven by a device-side cursor (the reference indexes python ints: vt.py:121-131).
+ * codes (rows, S1) int64 with S1 = S + 1: the slice being decoded, one always-padded extra slot per row.
+ * gather: out[r][j] = codes[r][nb[pos[0]][j]] for the `taps` causal-conv neighbours of the current position (nb is
+ *         (S, taps) int64, entries in [0, S]); commit: codes[r][pos[0]] = drawn[r] (drawn may be NULL), then pos[0] += 1. */
+int lvt_decode_gather_codes(const long long *codes, const long long *nb, const int *pos, int rows, int S1, int taps,
+                            long long *out, void *stream);
+int lvt_decode_commit(const long long *drawn, int rows, int S1, long long *codes, int *pos, void *stream);
 
 /* categorical draw per row from logits / temp with caller-supplied uniforms u[row] in [0,1) (the reference draws
  * with torch.multinomial on softmax(logit / temp), videotransformer.py:176-181): code = #{ j : cdf_j <= u * total },
- * clamped to V-1, written as int64 at out[row * out_stride]; `probs` (rows, V) is optional.  V <= 1024.   */
+ * clamped to V-1, written as int64 at out[row * out_stride]; `probs` (rows, V) is optional.  V <= 1024.
+ * With `pos` != NULL the uniforms are read at u + pos[0]*u_pos: a table of draws for every position of a slice,
+ * filled once per slice, indexed by the device-side cursor of the decode graphs (no generator inside a graph).  */
 int lvt_sample_categorical(const float *logits, long long rows, int V, float temp, const float *u,
-                           long long *out, long long out_stride, float *probs, void *stream);
+                           long long *out, long long out_stride, float *probs, const int *pos, long long u_pos,
+                           void *stream);
 
 /* ---- embedding bags: the one-hot Conv3d / Embedding sums / one-hot Linear inputs as gathers (K13,K15,K25)
  * out[b*P+pos][:] = bias + btable[bindex[b]] + sum_s table[tab_row[s] + idx[b*bstride + off[s] + pos]][:]

@@ -20,6 +20,7 @@ struct SmallParams {
     long long sA, sB, sC;             // per-batch (blockIdx.y) offsets of A (0: shared), B and C
     float alpha; int flags;
     const float *bias; const float *res; long long ldr;
+    const int *pos; long long c_pos, r_pos;   // device-side row cursor: C += pos[0]*c_pos, res += pos[0]*r_pos (hipGraph replay)
 };
 
 #define SM_KC 128
@@ -75,15 +76,18 @@ __global__ __launch_bounds__(256) void lvt_gemm_smallm_kernel(const SmallParams 
     }
     const int n = n0 + nl;
     if (n >= p.N) return;
+    const long long cur = p.pos ? (long long)p.pos[0] : 0;
+    float *Cp = p.C + cur * p.c_pos;
+    const float *Rp = p.res ? p.res + cur * p.r_pos : nullptr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int m = mg + 16 * r;
         if (m >= p.M) continue;
         float v = acc[r] * p.alpha;
         if (p.flags & LVT_EPI_BIAS) v += p.bias[n];
-        if (p.flags & LVT_EPI_RESIDUAL) v += p.res[(long long)m * p.ldr + n];
+        if (p.flags & LVT_EPI_RESIDUAL) v += Rp[(long long)m * p.ldr + n];
         if (p.flags & LVT_EPI_RELU) v = fmaxf(v, 0.f);
-        p.C[z * p.sC + (long long)m * p.ldc + n] = v;
+        Cp[z * p.sC + (long long)m * p.ldc + n] = v;
     }
 }
 
@@ -208,6 +212,9 @@ __global__ __launch_bounds__(64 * SMM_WAVES) void lvt_gemm_smallm_mfma_kernel(co
     __syncthreads();
     const int col = n0 + l31;
     if (col >= p.N) return;
+    const long long cur = p.pos ? (long long)p.pos[0] : 0;
+    float *Cp = p.C + cur * p.c_pos;
+    const float *Rp = p.res ? p.res + cur * p.r_pos : nullptr;
 #pragma unroll
     for (int t = 0; t < TM; ++t)
 #pragma unroll
@@ -220,16 +227,16 @@ __global__ __launch_bounds__(64 * SMM_WAVES) void lvt_gemm_smallm_mfma_kernel(co
             for (int w = 1; w < SMM_WAVES; ++w) v += red[w][t][r][lane];
             v *= p.alpha;
             if (p.flags & LVT_EPI_BIAS) v += p.bias[col];
-            if (p.flags & LVT_EPI_RESIDUAL) v += p.res[(long long)m * p.ldr + col];
+            if (p.flags & LVT_EPI_RESIDUAL) v += Rp[(long long)m * p.ldr + col];
             if (p.flags & LVT_EPI_RELU) v = fmaxf(v, 0.f);
-            p.C[z * p.sC + (long long)m * p.ldc + col] = v;
+            Cp[z * p.sC + (long long)m * p.ldc + col] = v;
         }
 }
 
 extern "C" int lvt_gemm_smallm_f32(int M, int N, int K, int tb, const float *A, long long lda, const float *B,
                                    long long ldb, float *C, long long ldc, int batch, long long sB, long long sC,
                                    float alpha, int flags, const float *bias, const float *res, long long ldr,
-                                   void *stream) {
+                                   const int *pos, long long c_pos, long long r_pos, void *stream) {
     LVT_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0, "gemm_smallm: bad shape (M=%d)", M);
     LVT_REQUIRE(M <= 64 || (tb == 0 && K % 8 == 0), "gemm_smallm: M=%d > 64 needs the k-contiguous layout (tb == 0, K %% 8 == 0)", M);
     LVT_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && lvt_aligned16(A) && lvt_aligned16(B), "gemm_smallm: alignment");
@@ -240,6 +247,7 @@ extern "C" int lvt_gemm_smallm_f32(int M, int N, int K, int tb, const float *A, 
     SmallParams p;
     p.M = M; p.N = N; p.K = K; p.tb = tb; p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
     p.sA = 0; p.sB = sB; p.sC = sC; p.alpha = alpha; p.flags = flags; p.bias = bias; p.res = res; p.ldr = ldr;
+    p.pos = pos; p.c_pos = c_pos; p.r_pos = r_pos;
     if (tb == 0 && K % 8 == 0) {
         dim3 grid((unsigned)lvt_cdiv(N, 32), (unsigned)batch, (unsigned)(M <= 32 ? 1 : lvt_cdiv(M, 64)));
         if (M <= 32) hipLaunchKernelGGL(lvt_gemm_smallm_mfma_kernel<1>, grid, dim3(64 * SMM_WAVES), 0, (hipStream_t)stream, p);
@@ -263,8 +271,10 @@ extern "C" int lvt_gemm_smallm_f32(int M, int N, int K, int tb, const float *A, 
 // ------------------------------------------------------------------------------------------------
 __global__ void lvt_smallm_reduce_kernel(const float *__restrict__ ws, int splits, int M, int N, float *__restrict__ C,
                                          long long ldc, float alpha, int flags, const float *__restrict__ bias,
-                                         const float *__restrict__ res, long long ldr) {
+                                         const float *__restrict__ res, long long ldr, const int *__restrict__ pos,
+                                         long long c_pos, long long r_pos) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // float4 index over M x N
+    if (pos) { const long long cur = pos[0]; C += cur * c_pos; if (res) res += cur * r_pos; }
     const int n4 = N / 4;
     if (i >= M * n4) return;
     const int m = i / n4, c = (i - m * n4) * 4;
@@ -307,6 +317,7 @@ static int smallm_partial(int M, int N, int K, int splits, const float *A, long 
     p.M = M; p.N = N; p.K = Kc; p.tb = 0; p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;
     p.C = (float *)workspace; p.ldc = N; p.sA = Kc; p.sB = Kc; p.sC = (long long)M * N;
     p.alpha = 1.f; p.flags = 0; p.bias = nullptr; p.res = nullptr; p.ldr = 0;
+    p.pos = nullptr; p.c_pos = 0; p.r_pos = 0;
     dim3 grid((unsigned)lvt_cdiv(N, 32), (unsigned)splits, (unsigned)(M <= 32 ? 1 : lvt_cdiv(M, 64)));
     if (M <= 32) hipLaunchKernelGGL(lvt_gemm_smallm_mfma_kernel<1>, grid, dim3(64 * SMM_WAVES), 0, s, p);
     else hipLaunchKernelGGL(lvt_gemm_smallm_mfma_kernel<2>, grid, dim3(64 * SMM_WAVES), 0, s, p);
@@ -316,7 +327,8 @@ static int smallm_partial(int M, int N, int K, int splits, const float *A, long 
 
 extern "C" int lvt_gemm_smallm_splitk_f32(int M, int N, int K, int splits, const float *A, long long lda, const float *B,
                                           long long ldb, float *C, long long ldc, float alpha, int flags,
-                                          const float *bias, const float *res, long long ldr, void *workspace,
+                                          const float *bias, const float *res, long long ldr, const int *pos,
+                                          long long c_pos, long long r_pos, void *workspace,
                                           size_t workspace_bytes, void *stream) {
     LVT_REQUIRE(C, "gemm_smallm_splitk: null output");
     LVT_REQUIRE(!(flags & ~(LVT_EPI_BIAS | LVT_EPI_RESIDUAL | LVT_EPI_RELU)), "gemm_smallm_splitk: unsupported flag");
@@ -327,7 +339,7 @@ extern "C" int lvt_gemm_smallm_splitk_f32(int M, int N, int K, int splits, const
     if (rc) return rc;
     const int total4 = M * (N / 4);
     hipLaunchKernelGGL(lvt_smallm_reduce_kernel, dim3((unsigned)lvt_cdiv(total4, 256)), dim3(256), 0, s,
-                       (const float *)workspace, splits, M, N, C, ldc, alpha, flags, bias, res, ldr);
+                       (const float *)workspace, splits, M, N, C, ldc, alpha, flags, bias, res, ldr, pos, c_pos, r_pos);
     LVT_CHECK_LAUNCH("lvt_smallm_reduce_kernel");
     return LVT_OK;
 }

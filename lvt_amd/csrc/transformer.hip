@@ -452,13 +452,19 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void lvt_attn_decode_kernel(const f
                                                              const float *__restrict__ Vc, int H, int S, int qi,
                                                              float temper, const float *__restrict__ dt,
                                                              const float *__restrict__ dh, const float *__restrict__ dw,
-                                                             BiasGeom g, float *__restrict__ o) {
+                                                             BiasGeom g, float *__restrict__ o,
+                                                             const int *__restrict__ pos, long long q_pos) {
     __shared__ float qs[DEC_DA];
     __shared__ float ps[1024];
     __shared__ float redm[DEC_WAVES], reds[DEC_WAVES];
     __shared__ float acc[DEC_WAVES][DEC_DA];
     const int b = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hd = H * DEC_DA;
+    if (pos) {                                   // device-side cursor (hipGraph replay): clamped so that a stale value cannot
+        qi = pos[0];                             // address outside the caches
+        qi = qi < 0 ? 0 : (qi >= S ? S - 1 : qi);
+        q += (long long)qi * q_pos;
+    }
     const float *qp = q + (long long)b * ldq + h * DEC_DA;
     if (tid < DEC_DA) qs[tid] = qp[tid];
     __syncthreads();
@@ -547,8 +553,10 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void lvt_attn_decode_kernel(const f
 #define SMP_MAXPER 16
 __global__ __launch_bounds__(64) void lvt_sample_categorical_kernel(const float *__restrict__ logits, int V, float inv_temp,
                                                                     const float *__restrict__ u, long long *__restrict__ out,
-                                                                    long long out_stride, float *__restrict__ probs) {
+                                                                    long long out_stride, float *__restrict__ probs,
+                                                                    const int *__restrict__ pos, long long u_pos) {
     const int row = blockIdx.x, lane = threadIdx.x;
+    if (pos) u += (long long)pos[0] * u_pos;
     const float *x = logits + (long long)row * V;
     const int per = (V + 63) / 64;                      // consecutive elements per lane: cdf order == memory order
     const int j0 = lane * per;
@@ -579,23 +587,68 @@ __global__ __launch_bounds__(64) void lvt_sample_categorical_kernel(const float 
 }
 
 extern "C" int lvt_sample_categorical(const float *logits, long long rows, int V, float temp, const float *u,
-                                      long long *out, long long out_stride, float *probs, void *stream) {
+                                      long long *out, long long out_stride, float *probs, const int *pos, long long u_pos,
+                                      void *stream) {
     LVT_REQUIRE(logits && u && out && rows > 0 && V > 0 && V <= 64 * SMP_MAXPER && temp > 0.f, "sample_categorical: bad args");
     hipLaunchKernelGGL(lvt_sample_categorical_kernel, dim3((unsigned)rows), dim3(64), 0, (hipStream_t)stream, logits, V,
-                       1.f / temp, u, out, out_stride, probs);
+                       1.f / temp, u, out, out_stride, probs, pos, u_pos);
     LVT_CHECK_LAUNCH("lvt_sample_categorical_kernel");
     return LVT_OK;
 }
 
 extern "C" int lvt_attn_decode(const float *q, long long ldq, const float *Kc, const float *Vc, int B, int H, int S, int da, int qi,
                                float temper, const float *dt, const float *dh, const float *dw, int bt, int bh, int bw,
-                               float *o, void *stream) {
+                               float *o, const int *pos, long long q_pos, void *stream) {
     LVT_REQUIRE(q && Kc && Vc && dt && dh && dw && o && B > 0 && H > 0, "attn_decode: bad args");
     LVT_REQUIRE(da == DEC_DA && S == bt * bh * bw && S <= 1024 && qi >= 0 && qi < S, "attn_decode: unsupported shape");
     BiasGeom g = {bt, bh, bw};
     LVT_REQUIRE(ldq >= (long long)H * da, "attn_decode: ldq");
     hipLaunchKernelGGL(lvt_attn_decode_kernel, dim3(B * H), dim3(64 * DEC_WAVES), 0, (hipStream_t)stream, q, ldq, Kc, Vc, H, S, qi,
-                       temper, dt, dh, dw, g, o);
+                       temper, dt, dh, dw, g, o, pos, q_pos);
     LVT_CHECK_LAUNCH("lvt_attn_decode_kernel");
+    return LVT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Integer plumbing of a decode step whose position lives in DEVICE memory, so that one captured hipGraph serves every
+// position of every slice (autoregressive/incremental.py):
+//   lvt_decode_gather_codes: out[b][c][j] = codes[b][c][ nb[pos][j] ]   -- the codes of the causal-conv neighbours of
+//       the current position (nb rows of `taps` int64 entries; entry == S points at the always-padded extra slot)
+//   lvt_decode_commit:       codes[b][c][pos] = drawn[b][c] (optional), then pos += 1.  ONE workgroup, so that the
+//       increment is ordered after every read of the cursor.
+// codes is (B, nc, S1) int64 with S1 = S + 1 (the padded slot).
+// ------------------------------------------------------------------------------------------------
+__global__ void lvt_decode_gather_codes_kernel(const long long *__restrict__ codes, const long long *__restrict__ nb,
+                                               const int *__restrict__ pos, int rows, int S1, int taps,
+                                               long long *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * taps) return;
+    int cur = pos[0];
+    cur = cur < 0 ? 0 : (cur >= S1 - 1 ? S1 - 2 : cur);
+    const int r = i / taps, j = i - r * taps;
+    long long n = nb[(long long)cur * taps + j];
+    n = n < 0 ? S1 - 1 : (n >= S1 ? S1 - 1 : n);
+    out[i] = codes[(long long)r * S1 + n];
+}
+__global__ __launch_bounds__(256) void lvt_decode_commit_kernel(const long long *__restrict__ drawn, int rows, int S1,
+                                                                long long *__restrict__ codes, int *__restrict__ pos) {
+    const int cur = pos[0];
+    if (drawn && cur >= 0 && cur < S1 - 1)
+        for (int r = threadIdx.x; r < rows; r += blockDim.x) codes[(long long)r * S1 + cur] = drawn[r];
+    __syncthreads();
+    if (threadIdx.x == 0) pos[0] = cur + 1;
+}
+extern "C" int lvt_decode_gather_codes(const long long *codes, const long long *nb, const int *pos, int rows, int S1,
+                                       int taps, long long *out, void *stream) {
+    LVT_REQUIRE(codes && nb && pos && out && rows > 0 && S1 > 1 && taps > 0, "decode_gather_codes: bad args");
+    hipLaunchKernelGGL(lvt_decode_gather_codes_kernel, dim3((unsigned)lvt_cdiv((long long)rows * taps, 256)), dim3(256), 0,
+                       (hipStream_t)stream, codes, nb, pos, rows, S1, taps, out);
+    LVT_CHECK_LAUNCH("lvt_decode_gather_codes_kernel");
+    return LVT_OK;
+}
+extern "C" int lvt_decode_commit(const long long *drawn, int rows, int S1, long long *codes, int *pos, void *stream) {
+    LVT_REQUIRE(codes && pos && rows > 0 && S1 > 1, "decode_commit: bad args");
+    hipLaunchKernelGGL(lvt_decode_commit_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, drawn, rows, S1, codes, pos);
+    LVT_CHECK_LAUNCH("lvt_decode_commit_kernel");
     return LVT_OK;
 }

@@ -14,6 +14,7 @@ _LIB_PATH = os.environ.get("LVT_HIP_LIB") or os.path.join(os.path.dirname(_HERE)
 
 EPI_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_TANH, EPI_MASK, EPI_ACCUM = 1, 2, 4, 8, 16, 32
 CAUSAL_KMAX, CAUSAL_KMIN, CAUSAL_TILE = 1 << 8, 1 << 9, 1 << 10      # causal attention products (include/lvt_hip.h)
+ABI_VERSION = 300           # lvt_version() of the library this module binds (argument lists below)
 MATH_F32 = 1 << 16          # per-call arithmetic selector of the engine entry points (include/lvt_hip.h)
 
 
@@ -63,9 +64,9 @@ def _declare(lib):
         "lvt_device_info": (ci, [C.c_char_p, ci, P(ci), P(ci), P(cll)]),
         "lvt_gemm_workspace_bytes": (sz, [P(GemmDesc)]),
         "lvt_gemm_f32": (ci, [P(GemmDesc), vp, sz, vp]),
-        "lvt_gemm_smallm_f32": (ci, [ci, ci, ci, ci, vp, cll, vp, cll, vp, cll, ci, cll, cll, cf, ci, vp, vp, cll, vp]),
+        "lvt_gemm_smallm_f32": (ci, [ci, ci, ci, ci, vp, cll, vp, cll, vp, cll, ci, cll, cll, cf, ci, vp, vp, cll, vp, cll, cll, vp]),
         "lvt_gemm_smallm_splitk_workspace_bytes": (sz, [ci, ci, ci]),
-        "lvt_gemm_smallm_splitk_f32": (ci, [ci, ci, ci, ci, vp, cll, vp, cll, vp, cll, cf, ci, vp, vp, cll, vp, sz, vp]),
+        "lvt_gemm_smallm_splitk_f32": (ci, [ci, ci, ci, ci, vp, cll, vp, cll, vp, cll, cf, ci, vp, vp, cll, vp, cll, cll, vp, sz, vp]),
         "lvt_gemm_smallm_partial_f32": (ci, [ci, ci, ci, ci, vp, cll, vp, cll, vp, sz, vp]),
         "lvt_splitsum_layernorm_fwd": (ci, [vp, ci, ci, ci, vp, vp, cll, vp, cf, vp, vp, vp, vp]),
         "lvt_conv3d_pack_weight": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
@@ -105,8 +106,10 @@ def _declare(lib):
         "lvt_attn_softmax_fwd": (ci, [vp, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp]),
         "lvt_attn_softmax_bwd": (ci, [vp, vp, ci, ci, ci, cf, ci, ci, ci, vp, vp, vp, vp, vp]),
         "lvt_attn_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp]),
-        "lvt_attn_decode": (ci, [vp, cll, vp, vp, ci, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, vp, vp]),
-        "lvt_sample_categorical": (ci, [vp, cll, ci, cf, vp, vp, cll, vp, vp]),
+        "lvt_attn_decode": (ci, [vp, cll, vp, vp, ci, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, vp, vp, cll, vp]),
+        "lvt_decode_gather_codes": (ci, [vp, vp, vp, ci, ci, ci, vp, vp]),
+        "lvt_decode_commit": (ci, [vp, ci, ci, vp, vp, vp]),
+        "lvt_sample_categorical": (ci, [vp, cll, ci, cf, vp, vp, cll, vp, vp, cll, vp]),
         "lvt_embbag_fwd": (ci, [vp, cll, ci, cll, ci, P(ci), P(ci), vp, ci, vp, vp, vp, vp, vp]),
         "lvt_onehot_tn_workspace_bytes": (sz, [ci, ci, ci, cll]),
         "lvt_onehot_tn_gemm": (ci, [vp, ci, ci, P(ci), cll, cll, ci, cll, vp, cll, ci, vp, ci, vp, sz, vp]),
@@ -138,6 +141,10 @@ def lib():
             raise LvtError("liblvt_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; "
                            "g.build()'` (or `make -C lvt_amd/csrc`); there is no CPU fallback" % _LIB_PATH)
         handle = C.CDLL(_LIB_PATH)
+        handle.lvt_version.restype = C.c_int
+        if handle.lvt_version() != ABI_VERSION:
+            raise LvtError("liblvt_hip.so at %s has ABI version %d, this package binds version %d -- rebuild it "
+                           "(`make -C lvt_amd/csrc`)" % (_LIB_PATH, handle.lvt_version(), ABI_VERSION))
         handle._lvt_sigs = _declare(handle)
         _lib = handle
     return _lib
@@ -232,7 +239,12 @@ _ws = {}
 
 
 def workspace(nbytes, device, tag="default"):
-    """Grow-only scratch buffer per (device, tag, stream), reused across calls on the same stream."""
+    """Grow-only scratch buffer per (device, tag, stream), reused across calls on the same stream.  A larger request
+    REPLACES the buffer, so its address must never be recorded into a hipGraph: callers that capture launches own their
+    scratch (autoregressive/incremental.py), and asking for this one while a capture is running is an error."""
+    if torch.cuda.is_current_stream_capturing():
+        raise LvtError("binding.workspace(%r) requested during hipGraph capture: captured launches must use scratch "
+                       "owned by the object that owns the graph" % (tag,))
     key = (device, tag, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:

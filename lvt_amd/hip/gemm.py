@@ -51,15 +51,19 @@ def _smallm_splits(N, K):
 
 
 def gemm_small(A, B, C_out, M, N, K, tb=0, lda=None, ldb=None, ldc=None, batch=1, sB=0, sC=0, alpha=1.0, flags=0,
-               bias=None, res=None, ldr=0, split_ws=None):
+               bias=None, res=None, ldr=0, split_ws=None, pos=None, c_pos=0, r_pos=0):
     """C = epi(alpha * A @ B) for a few rows (incremental decoding: M = videos per step); see lvt_gemm_smallm_f32.
     `split_ws`: the caller's own split-K scratch (a callable bytes -> uint8/float tensor).  Callers that record
     launches into hipGraphs replayed on several streams (autoregressive/incremental.py) must pass one: the
-    default workspace is shared per stream and every capture runs on the same capture stream."""
-    L.require(A, B, bias, res)
+    default workspace is shared per stream and every capture runs on the same capture stream.
+    `pos` (int32 device scalar): row cursor read by the kernel, C += pos*c_pos and res += pos*r_pos elements."""
+    L.require(A, B, bias, res, pos)
     # up to 512 rows stay on the decode kernels (one workgroup per 64 rows x 32 columns: 3x the workgroups of the
     # 128x128 engine tile at these shapes); the n-contiguous layout only exists for M <= 64
     if M > 512 or (M > 64 and (tb != 0 or K % 8 != 0)):
+        if pos is not None or split_ws is not None:
+            raise L.LvtError("gemm_small: M=%d, tb=%d, K=%d is served by the tile engine, which has neither a device-side "
+                             "cursor nor caller-owned split-K scratch (decode groups are limited to 512 rows)" % (M, tb, K))
         return gemm(A, B, C_out, M, N, K, ta=0, tb=tb, lda=lda, ldb=ldb, ldc=ldc, batch_inner=batch, sB=(0, sB),
                     sC=(0, sC), alpha=alpha, flags=flags, bias=bias, res=res, ldr=ldr)
     splits = _smallm_splits(N, K) if (tb == 0 and batch == 1 and N % 4 == 0) else 1
@@ -72,13 +76,14 @@ def gemm_small(A, B, C_out, M, N, K, tb=0, lda=None, ldb=None, ldc=None, batch=1
         L.check(lib.lvt_gemm_smallm_splitk_f32(M, N, K, splits, L.ptr(A), lda if lda is not None else K, L.ptr(B),
                                                ldb if ldb is not None else K, L.ptr(C_out), ldc if ldc is not None else N,
                                                alpha, flags, L.ptr(bias), L.ptr(res),
-                                               ldr if ldr else (ldc if ldc is not None else N), L.ptr(ws), nws,
-                                               L.stream_ptr()), "lvt_gemm_smallm_splitk_f32")
+                                               ldr if ldr else (ldc if ldc is not None else N), L.ptr(pos), c_pos, r_pos,
+                                               L.ptr(ws), nws, L.stream_ptr()), "lvt_gemm_smallm_splitk_f32")
         return C_out
     L.check(L.lib().lvt_gemm_smallm_f32(M, N, K, tb, L.ptr(A), lda if lda is not None else K, L.ptr(B),
                                         ldb if ldb is not None else (K if tb == 0 else N), L.ptr(C_out),
                                         ldc if ldc is not None else N, batch, sB, sC, alpha, flags, L.ptr(bias),
-                                        L.ptr(res), ldr if ldr else (ldc if ldc is not None else N), L.stream_ptr()),
+                                        L.ptr(res), ldr if ldr else (ldc if ldc is not None else N), L.ptr(pos), c_pos,
+                                        r_pos, L.stream_ptr()),
             "lvt_gemm_smallm_f32")
     return C_out
 

@@ -135,24 +135,46 @@ def xent_bwd(logits, target, tstride_b, tstride_pos, P, ignore, lse, count, gout
     return dl
 
 
-def attn_decode(q, Kc, Vc, H, qi, temper, dt, dh, dw, block, ldq=None):
+def attn_decode(q, Kc, Vc, H, qi, temper, dt, dh, dw, block, ldq=None, pos=None, q_pos=0):
     """q: B rows of H*da floats (row stride ldq, default contiguous); Kc/Vc (B, S, H*da) caches -> o (B, H*da) for
-    query position qi over keys 0..qi."""
-    L.require(Kc, Vc, dt, dh, dw)
+    query position qi over keys 0..qi.  With `pos` (int32 device scalar) the position is read on the device and the
+    query rows start q_pos * pos elements after `q`."""
+    L.require(Kc, Vc, dt, dh, dw, pos)
     B, S, hd = Kc.shape
     o = torch.empty(B, hd, dtype=torch.float32, device=Kc.device)
     L.check(L.lib().lvt_attn_decode(C.c_void_p(q.data_ptr()), ldq if ldq is not None else hd, L.ptr(Kc), L.ptr(Vc), B, H, S, hd // H, qi, temper, L.ptr(dt), L.ptr(dh),
-                                    L.ptr(dw), block[0], block[1], block[2], L.ptr(o), L.stream_ptr()),
+                                    L.ptr(dw), block[0], block[1], block[2], L.ptr(o), L.ptr(pos), q_pos, L.stream_ptr()),
             "lvt_attn_decode")
     return o
 
 
-def sample_categorical(logits, temp, u, out, out_stride=1, want_probs=False):
+def sample_categorical(logits, temp, u, out, out_stride=1, want_probs=False, pos=None, u_pos=0):
     """Draw one code per row of `logits` (rows, V) with the uniforms `u` (rows,); the int64 codes go to
-    out.data_ptr() + row * out_stride (elements).  Returns the probabilities when asked for."""
-    L.require(logits, u)
+    out.data_ptr() + row * out_stride (elements).  Returns the probabilities when asked for.
+    `pos` (int32 device scalar): the uniforms are read u_pos * pos elements after `u`."""
+    L.require(logits, pos)
     rows, V = logits.shape
     probs = torch.empty(rows, V, dtype=torch.float32, device=logits.device) if want_probs else None
-    L.check(L.lib().lvt_sample_categorical(L.ptr(logits), rows, V, float(temp), L.ptr(u), C.c_void_p(out.data_ptr()),
-                                           out_stride, L.ptr(probs), L.stream_ptr()), "lvt_sample_categorical")
+    L.check(L.lib().lvt_sample_categorical(L.ptr(logits), rows, V, float(temp), C.c_void_p(u.data_ptr()), C.c_void_p(out.data_ptr()),
+                                           out_stride, L.ptr(probs), L.ptr(pos), u_pos, L.stream_ptr()), "lvt_sample_categorical")
     return probs
+
+
+def decode_gather_codes(codes_ext, nb, pos):
+    """codes_ext (rows, S+1) int64, nb (S, taps) int64, pos int32 device scalar -> (rows, taps) codes of the causal
+    neighbours of the current position."""
+    L.require(codes_ext, nb, pos)
+    rows, S1 = codes_ext.shape
+    taps = nb.shape[1]
+    out = torch.empty(rows, taps, dtype=torch.int64, device=codes_ext.device)
+    L.check(L.lib().lvt_decode_gather_codes(L.ptr(codes_ext), L.ptr(nb), L.ptr(pos), rows, S1, taps, L.ptr(out),
+                                            L.stream_ptr()), "lvt_decode_gather_codes")
+    return out
+
+
+def decode_commit(codes_ext, pos, drawn=None):
+    """codes_ext[:, pos] = drawn (rows,) when given; pos += 1 (both on the device, one launch)."""
+    L.require(codes_ext, pos, drawn)
+    rows, S1 = codes_ext.shape
+    L.check(L.lib().lvt_decode_commit(L.ptr(drawn), rows, S1, L.ptr(codes_ext), L.ptr(pos), L.stream_ptr()),
+            "lvt_decode_commit")

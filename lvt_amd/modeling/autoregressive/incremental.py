@@ -6,8 +6,18 @@ strictly causal (MaskedConv3d) and every attention layer is causally masked, the
 depends only on tokens < i, so token i can be computed alone against cached keys / values of the earlier
 tokens: S single-token steps per slice, the same arithmetic per row (the masked columns of the full pass
 carry exactly zero probability).  `tests/test_gpu_sampling.py` checks step(i) against row i of the full pass.
+
+The position being decoded lives in DEVICE memory (`IncrementalDecoder.pos`, one int32): every kernel of a step
+that addresses by position (neighbour gather, the row of the K/V caches written by the q/k/v product, the residual
+row of the front end, the number of keys of the decode attention, the write-back of the drawn codes) reads it
+there, and the last launch of a step increments it.  The launch arguments of a step are therefore the same for
+every position, and ONE captured hipGraph per group of videos (two when a slice mixes primed and generated
+positions) is replayed for all S positions of all slices -- not one graph per position.  Everything a captured
+launch touches is owned by the decoder object of its group and allocated before the capture; nothing in a graph
+points into `binding.workspace()` (which refuses to serve a capturing stream).
 """
 import math
+import os
 
 import torch
 
@@ -32,6 +42,7 @@ class IncrementalDecoder:
         # neighbours point at; `self.sl` is the (b, nc, t, h, w) view callers write drawn codes into
         self.sl_ext = torch.full((b, self.nc, self.S + 1), -1, dtype=torch.int64, device=dev)
         self.sl = self.sl_ext[:, :, :self.S].view(b, self.nc, t, h, w)
+        self.pos = torch.zeros(1, dtype=torch.int32, device=dev)       # the device-side cursor (module docstring)
         # single-position causal conv: x_i = sum over the taps that can see data of W_tap . emb[neighbour_tap(i)]
         kt, kh, kw = cw.shape[2:]
         self.taps = [(jt, jh, jw) for jt in range(kt) for jh in range(kh) for jw in range(kw)
@@ -91,17 +102,18 @@ class IncrementalDecoder:
         G.gemm(zl_tok, self.dec.linear_projector.weight, self.base, self.b * self.S, self.d, self.d)
         self.dec.positional_encoder.add_tokens_(self.base, t, h, w)
 
-    def _front_row(self, i):
-        """x_i = causal_conv(sum_k Emb_k(slice))[i] + pos[i] + proj(zl)[i]  -> (b, d): the codes of the causal
-        neighbours of position i are gathered (integer plumbing), embedded and contracted with the packed taps."""
+    def _front_row(self):
+        """x_i = causal_conv(sum_k Emb_k(slice))[i] + pos[i] + proj(zl)[i]  -> (b, d) for i = the device cursor: the codes
+        of the causal neighbours of position i are gathered (integer plumbing), embedded and contracted with the packed taps."""
         b, nc, nt = self.b, self.nc, len(self.taps)
         nv = self.tables.shape[0] // nc
-        codes = self.sl_ext.index_select(2, self.nb[i])                              # (b, nc, taps), -1 = outside
+        codes = tx.decode_gather_codes(self.sl_ext.view(b * nc, self.S + 1), self.nb, self.pos)   # (b*nc, taps), -1 = outside
         a = tx.embbag_fwd(codes, nc * nt, nt, b * nt, [k * nt for k in range(nc)], [k * nv for k in range(nc)],
                           self.tables, self.de)                                      # (b*taps, de) == (b, taps*de)
         x = torch.empty(b, self.d, dtype=torch.float32, device=a.device)
         G.gemm_small(a, self.wfront, x, b, self.d, nt * self.de, flags=L.EPI_BIAS | L.EPI_RESIDUAL,
-                     bias=self.dec.conv.conv.bias, res=self.base.view(-1)[i * self.d:], ldr=self.S * self.d, split_ws=self._split_ws)
+                     bias=self.dec.conv.conv.bias, res=self.base, ldr=self.S * self.d, split_ws=self._split_ws,
+                     pos=self.pos, r_pos=self.d)
         return x
 
     def _partials(self, which, splits):
@@ -120,13 +132,21 @@ class IncrementalDecoder:
         return buf
 
     def step(self, sl, i):
-        """Hidden state y_i (b, d) of token i given the codes of tokens < i in `sl`; fills the caches at i."""
+        """Hidden state y_i (b, d) of token i given the codes of tokens < i in `sl`; fills the caches at i.
+        (Eager entry: points the device cursor at i; the cursor is not advanced.)"""
+        if not 0 <= i < self.S:
+            raise L.LvtError("IncrementalDecoder.step: position %d outside the slice of %d tokens" % (i, self.S))
+        if sl.data_ptr() != self.sl.data_ptr():
+            self.sl.copy_(sl)
+        self.pos.fill_(i)
+        return self.step_at_cursor()
+
+    def step_at_cursor(self):
+        """y (b, d) of the token the device cursor points at; every position-dependent address is formed on the device."""
         b, d, S = self.b, self.d, self.S
         na, da = self.na, self.da
         hd = na * da
-        if sl.data_ptr() != self.sl.data_ptr():
-            self.sl.copy_(sl)
-        x = self._front_row(i)
+        x = self._front_row()
         dev = x.device
         # Both products of a layer that end in a residual (output projection, FFN down-projection) are followed by a
         # LayerNorm: they run split-K (one 128-deep chunk per workgroup, 4x the workgroups) and leave raw partial
@@ -143,9 +163,10 @@ class IncrementalDecoder:
                                              bias=pend[2], res=pend[3])
             # q_i / k_i / v_i of every sample in one launch: output row i of slot z, row stride S*hd, slot stride b*S*hd
             qkv = self.qkv[li]
-            G.gemm_small(xn, self.wqkv[li], qkv.view(-1)[i * hd:], b, hd, d, ldc=S * hd, batch=3, sB=hd * d, sC=b * S * hd, split_ws=self._split_ws)
-            o = tx.attn_decode(qkv.view(-1)[i * hd:], self.kc[li], self.vc[li], na, i, math.sqrt(da), layer.dt_bank,
-                               layer.dh_bank, layer.dw_bank, layer.block_size, ldq=S * hd)
+            G.gemm_small(xn, self.wqkv[li], qkv, b, hd, d, ldc=S * hd, batch=3, sB=hd * d, sC=b * S * hd,
+                         split_ws=self._split_ws, pos=self.pos, c_pos=hd)
+            o = tx.attn_decode(qkv, self.kc[li], self.vc[li], na, 0, math.sqrt(da), layer.dt_bank,
+                               layer.dh_bank, layer.dw_bank, layer.block_size, ldq=S * hd, pos=self.pos, q_pos=hd)
             if hd % KS == 0 and d % 4 == 0:
                 ws = G.gemm_small_partial(o, m.proj.weight, b, d, hd, hd // KS, self._partials("proj", hd // KS))
                 y1, fn = G.splitsum_layernorm(ws, hd // KS, b, d, f[0].weight, f[0].bias, res=x)
@@ -167,19 +188,22 @@ class IncrementalDecoder:
 
 
 class GraphedSliceSampler:
-    """Per-position hipGraphs of (decoder step + channel-predictor draw + write-back of the drawn codes).
+    """One decoding step (decoder step + channel-predictor draw + write-back of the drawn codes + cursor increment) as a
+    replayed hipGraph.
 
-    One decoding step is ~110 tiny launches (M = batch rows); eagerly it is bound by host launch overhead
-    (~3.7 ms/step measured at 16 videos).  Every position of a slice runs the same launch sequence on the same
-    buffers, so the sequence is captured once per position (first slice: eager + capture) and replayed for
-    every later slice / video batch."""
+    A step is ~110 tiny launches (M = batch rows); eagerly it is bound by host launch overhead (~3.7 ms/step measured at
+    16 videos).  Because the position is a device-side cursor the launch sequence AND its arguments are identical for
+    every position: the first step of each flavour (drawing / cache-filling only) runs eagerly and is then captured once;
+    every later position of every slice replays that graph.  LVT_DECODE_GRAPHS=0 keeps every step eager."""
 
     def __init__(self, vt_module, b, thw, temp=1.0):
         self.vt, self.b, self.thw, self.temp = vt_module, b, thw, temp
         self.dec = None
         self.sl = None
         self.graphs = {}
-        self.enabled = True
+        self.uniforms = None
+        self.enabled = os.environ.get("LVT_DECODE_GRAPHS", "1") != "0"
+        self._next = 0                                      # host mirror of the device cursor (argument checking only)
 
     def begin_slice(self, zl_tok, sl):
         if self.dec is None:
@@ -189,31 +213,33 @@ class GraphedSliceSampler:
             self.dec.begin_slice(zl_tok)
         self.vt.ch_predictor.prepare_decode()
         self.sl.copy_(sl)
+        self.dec.pos.zero_()
+        self._next = 0
+        # every uniform of the slice in one draw (S, nc, b); the steps index it with the device cursor
+        if self.uniforms is None:
+            self.uniforms = torch.empty(self.dec.S, self.dec.nc, self.b, dtype=torch.float32, device=self.sl.device)
+        self.uniforms.uniform_()
 
-    def _body(self, pos, sample):
-        y = self.dec.step(self.sl, pos)
-        if sample:
-            t, h, w = self.thw
-            ti, rem = divmod(pos, h * w)
-            hi, wi = divmod(rem, w)
-            self.sl[:, :, ti, hi, wi] = self.vt.ch_predictor.sample_from_rows(y, self.temp)
+    def _body(self, sample):
+        dec = self.dec
+        y = dec.step_at_cursor()
+        drawn = self.vt.ch_predictor.sample_from_rows(y, self.temp, uniforms=self.uniforms, pos=dec.pos).reshape(-1) if sample else None     # (b*nc,)
+        tx.decode_commit(dec.sl_ext.view(dec.b * dec.nc, dec.S + 1), dec.pos, drawn)
 
     def step(self, pos, sample):
-        key = (pos, bool(sample))
-        g = self.graphs.get(key)
+        """Decode position `pos` (must be the next one: positions of a slice are visited in order)."""
+        if pos != self._next:
+            raise L.LvtError("GraphedSliceSampler.step(%d): the device cursor is at %d" % (pos, self._next))
+        self._next += 1
+        g = self.graphs.get(bool(sample))
         if g is not None:
             g.replay()
             return
-        self._body(pos, sample)                           # eager (also the warm-up the capture needs)
+        self._body(sample)                                # eager (also the warm-up the capture needs)
         if not self.enabled:
             return
-        try:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._body(pos, sample)
-            self.graphs[key] = g
-        except Exception:                                 # capture unsupported in this environment: stay eager
-            self.enabled = False
-            self.graphs.clear()
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):                         # recorded, not executed: the cursor keeps its value
+            self._body(sample)
+        self.graphs[bool(sample)] = g

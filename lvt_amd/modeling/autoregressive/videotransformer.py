@@ -362,15 +362,19 @@ class ChannelPredictor(nn.Module):
         for k in range(1, self.nc):
             self._ut[k].copy_(self.U[k].weight.detach()[:, d:d + k * self.nv].t())
 
-    def sample_from_rows(self, rows, temp=1.0, forced_codes=None, return_probs=False):
-        """rows (b, d): decoder hidden state of ONE position per sample -> codes (b, nc)."""
+    def sample_from_rows(self, rows, temp=1.0, forced_codes=None, return_probs=False, uniforms=None, pos=None):
+        """rows (b, d): decoder hidden state of ONE position per sample -> codes (b, nc).
+        `uniforms` (P, nc, b) with the int32 device cursor `pos`: the draws of position pos[0] come from uniforms[pos[0]]
+        (a table filled once per slice: the decode graphs contain no random-number generator)."""
         b, d = rows.shape
         cached = getattr(self, "_ut", None)
         y, _, _ = ew.layernorm_fwd(rows, self.layer_norm.weight, self.layer_norm.bias, save_stats=False)
         codes = torch.zeros(b, self.nc, 1, dtype=torch.int64, device=rows.device)
         probs = []
         # one uniform per (sample, channel); a draw is then a pure function of (logits, u) -- lvt_sample_categorical
-        u = torch.rand(self.nc, b, device=rows.device) if forced_codes is None else None
+        u = None
+        if forced_codes is None and uniforms is None:
+            u = torch.rand(self.nc, b, device=rows.device)
         for k in range(self.nc):
             uw, pw = self.U[k].weight, self.P[k].weight
             res = None
@@ -384,7 +388,11 @@ class ChannelPredictor(nn.Module):
             G.gemm_small(u_, pw, o, b, self.nv, d, flags=L.EPI_BIAS, bias=self.P[k].bias)
             if forced_codes is None:
                 # writes codes[:, k, 0] (element stride nc between samples)
-                pr = tx.sample_categorical(o, temp, u[k], codes.view(-1)[k:], self.nc, want_probs=return_probs)
+                if uniforms is not None:
+                    pr = tx.sample_categorical(o, temp, uniforms.view(-1)[k * b:], codes.view(-1)[k:], self.nc,
+                                               want_probs=return_probs, pos=pos, u_pos=self.nc * b)
+                else:
+                    pr = tx.sample_categorical(o, temp, u[k], codes.view(-1)[k:], self.nc, want_probs=return_probs)
                 if return_probs:
                     probs.append(pr)
             else:

@@ -163,3 +163,70 @@ def test_sample_categorical_matches_oracle_rule():
     assert bool(((got - want).abs() <= 1).all())
     assert bool((out[:, [0, 1, 3]] == -1).all())
     assert rel_err(pr, prob.float()) < 1e-5
+
+
+def test_graph_replay_equals_eager_steps(vt, monkeypatch):
+    """One captured hipGraph per group replayed for every position (device-side cursor) == the same steps launched
+    eagerly, bit for bit: two generated frames (512 positions, the second frame replays the graph from position 0)."""
+    codes = torch.stack([seeded.seeded_codes("e%d" % i, (16, 4, 16, 16), 21) for i in range(3)])
+    with torch.no_grad():
+        video = codes.transpose(1, 2).contiguous().to(DEV)
+        video[:, :, 14:] = 0
+        vt._samplers = {}
+        torch.manual_seed(5)
+        graphed = vt.sample_video(video, n_prime=14, temp=1e-4)
+        (_, _, smp, _), = vt._samplers[(3, 1, 16, 16, 1e-4)]
+        assert set(smp.graphs) == {True} and smp._next == 256          # ONE graph served 2 x 256 positions
+        monkeypatch.setenv("LVT_DECODE_GRAPHS", "0")
+        vt._samplers = {}
+        torch.manual_seed(5)
+        eager = vt.sample_video(video, n_prime=14, temp=1e-4)
+        (_, _, smp, _), = vt._samplers[(3, 1, 16, 16, 1e-4)]
+        assert not smp.graphs
+        vt._samplers = {}
+    print("graph replay vs eager: %d codes differ" % int((graphed != eager).sum()))
+    assert torch.equal(graphed, eager)
+
+
+def test_workspace_refuses_capture():
+    """The grow-and-replace scratch of binding.workspace() must never be recorded into a graph."""
+    from lvt_amd.hip import binding as L
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with pytest.raises(L.LvtError, match="capture"):
+        with torch.cuda.graph(g):
+            L.workspace(1 << 20, torch.device(DEV), "gemm")
+
+
+@pytest.mark.parametrize("ngroups", [1, 3])
+def test_groups_of_256_videos(vt, ngroups):
+    """The bench configuration of the generation leg (groups of 256 videos, three groups replaying their graphs
+    concurrently on three streams) for one generated frame: concurrent == the groups one after the other on one stream,
+    bit for bit; every code in range; primed frames untouched."""
+    import lvt_amd.modeling.meta_arch.vt as vtmod
+    B = 256 * ngroups
+    base = torch.stack([seeded.seeded_codes("w%d" % i, (16, 4, 16, 16), 30 + i) for i in range(16)])
+    codes = base[torch.arange(B) % 16].roll(1, 0).contiguous()
+    with torch.no_grad():
+        video = codes.transpose(1, 2).contiguous().to(DEV)
+        video[:, :, 15:] = 0
+        vt._samplers = {}
+        torch.manual_seed(3)
+        conc = vt.sample_video(video, n_prime=15, temp=1e-4)
+        groups = vt._samplers[(B, 1, 16, 16, 1e-4)]
+        assert len(groups) == ngroups and all(set(g[2].graphs) == {True} for g in groups)
+        assert torch.equal(conc[:, :, :15].cpu(), codes.transpose(1, 2)[:, :, :15])
+        assert 0 <= int(conc.min()) and int(conc.max()) < 512
+        # identical inputs 16 videos apart inside a group: same arithmetic per row, only arg-max near-ties (decided by the
+        # per-row uniforms) may differ
+        assert float((conc[0:16] != conc[16:32]).float().mean()) < 0.01
+        vtmod.DECODE_GROUP_STREAMS = False
+        try:
+            vt._samplers = {}
+            torch.manual_seed(3)
+            serial = vt.sample_video(video, n_prime=15, temp=1e-4)
+        finally:
+            vtmod.DECODE_GROUP_STREAMS = True
+            vt._samplers = {}
+    print("%d groups of 256: serial vs concurrent %d codes differ" % (ngroups, int((serial != conc).sum())))
+    assert torch.equal(serial, conc)
