@@ -14,9 +14,10 @@ Semantics are those of torch DDP, with no call required from the training loop
   * EVERY backward averages the gradients (a DDP without `no_sync`).  With gradient accumulation the
     bucket holds avg(g1) + local g2 before the second reduction and avg(g1) + avg(g2) after it.
   * the reduction is joined automatically (a) before any `torch.optim.Optimizer.step()` (global
-    step pre-hook), (b) at the next forward of the owning meta-architecture, (c) when a gradient
-    arrives for a bucket whose previous reduction is still in flight, and (d) by an explicit
-    `wait()` for callers that read `.grad` themselves.
+    step pre-hook), (b) at the next forward of the owning meta-architecture, and (c) by an explicit
+    `wait()` for callers that read `.grad` themselves.  A gradient that arrives for a bucket whose
+    previous reduction is still in flight (two `backward()` calls with none of (a)-(c) in between) is an
+    ERROR, as it is in torch DDP: autograd has by then accumulated into memory the collective is reading.
   * `optimizer.zero_grad(set_to_none=True)` (torch's default) detaches `.grad` from the bucket; the
     next gradient is then moved into the slot once and `.grad` re-pointed -- still no copy-back.
     `zero_()` restores the zero-copy path and is what `solver/fused.py` optimizers do.
@@ -59,6 +60,7 @@ class BucketedGradReducer:
         if cur:
             self._make_bucket(cur)
         self._comm_stream = None
+        self.enabled = True        # False: gradients stay local (bench.py times a step without communication)
         # gloo (CPU unit tests, and the 2-ranks-on-one-GPU tests) has no AVG: SUM + one division there
         self._avg = self.world > 1 and dist.get_backend(group) == "nccl"
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
@@ -120,16 +122,24 @@ class BucketedGradReducer:
                     p.grad = v
         return True
 
+    @property
+    def bytes_per_backward(self):
+        """Bytes every rank contributes to the all-reduces of one backward pass."""
+        return sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)
+
     def _on_grad(self, p):
-        if self.world == 1:
+        if self.world == 1 or not self.enabled:
             return
         bi, view = self._slot[p]
         b = self.buckets[bi]
         if b["work"] is not None:
-            # a second backward without a join in between: finish the reduction in flight first (p.grad, if it
-            # is the view, was accumulated while the all-reduce was reading it -- DDP forbids that too; the
-            # built-in joins (a)/(b) make sure a training loop never gets here)
-            self._join(b)
+            # a second backward without a join in between: autograd has already accumulated the new gradient in place
+            # into the bucket view the all-reduce in flight is reading (and, on the SUM path, the join's division would
+            # scale the fresh local gradient too) -- the result cannot be repaired here, so fail as torch DDP does
+            raise RuntimeError(
+                "BucketedGradReducer: a gradient arrived for a bucket whose all-reduce from the previous backward() is still "
+                "in flight.  Join it first -- optimizer.step(), the meta-architecture's forward / finish_gradient_sync(), or "
+                "reducer.wait() -- before calling backward() again (torch DDP has the same rule)")
         g = p.grad
         if g.data_ptr() != view.data_ptr():
             view.copy_(g)                      # .grad was detached by zero_grad(set_to_none=True)

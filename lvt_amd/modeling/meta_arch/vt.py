@@ -45,6 +45,40 @@ class _XentFn(torch.autograd.Function):
 DECODE_GROUP_STREAMS = os.environ.get("LVT_DECODE_GROUP_STREAMS", "1") != "0"      # "0": groups one after the other
 MAX_CONCURRENT_GROUPS = 3
 DECODE_GROUP_ROWS = 256          # videos per decode group (rows of every decode-step launch)
+# The host issues a decode step (one graph launch per group) ~50x faster than the GPU executes it and nothing in the
+# sampling loop needs a result on the host, so unchecked it would queue every step of every remaining slice (thousands of
+# graph launches, ~10^6 AQL packets across streams that wait on each other) ahead of the device.  The loop therefore never
+# runs more than this many positions ahead of the slowest group (event per window, host waits on the window before last).
+DECODE_MAX_STEPS_AHEAD = int(os.environ.get("LVT_DECODE_MAX_STEPS_AHEAD", "64"))
+
+
+class _RunAhead:
+    """Bounds how far the host may run ahead of the streams it feeds: tick() after every position; every `window`
+    positions an event is recorded on each stream and the host waits for the events of the window before last."""
+
+    def __init__(self, streams, max_ahead):
+        self.streams, self.window = streams, max(1, max_ahead // 2)
+        self.count, self.pending = 0, []
+
+    def tick(self):
+        self.count += 1
+        if self.count % self.window:
+            return
+        evs = []
+        for s in self.streams:
+            e = torch.cuda.Event()
+            e.record(s)
+            evs.append(e)
+        self.pending.append(evs)
+        if len(self.pending) > 1:
+            for e in self.pending.pop(0):
+                e.synchronize()
+
+    def drain(self):
+        for evs in self.pending:
+            for e in evs:
+                e.synchronize()
+        self.pending = []
 
 @META_ARCH_REGISTRY.register()
 class VideoTransformerModel(nn.Module):
@@ -212,8 +246,10 @@ class VideoTransformerModel(nn.Module):
                 S = t * h * w
                 if len(groups) == 1:
                     sampler.begin_slice(zl, sl)
+                    ahead = _RunAhead([torch.cuda.current_stream(video.device)], DECODE_MAX_STEPS_AHEAD)
                     for pos in range(S):
                         sampler.step(pos, sample=not flat[pos])     # primed pixels only fill the K/V caches
+                        ahead.tick()
                     sl = sampler.sl.clone()
                 else:
                     main = torch.cuda.current_stream(video.device)
@@ -231,10 +267,12 @@ class VideoTransformerModel(nn.Module):
                             for _, _, _, other in wave:
                                 if other is not stream:
                                     stream.wait_stream(other)
+                        ahead = _RunAhead([g[3] for g in wave], DECODE_MAX_STEPS_AHEAD)
                         for pos in range(S):
                             for g0, g1, smp, stream in wave:
                                 with torch.cuda.stream(stream):
                                     smp.step(pos, sample=not flat[pos])
+                            ahead.tick()
                         for g0, g1, smp, stream in wave:
                             with torch.cuda.stream(stream):
                                 sl[g0:g1] = smp.sl

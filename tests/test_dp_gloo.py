@@ -153,3 +153,26 @@ def test_training_sampler_shards_are_disjoint_and_cover():
     full = list(itertools.islice(iter(TrainingSampler(10, seed=7, rank=0, world_size=1)), 20))
     assert a == full[0::2] and b == full[1::2]
     assert sorted(full[:10]) == list(range(10))
+
+
+def _second_backward_case(rank, world):
+    from lvt_amd.engine.grad_reducer import BucketedGradReducer
+    torch.manual_seed(3)
+    net = torch.nn.Linear(5, 4)
+    red = BucketedGradReducer(net.parameters(), bucket_bytes=1 << 20)
+    x = torch.randn(2, 5, generator=torch.Generator().manual_seed(rank))
+    net(x).sum().backward()                      # launches the all-reduce of the single bucket
+    try:
+        net(x).sum().backward()                  # no join in between
+        raised = False
+    except RuntimeError as e:
+        raised = "still in flight" in str(e)
+    red.wait()
+    red.remove()
+    return raised
+
+
+def test_second_backward_without_join_raises():
+    """a gradient landing in a bucket whose all-reduce is in flight must fail loudly, not be joined silently."""
+    res = _run(_second_backward_case)
+    assert res[0] is True and res[1] is True
