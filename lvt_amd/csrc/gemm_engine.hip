@@ -92,18 +92,7 @@ template <int ROWS> struct HPlane { static constexpr int SIZE = ROWS * HLD + (RO
 // 4 consecutive k of one row -> one 8-byte store per plane
 template <int ROWS> __device__ __forceinline__ void store_split_k(unsigned short *lds, int row, int k4, const float4 v) {
     uint2 p1, p2, p3;
-#if defined(LVT_EXP_PART) && (LVT_EXP_PART & 2)
-    p1.x = __float_as_uint(v.x); p1.y = __float_as_uint(v.y); p2.x = __float_as_uint(v.z); p2.y = __float_as_uint(v.w);
-    p3.x = p1.x; p3.y = p2.y;                      // timing experiment: no split arithmetic
-#else
     split3(v, p1, p2, p3);
-#endif
-#if defined(LVT_EXP_PART) && (LVT_EXP_PART & 4)
-    if (lds == nullptr) {                          // timing experiment: split computed, LDS stores skipped
-        asm volatile("" :: "v"(p1.x), "v"(p1.y), "v"(p2.x), "v"(p2.y), "v"(p3.x), "v"(p3.y));
-        return;
-    }
-#endif
     unsigned short *d = lds + hrow<ROWS>(row) + k4;
     *reinterpret_cast<uint2 *>(d) = p1;
     *reinterpret_cast<uint2 *>(d + HPlane<ROWS>::SIZE) = p2;
@@ -203,11 +192,7 @@ template <int BM, int MATH> struct ALoader<A_KPLAIN, BM, MATH> : AKLoaderBase<A_
     }
     __device__ __forceinline__ void fetch(int kend) {
         const bool kok = kcur < kend;
-#ifdef LVT_EXP_L1
-        const long long koff = (kbase + kin) & 31;     // timing experiment: same loads, but every k-tile re-reads the first one (L1 hits)
-#else
         const long long koff = kbase + kin;
-#endif
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i)
             this->v[i] = (kok && rowok[i]) ? ldg4(rowp[i] + koff) : zero4();
@@ -485,11 +470,7 @@ template <int BN, int MATH> struct BLoader<B_KPLAIN, BN, MATH> : BKLoaderBase<BN
     }
     __device__ __forceinline__ void fetch(int kend) {
         const bool kok = kcur < kend;
-#ifdef LVT_EXP_L1
-        const long long koff = (kbase + kin) & 31;
-#else
         const long long koff = kbase + kin;
-#endif
 #pragma unroll
         for (int i = 0; i < Base::ITERS; ++i)
             this->v[i] = (kok && rowok[i]) ? ldg4(rowp[i] + koff) : zero4();
@@ -812,12 +793,6 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
     const float *A = tc.A, *B = tc.B;
     const long long coff = tc.coff;
 
-#ifdef LVT_EXP_STAGGER
-    // experiment: the two workgroups resident on a CU start half an iteration apart (odd hardware wave slots sleep)
-    if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1) {
-        for (int i_ = 0; i_ < LVT_EXP_STAGGER; ++i_) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
     AL al; BL bl;
     al.init(p, tid, m0, A, cls);
     bl.init(p, tid, n0, B, cls);
@@ -845,27 +820,9 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
     const float *Ard = As + half * LDA + wm * (TM * 32) + l31;
     const float *Brd = Bs + half * LDB + wn * (TN * 32) + l31;
 
-#if defined(LVT_EXP_SKIP) || defined(LVT_EXP_PART)
-    int exp_it = 0;
-#endif
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool has_next = k0 + BK < kend;
-#ifdef LVT_EXP_SKIP
-        // timing experiment only (results are wrong): stage the A / B side on every 8th k-tile only
-        ++exp_it;
-#ifndef LVT_EXP_MA
-#define LVT_EXP_MA 7
-#define LVT_EXP_MB 7
-#endif
-        const bool exp_a = !(LVT_EXP_SKIP & 1) || (exp_it & LVT_EXP_MA) == 0, exp_b = !(LVT_EXP_SKIP & 2) || (exp_it & LVT_EXP_MB) == 0;
-        if (has_next) { if (exp_a) al.fetch(kend); if (exp_b) bl.fetch(kend); }
-#elif defined(LVT_EXP_PART)
-        ++exp_it;
-        const bool exp_full = (exp_it & 7) == 0;
-        if (has_next && (!(LVT_EXP_PART & 1) || exp_full)) { al.fetch(kend); bl.fetch(kend); }
-#else
         if (has_next) { al.fetch(kend); bl.fetch(kend); }
-#endif
         if (MATH == 0) {
             // operand fragments are double-buffered in registers: the ds_reads of step kk+2 are in flight
             // while the MFMAs of step kk issue, so the LDS latency is not exposed once per step
@@ -926,23 +883,10 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
         }
         __syncthreads();
         if (has_next) {
-#ifdef LVT_EXP_SKIP
-            if (MATH == 0) { al.store(As); bl.store(Bs); }
-            else { if (exp_a) al.store_split(Ah); if (exp_b) bl.store_split(Bh); }
-#elif defined(LVT_EXP_PART)
-            if (MATH == 0) { al.store(As); bl.store(Bs); }
-            else if ((LVT_EXP_PART & 4) && !exp_full) { al.store_split(nullptr); bl.store_split(nullptr); }
-            else { al.store_split(Ah); bl.store_split(Bh); }
-#else
             if (MATH == 0) { al.store(As); bl.store(Bs); }
             else { al.store_split(Ah); bl.store_split(Bh); }
-#endif
         }
-#if defined(LVT_EXP_PART) && (LVT_EXP_PART & 8)
-        if (exp_full) __syncthreads();
-#else
         __syncthreads();
-#endif
     }
 
     if constexpr (COLSUM) {

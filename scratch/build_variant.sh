@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../lvt_amd/csrc"
 mkdir -p ../../scratch/variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -I../../include -I. -Wno-unused-result $2 -c gemm_engine.hip -o ../../scratch/variants/ge_$1.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wno-unused-result $2 -c gemm_engine.hip -o ../../scratch/variants/ge_$1.o
 OTHERS=$(ls *.o | grep -v gemm_engine.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OTHERS ../../scratch/variants/ge_$1.o -o ../../scratch/variants/lib_$1.so
 rm ../../scratch/variants/ge_$1.o
