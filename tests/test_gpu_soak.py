@@ -13,17 +13,35 @@ sys.path.insert(0, ROOT)
 
 
 def test_vqvae_learns_a_fixed_batch():
-    import bench
+    from lvt_amd.config import get_cfg
+    from lvt_amd.modeling import build_model
+    from lvt_amd.utils.events import EventStorage
     dev = "cuda:0"
-    cfg, model = bench.build_vqvae(dev, 1234)
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs/vqvae/PR-DVQVAE2.yaml"))
+    cfg.MODEL.DEVICE = dev
+    cfg.OUTPUT_DIR = "/tmp/lvt_soak_out"
+    torch.manual_seed(1234)
+    model = build_model(cfg)
+    model.train()
     optimizers, _ = model.configure_optimizers_and_checkpointers()
+
+    def vqvae_step(i):
+        with EventStorage(i):
+            losses = model(data, mode="supervised")
+        sum(losses.values()).backward()
+        for o in optimizers:
+            o["optimizer"].step()
+        for o in optimizers:
+            o["optimizer"].zero_grad()
+        return losses
     rng = np.random.RandomState(0)
     base = rng.rand(8, 1, 3, 8, 8).astype(np.float32)                      # low-frequency (learnable) clips
     clips = np.repeat(np.repeat(np.repeat(base, 16, 1), 8, 3), 8, 4)       # (8, 16, 3, 64, 64) in [0, 1]
     data = [{"image_sequence": clips[i]} for i in range(8)]
     hist, peaks = [], []
     for i in range(251):
-        losses = bench.vqvae_step(model, optimizers, data, i)
+        losses = vqvae_step(i)
         if i % 50 == 0:
             hist.append({k: float(v.detach()) for k, v in losses.items()})
             peaks.append(torch.cuda.max_memory_allocated())
