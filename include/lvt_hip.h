@@ -53,6 +53,10 @@ int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long lon
 #define LVT_EPI_TANH        8   /* tanhf(.)                                                    */
 #define LVT_EPI_MASK       16   /* * (mask[m][n] > 0)   (ReLU backward with the saved output)  */
 #define LVT_EPI_ACCUM      32   /* C += result                                                 */
+#define LVT_EPI_PLANES     64   /* lvt_gemm_f32 only: C is a bf16 image and receives the result as its EXACT 3-way bf16 split
+                                 * (v = p1 + p2 + p3, round-to-nearest-even at every level): plane j of element (m, n) at
+                                 * ((uint16_t *)C)[j*c_plane + z-offset + m*ldc + n]; ldc, sC_*, c_plane count bf16 elements.
+                                 * The operand format of lvt_attn_fwd_planes / lvt_attn_bwd_planes.                          */
 /* causal structure of the batched attention products of a masked layer (M, N, K token positions of one block):          */
 #define LVT_CAUSAL_KMAX   (1 << 8)    /* A(m,k) == 0 for k > m: a tile reduces over k < m0 + 128 only  (dQ = dS K)        */
 #define LVT_CAUSAL_KMIN   (1 << 9)    /* A(m,k) == 0 for k < m: a tile starts its reduction at k = m0  (dV = P^T dO, dK)  */
@@ -84,6 +88,7 @@ typedef struct {
     /* ta == 1 with splits > 1 only (weight gradient dW = dY^T X): when non-NULL receives the M column sums of A
      * (= sum over the K rows of dY: the bias gradient), accumulated from the A tiles the kernel streams anyway. */
     float *a_colsum;
+    long long c_plane;                  /* LVT_EPI_PLANES: distance between the bf16 planes of C (elements)                 */
 } lvt_gemm_desc;
 size_t lvt_gemm_workspace_bytes(const lvt_gemm_desc *d);
 int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t workspace_bytes, void *stream);
@@ -261,6 +266,28 @@ int lvt_attn_softmax_bwd(const float *P, float *dP, int B, int H, int S, float t
 int lvt_attn_fwd(const float *q, const float *k, const float *v, int B, int H, int S, int da, float temper,
                  const float *dt, const float *dh, const float *dw, int bt, int bh, int bw, int masked, float fill,
                  float *P, float *o, void *stream);
+
+/* ---- fused attention on PRE-SPLIT operands (csrc/attention_pipe.hip) ------------------------------------------------
+ * q, k, v (and dO) arrive as the exact 3-way bf16 split written by lvt_gemm_f32 with LVT_EPI_PLANES: operand x, plane j,
+ * element (token row m, column c) at ((uint16_t *)qkv_planes)[x*operand_stride + j*plane_stride + m*(H*da) + c], x = 0 (q),
+ * 1 (k), 2 (v); do_planes has the layout of one operand.  Same arithmetic as lvt_attn_fwd (the planes ARE the fp32 values),
+ * software-pipelined: staging is a copy, transposed operands come from ds_read_b64_tr_b16, the softmax is online per key
+ * chunk beside the MFMAs of the next one.  S == 256, da == 128 and a block geometry with an instantiation
+ * (lvt_attn_planes_supported: (1,16,16) and (4,8,8)).
+ * forward : P (B,H,S,S) and o (B*S, H*da) fp32, as lvt_attn_fwd.
+ * backward: two launches over the saved P -- (A) dS = P o (dO V^T - rowsum(dO o O)) / temper, dQ = dS K and the per-(sample,
+ *           head, query half) bias-bank sums; (B) dV = P^T dO, dK = dS^T Q -- and a fixed-order reduction of the bank sums:
+ *           dq / dk / dv (B*S, H*da) fp32, ddt (H, 2bt-1), ddh (H, 2bh-1), ddw (H, 2bw-1).  Replaces the four batched
+ *           GEMMs + lvt_attn_softmax_bwd of the unfused path (vt_attention.py:59-81 under autograd).  The workspace holds dS. */
+int lvt_attn_planes_supported(int S, int da, int bt, int bh, int bw);
+int lvt_attn_fwd_planes(const void *qkv_planes, long long plane_stride, long long operand_stride, int B, int H, int S, int da,
+                        float temper, const float *dt, const float *dh, const float *dw, int bt, int bh, int bw, int masked,
+                        float fill, float *P, float *o, void *stream);
+size_t lvt_attn_bwd_planes_workspace_bytes(int B, int H, int S, int bt, int bh, int bw);
+int lvt_attn_bwd_planes(const void *qkv_planes, long long plane_stride, long long operand_stride, const void *do_planes,
+                        const float *P, const float *o, int B, int H, int S, int da, float temper, int bt, int bh, int bw,
+                        int masked, float *dq, float *dk, float *dv, float *ddt, float *ddh, float *ddw, void *workspace,
+                        size_t workspace_bytes, void *stream);
 
 /* single-query attention against a token-major K/V cache (incremental sampling: the reference re-runs the
  * whole causal decoder for every generated pixel, vt.py:121-131).  q (B rows of H*da, row stride ldq), o (B, H*da), caches (B, S, H*da);

@@ -41,7 +41,7 @@ struct KParams {
     int M, N, K;
     const float *A; long long lda; int a_kb; long long a_skb;
     const float *B; long long ldb; int b_kb; long long b_skb;
-    float *C; long long ldc;
+    float *C; long long ldc; long long c_plane;
     int batch_inner;
     long long sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
     float alpha; int flags;
@@ -753,9 +753,20 @@ __device__ __forceinline__ void lvt_epilogue_vec(const KParams &p, f32x16 (&acc)
                         const float4 mk = ldg4(p.mask + coff + orow * p.ldm + col);
                         v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
                     }
-                    float4 *cp = reinterpret_cast<float4 *>(p.C + coff + orow * p.ldc + col);
-                    if (flags & LVT_EPI_ACCUM) { const float4 c = *cp; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
-                    *cp = v;
+                    if (flags & LVT_EPI_PLANES) {
+                        // C is a bf16 image: the result leaves as its exact 3-way bf16 split, one plane c_plane elements
+                        // after the other (the operand format of the fused attention kernels, attention_pipe.hip)
+                        uint2 p1, p2, p3;
+                        split3(v, p1, p2, p3);
+                        unsigned short *cp = reinterpret_cast<unsigned short *>(p.C) + coff + orow * p.ldc + col;
+                        *reinterpret_cast<uint2 *>(cp) = p1;
+                        *reinterpret_cast<uint2 *>(cp + p.c_plane) = p2;
+                        *reinterpret_cast<uint2 *>(cp + 2 * p.c_plane) = p3;
+                    } else {
+                        float4 *cp = reinterpret_cast<float4 *>(p.C + coff + orow * p.ldc + col);
+                        if (flags & LVT_EPI_ACCUM) { const float4 c = *cp; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+                        *cp = v;
+                    }
                 }
             }
         }
@@ -1283,7 +1294,7 @@ static void kparams_from_desc(const lvt_gemm_desc *d, KParams &p) {
     p.M = d->M; p.N = d->N; p.K = d->K;
     p.A = d->A; p.lda = d->lda; p.a_kb = d->a_kb > 0 ? d->a_kb : d->K; p.a_skb = d->a_skb;
     p.B = d->B; p.ldb = d->ldb; p.b_kb = d->b_kb > 0 ? d->b_kb : d->K; p.b_skb = d->b_skb;
-    p.C = d->C; p.ldc = d->ldc;
+    p.C = d->C; p.ldc = d->ldc; p.c_plane = d->c_plane;
     p.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;
     p.sA_o = d->sA_o; p.sA_i = d->sA_i; p.sB_o = d->sB_o; p.sB_i = d->sB_i; p.sC_o = d->sC_o; p.sC_i = d->sC_i;
     p.alpha = d->alpha; p.flags = d->flags; p.bias = d->bias; p.res = d->res; p.ldr = d->ldr;
@@ -1314,6 +1325,10 @@ extern "C" int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t work
     LVT_REQUIRE(!(d->flags & LVT_EPI_BIAS) || d->bias, "gemm: BIAS flag without bias");
     LVT_REQUIRE(!(d->flags & LVT_EPI_RESIDUAL) || d->res, "gemm: RESIDUAL flag without res");
     LVT_REQUIRE(!(d->flags & LVT_EPI_MASK) || d->mask, "gemm: MASK flag without mask");
+    if (d->flags & LVT_EPI_PLANES)
+        LVT_REQUIRE(d->splits <= 1 && !(d->flags & LVT_EPI_ACCUM) && d->N % 4 == 0 && d->ldc % 4 == 0 && d->c_plane % 4 == 0 &&
+                    d->sC_o % 4 == 0 && d->sC_i % 4 == 0 && lvt_aligned16(d->C) && !(d->flags & LVT_MATH_F32),
+                    "gemm: PLANES needs the bf16x3 arithmetic, no split-K / ACCUM, N, ldc, c_plane, sC %% 4 == 0 and an aligned C");
     hipStream_t s = (hipStream_t)stream;
     KParams p; kparams_from_desc(d, p);
     const int zc = gemm_batch(d);

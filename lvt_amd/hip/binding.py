@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("LVT_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "liblvt_hip.so")
 
-EPI_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_TANH, EPI_MASK, EPI_ACCUM = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_TANH, EPI_MASK, EPI_ACCUM, EPI_PLANES = 1, 2, 4, 8, 16, 32, 64
 CAUSAL_KMAX, CAUSAL_KMIN, CAUSAL_TILE = 1 << 8, 1 << 9, 1 << 10      # causal attention products (include/lvt_hip.h)
 ABI_VERSION = 300           # lvt_version() of the library this module binds (argument lists below)
 MATH_F32 = 1 << 16          # per-call arithmetic selector of the engine entry points (include/lvt_hip.h)
@@ -34,7 +34,7 @@ class GemmDesc(C.Structure):
         ("alpha", C.c_float), ("flags", C.c_int),
         ("bias", C.c_void_p), ("res", C.c_void_p), ("ldr", C.c_longlong),
         ("mask", C.c_void_p), ("ldm", C.c_longlong), ("splits", C.c_int),
-        ("a_colsum", C.c_void_p),
+        ("a_colsum", C.c_void_p), ("c_plane", C.c_longlong),
     ]
 
 
@@ -106,6 +106,10 @@ def _declare(lib):
         "lvt_attn_softmax_fwd": (ci, [vp, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp]),
         "lvt_attn_softmax_bwd": (ci, [vp, vp, ci, ci, ci, cf, ci, ci, ci, vp, vp, vp, vp, vp]),
         "lvt_attn_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp]),
+        "lvt_attn_planes_supported": (ci, [ci, ci, ci, ci, ci]),
+        "lvt_attn_fwd_planes": (ci, [vp, cll, cll, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp]),
+        "lvt_attn_bwd_planes_workspace_bytes": (sz, [ci, ci, ci, ci, ci, ci]),
+        "lvt_attn_bwd_planes": (ci, [vp, cll, cll, vp, vp, vp, ci, ci, ci, ci, cf, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
         "lvt_attn_decode": (ci, [vp, cll, vp, vp, ci, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, vp, vp, cll, vp]),
         "lvt_decode_gather_codes": (ci, [vp, vp, vp, ci, ci, ci, vp, vp]),
         "lvt_decode_commit": (ci, [vp, ci, ci, vp, vp, vp]),

@@ -8,8 +8,9 @@ from . import binding as L
 
 def gemm(A, B, C_out, M, N, K, ta=0, tb=0, lda=None, ldb=None, ldc=None, a_kb=0, a_skb=0, b_kb=0,
          b_skb=0, batch_outer=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, flags=0,
-         bias=None, res=None, ldr=0, mask=None, ldm=0, splits=1, a_colsum=None):
-    """C = epi(alpha * A @ B); see include/lvt_hip.h for the addressing rules."""
+         bias=None, res=None, ldr=0, mask=None, ldm=0, splits=1, a_colsum=None, c_plane=0):
+    """C = epi(alpha * A @ B); see include/lvt_hip.h for the addressing rules.  With EPI_PLANES `C_out` is a bf16 tensor
+    that receives the exact 3-way bf16 split of the result (planes c_plane elements apart)."""
     L.require(A, B, C_out, bias, res, mask)
     d = L.GemmDesc()
     d.M, d.N, d.K, d.ta, d.tb = M, N, K, ta, tb
@@ -28,6 +29,7 @@ def gemm(A, B, C_out, M, N, K, ta=0, tb=0, lda=None, ldb=None, ldc=None, a_kb=0,
     d.ldm = ldm if mask is not None and ldm else d.ldc
     d.splits = splits
     d.a_colsum = a_colsum.data_ptr() if a_colsum is not None else None
+    d.c_plane = c_plane
     lib = L.lib()
     ws, nws = None, 0
     if splits > 1:

@@ -38,6 +38,49 @@ def attn_fwd(q, k, v, B, H, S, da, temper, dt, dh, dw, block, masked, fill=-1e4)
     return P, o
 
 
+def attn_planes_supported(S, da, block, bh_pairs=8):
+    """bh_pairs = batch x heads (the pipelined kernels pair their workgroups per XCD: a multiple of 8)."""
+    return bh_pairs % 8 == 0 and bool(L.lib().lvt_attn_planes_supported(S, da, block[0], block[1], block[2])) and L.get_math_mode() == "bf16x3"
+
+
+def attn_fwd_planes(qkvp, B, H, S, da, temper, dt, dh, dw, block, masked, fill=-1e4):
+    """qkvp (3 operands, 3 planes, B*S, H*da) bf16: the exact 3-way split of q, k, v (gemm with EPI_PLANES)
+    -> (P (B,H,S,S), o (B*S, H*da)) fp32."""
+    L.require(qkvp, dt, dh, dw)
+    M, hd = B * S, H * da
+    P = torch.empty(B, H, S, S, dtype=torch.float32, device=qkvp.device)
+    o = torch.empty(M, hd, dtype=torch.float32, device=qkvp.device)
+    t0 = L.TIMER.begin() if L.TIMER is not None else None
+    L.check(L.lib().lvt_attn_fwd_planes(L.ptr(qkvp), M * hd, 3 * M * hd, B, H, S, da, temper, L.ptr(dt), L.ptr(dh), L.ptr(dw),
+                                        block[0], block[1], block[2], 1 if masked else 0, fill, L.ptr(P), L.ptr(o),
+                                        L.stream_ptr()), "lvt_attn_fwd_planes")
+    if t0 is not None:
+        L.TIMER.end("attn_fwd", 4.0 * B * H * S * S * da, t0)
+    return P, o
+
+
+def attn_bwd_planes(qkvp, dop, P, o, B, H, S, da, temper, block, masked):
+    """-> (dqkv (3, B*S, H*da) fp32, ddt, ddh, ddw).  dop: (3 planes, B*S, H*da) bf16 split of dO."""
+    L.require(qkvp, dop, P, o)
+    M, hd = B * S, H * da
+    dev = P.device
+    dqkv = torch.empty(3, M, hd, dtype=torch.float32, device=dev)
+    ddt = torch.empty(H, 2 * block[0] - 1, dtype=torch.float32, device=dev)
+    ddh = torch.empty(H, 2 * block[1] - 1, dtype=torch.float32, device=dev)
+    ddw = torch.empty(H, 2 * block[2] - 1, dtype=torch.float32, device=dev)
+    lib = L.lib()
+    nws = lib.lvt_attn_bwd_planes_workspace_bytes(B, H, S, block[0], block[1], block[2])
+    ws = L.workspace(nws, dev, "attn_bwd")
+    t0 = L.TIMER.begin() if L.TIMER is not None else None
+    L.check(lib.lvt_attn_bwd_planes(L.ptr(qkvp), M * hd, 3 * M * hd, L.ptr(dop), L.ptr(P), L.ptr(o), B, H, S, da, temper,
+                                    block[0], block[1], block[2], 1 if masked else 0, L.ptr(dqkv[0]), L.ptr(dqkv[1]),
+                                    L.ptr(dqkv[2]), L.ptr(ddt), L.ptr(ddh), L.ptr(ddw), L.ptr(ws), nws, L.stream_ptr()),
+            "lvt_attn_bwd_planes")
+    if t0 is not None:
+        L.TIMER.end("attn_bwd", 8.0 * B * H * S * S * da, t0)
+    return dqkv, ddt, ddh, ddw
+
+
 def attn_softmax_bwd_(P, dP, temper, block):
     """dP is overwritten with dS.  Returns (ddt, ddh, ddw)."""
     L.require(P, dP)

@@ -123,6 +123,12 @@ def linear_wgrad(dy, x, n_out, k_in, rows, want_bias=False):
 
 CAUSAL_SKIP = not os.environ.get("LVT_NO_CAUSAL_SKIP")      # A/B switch of the causal reductions in the backward products
 FUSED_ATTENTION = True      # scores + bias + mask + softmax + P.V in one launch when the block is 256 tokens x 128 dims
+# q / k / v / dO as bf16x3 planes into the software-pipelined attention kernels (csrc/attention_pipe.hip): forward and the
+# whole core backward (dQ, dK, dV, bank gradients) as three fused launches.  Same results (tests/test_gpu_vt.py), but on
+# one MI355X it is NOT faster than the default path at the DSFVT shape -- forward 175 vs 176 us, backward 520 vs 480 us per
+# layer: both are bound by the P / dS round trips through HBM (2.1-3.8 TB/s measured) with one wave per SIMD, see
+# DESIGN.md section 3 -- so it is opt-in: LVT_PLANE_ATTENTION=1.
+PLANE_ATTENTION = bool(os.environ.get("LVT_PLANE_ATTENTION"))
 
 
 class _BlockLocalAttentionFn(torch.autograd.Function):
@@ -138,12 +144,23 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         temper = math.sqrt(da)
         dev = x.device
         xn, mean1, rstd1 = ew.layernorm_fwd(x, ln_w, ln_b)
-        # q, k, v of all heads in ONE launch: 3 x na batches of (M x da x d) against the packed weights, C = (3, M, hd)
-        qkv = torch.empty(3, M, hd, dtype=torch.float32, device=dev)
-        G.gemm(xn, wqkv, qkv, M, da, d, ta=0, tb=1, lda=d, ldb=da, ldc=hd, batch_outer=3, batch_inner=na,
-               sB=(na * d * da, d * da), sC=(M * hd, da))
-        q, k, v = qkv[0], qkv[1], qkv[2]
-        if FUSED_ATTENTION and tx.attn_fwd_supported(S, da):
+        planes = FUSED_ATTENTION and PLANE_ATTENTION and tx.attn_planes_supported(S, da, block, b * na)
+        if planes:
+            # q, k, v of all heads in ONE launch whose epilogue writes them as their exact 3-way bf16 split (3 operands x
+            # 3 planes x (M, hd)): the operand format of the pipelined attention kernels, which then stage by copying
+            qkv = torch.empty(3, 3, M, hd, dtype=torch.bfloat16, device=dev)
+            G.gemm(xn, wqkv, qkv, M, da, d, ta=0, tb=1, lda=d, ldb=da, ldc=hd, batch_outer=3, batch_inner=na,
+                   sB=(na * d * da, d * da), sC=(3 * M * hd, da), flags=L.EPI_PLANES, c_plane=M * hd)
+            P, o = tx.attn_fwd_planes(qkv, b, na, S, da, temper, dt, dh, dw, block, masked)
+        else:
+            # q, k, v of all heads in ONE launch: 3 x na batches of (M x da x d) against the packed weights, C = (3, M, hd)
+            qkv = torch.empty(3, M, hd, dtype=torch.float32, device=dev)
+            G.gemm(xn, wqkv, qkv, M, da, d, ta=0, tb=1, lda=d, ldb=da, ldc=hd, batch_outer=3, batch_inner=na,
+                   sB=(na * d * da, d * da), sC=(M * hd, da))
+            q, k, v = qkv[0], qkv[1], qkv[2]
+        if planes:
+            pass
+        elif FUSED_ATTENTION and tx.attn_fwd_supported(S, da):
             P, o = tx.attn_fwd(q, k, v, b, na, S, da, temper, dt, dh, dw, block, masked)
         else:
             P = torch.empty(b, na, S, S, dtype=torch.float32, device=dev)
@@ -162,14 +179,13 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         G.gemm(h1, f3w, y2, M, d, f3w.shape[1], flags=L.EPI_BIAS | L.EPI_RESIDUAL, bias=f3b, res=y1)
         ctx.save_for_backward(x, mean1, rstd1, xn, qkv, P, o, y1, mean2, rstd2, fn, h1,
                               ln_w, wqkv, proj_w, f0w, f1w, f3w)
-        ctx.block, ctx.dims, ctx.masked = block, (M, d, S, b, na, da), bool(masked)
+        ctx.block, ctx.dims, ctx.masked, ctx.planes = block, (M, d, S, b, na, da), bool(masked), bool(planes)
         return y2
 
     @staticmethod
     def backward(ctx, dy2):
         (x, mean1, rstd1, xn, qkv, P, o, y1, mean2, rstd2, fn, h1,
          ln_w, wqkv, proj_w, f0w, f1w, f3w) = ctx.saved_tensors
-        q, k, v = qkv[0], qkv[1], qkv[2]
         M, d, S, b, na, da = ctx.dims
         hd = na * da
         temper = math.sqrt(da)
@@ -185,10 +201,19 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         df1w, df1b = linear_wgrad(dh1, fn, dff, d, M, want_bias=True)
         dy1, df0w, df0b = ew.layernorm_bwd(dfn, y1, mean2, rstd2, f0w, add=dy2)
         # proj: y1 = o proj^T + x
+        if ctx.planes:
+            # dO leaves its GEMM as bf16x3 planes; the whole attention core backward is lvt_attn_bwd_planes
+            do = torch.empty(3, M, hd, dtype=torch.bfloat16, device=dev)
+            G.gemm(dy1, proj_w, do, M, hd, d, ta=0, tb=1, ldb=hd, flags=L.EPI_PLANES, c_plane=M * hd)
+            dproj = linear_wgrad(dy1, o, d, hd, M)
+            dqkv, ddt, ddh, ddw = tx.attn_bwd_planes(qkv, do, P, o, b, na, S, da, temper, ctx.block, ctx.masked)
+            return _BlockLocalAttentionFn._finish_backward(ctx, dqkv, ddt, ddh, ddw, dy1, dproj, df0w, df0b, df1w, df1b,
+                                                            df3w, df3b)
         do = torch.empty(M, hd, dtype=torch.float32, device=dev)
         G.gemm(dy1, proj_w, do, M, hd, d, ta=0, tb=1, ldb=hd)
         dproj = linear_wgrad(dy1, o, d, hd, M)
         # attention core
+        q, k, v = qkv[0], qkv[1], qkv[2]
         bh = dict(batch_outer=b, batch_inner=na)
         dqkv = torch.empty(3, M, hd, dtype=torch.float32, device=dev)
         dq, dk, dv = dqkv[0], dqkv[1], dqkv[2]
@@ -206,6 +231,15 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         G.gemm(dP, q, dk, S, da, S, ta=1, tb=1, lda=S, ldb=hd, ldc=hd, sA=(na * S * S, S * S), sB=(S * hd, da),
                sC=(S * hd, da), flags=L.CAUSAL_KMIN if cz else 0, **bh)              # dK[j] = sum_{i >= j} dS[i][j] Q[i]
         del dP
+        return _BlockLocalAttentionFn._finish_backward(ctx, dqkv, ddt, ddh, ddw, dy1, dproj, df0w, df0b, df1w, df1b, df3w, df3b)
+
+    @staticmethod
+    def _finish_backward(ctx, dqkv, ddt, ddh, ddw, dy1, dproj, df0w, df0b, df1w, df1b, df3w, df3b):
+        x, mean1, rstd1, xn = ctx.saved_tensors[:4]
+        ln_w, wqkv = ctx.saved_tensors[12], ctx.saved_tensors[13]
+        M, d, S, b, na, da = ctx.dims
+        hd = na * da
+        dev = x.device
         # per-head projections q = xn w_q[h] (k, v alike), all three at once: the data gradient is one GEMM whose
         # reduction runs over (projection, head, da) = 3*hd -- A walks the (3, M, hd) gradient with a 2-level k,
         # B the packed (3, na, d, da) weights -- and the weight gradient one launch of 3 x na batches

@@ -5,7 +5,7 @@ cur = sqlite3.connect(db).cursor()
 rows = cur.execute("select name, counter_name, count(*), avg(counter_value), avg(duration) from pmc_events group by name, counter_name").fetchall()
 res = {}
 for n, c, cnt, avg, dur in rows:
-    k = re.sub(r"\(.*", "", n)[:64]
+    k = re.sub(r"\((?!anonymous).*", "", n.replace("(anonymous namespace)::", ""))[:64]
     res.setdefault(k, {"calls": cnt, "us": dur / 1e3})[c] = avg
 names = sorted({c for v in res.values() for c in v if c not in ("calls", "us")})
 lines = ["# " + title, "# per-dispatch averages", "%-56s %6s %9s " % ("kernel", "calls", "avg_us") + " ".join("%22s" % c for c in names)]

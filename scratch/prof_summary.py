@@ -12,7 +12,7 @@ tot = sum(r[2] for r in rows)
 lines = ["# " + title, "# times in microseconds; pct = share of total kernel time",
          "%-96s %7s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct")]
 for n, c, t, a, mn, mx in rows[:45]:
-    n = re.sub(r"\(.*", "", n)[:94]
+    n = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", ""))[:94]
     lines.append("%-96s %7d %12.1f %10.1f %10.1f %10.1f %6.2f" % (n, c, t / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100 * t / tot))
 lines.append("TOTAL kernel time %.1f us over %d launches; first-to-last kernel span %.1f us (GPU busy %.1f%%)"
              % (tot / 1e3, sum(r[1] for r in rows), (span[1] - span[0]) / 1e3, 100 * tot / (span[1] - span[0])))

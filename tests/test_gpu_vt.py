@@ -386,3 +386,37 @@ def test_fused_attention_forward(masked, blk):
            sA=(S * hd, da), sB=(S * hd, da), sC=(H * S * S, S * S))
     tx.attn_softmax_fwd_(P2, temper, bd[0], bd[1], bd[2], blk, masked)
     assert rel_err(P, P2) < 2e-5
+
+
+@pytest.mark.parametrize("block,masked", [((1, 16, 16), False), ((1, 16, 16), True), ((4, 8, 8), True)])
+def test_plane_attention_path_equals_default_path(block, masked):
+    """The opt-in pipelined attention kernels on bf16x3-plane operands (csrc/attention_pipe.hip: LVT_EPI_PLANES epilogue of the
+    QKV / dO GEMMs, lvt_attn_fwd_planes, lvt_attn_bwd_planes) against the default path on one layer: output and every
+    gradient, including the bias banks reduced from per-workgroup partial sums."""
+    import lvt_amd.modeling.autoregressive.vt_attention as A
+    torch.manual_seed(0)
+    layer = A.BlockLocalAttention(block, 128, 512, 8, masked=masked).to(DEV)
+    with torch.no_grad():
+        layer.dt_bank.normal_(0, 0.3); layer.dh_bank.normal_(0, 0.3); layer.dw_bank.normal_(0, 0.3)
+    x = torch.randn(8 * 256, 512, device=DEV)
+    gy = torch.randn_like(x)
+
+    def run(planes):
+        A.PLANE_ATTENTION = planes
+        try:
+            for p in layer.parameters():
+                p.grad = None
+            xx = x.clone().requires_grad_(True)
+            y = layer.forward_tokens(xx, layer.block_size)
+            y.backward(gy)
+            return [y.detach(), xx.grad] + [p.grad.clone() for p in layer.parameters()]
+        finally:
+            A.PLANE_ATTENTION = False
+
+    new, old = run(True), run(False)
+    names = ["y", "dx"] + [n for n, _ in layer.named_parameters()]
+    bank_scale = float(old[names.index("dh_bank")].abs().max())
+    for n, a, c in zip(names, new, old):
+        # (the gradient of a one-entry bank is sum_ij g_ij == 0 up to rounding: judged against the scale of the other banks)
+        scale = bank_scale if n.endswith("_bank") else float(c.abs().max())
+        assert float((a - c).abs().max()) < 2e-5 * scale + 1e-30, (n, float((a - c).abs().max()), scale)
