@@ -99,7 +99,12 @@ class MSEEvaluator(_SumEvaluator):
         for inp, out in zip(inputs, outputs):
             rec = out["reconstruction"].detach()
             tgt = torch.as_tensor(inp["image"] if "image" in inp else inp["image_sequence"], device=rec.device)
-            self._add(F.mse_loss(rec, tgt.to(rec.dtype), reduction="sum"), tgt.numel())
+            if rec.is_cuda:       # sum of squared differences on the device: lvt_mse_fwd (F.mse_loss(reduction="sum"))
+                from ..hip import ew
+                sq = ew.mse_fwd(rec.contiguous().float(), tgt.to(torch.float32).contiguous(), denom=1.0)
+            else:
+                sq = F.mse_loss(rec, tgt.to(rec.dtype), reduction="sum")
+            self._add(sq, tgt.numel())
 
     def evaluate(self):
         s, n = self._totals()
@@ -116,8 +121,19 @@ class BitsEvaluator(_SumEvaluator):
             logits = out["logits"]                                   # nc, nv, T, H, W
             target = torch.as_tensor(inp["image_sequence"], device=logits.device).transpose(0, 1)   # nc, T, H, W
             keep = ~out["ignore_mask"].expand(target.size(0), -1, -1, -1)
-            ce = F.cross_entropy(logits.permute(1, 0, 2, 3, 4).unsqueeze(0), target.unsqueeze(0), reduction="none")[0]
-            self._add(ce[keep].sum(), int(keep.sum()))
+            if logits.is_cuda:
+                # lvt_xent_fwd on token-major rows (vidgen/evaluation/bits_evaluation.py:28-58 sums F.cross_entropy over the
+                # kept positions): (nc, nv, P) -> (nc * P, nv) by lvt_permute3, ignored positions carry the ignore index
+                from ..hip import tx
+                nc, nv = logits.shape[:2]
+                P = target[0].numel()
+                rows = tx.permute3(logits.contiguous().float().view(nc, nv, P), (nv * P, 1, P), (nc, P, nv)).view(nc * P, nv)
+                tgt = torch.where(keep, target, torch.full_like(target, -100)).reshape(1, nc * P).contiguous()
+                loss, _, count = tx.xent_fwd(rows, tgt[0], 0, 1, nc * P, -100, 1.0)      # mean over the kept rows
+                self._add(loss.double() * count.double().reshape(()), int(keep.sum()))
+            else:
+                ce = F.cross_entropy(logits.permute(1, 0, 2, 3, 4).unsqueeze(0), target.unsqueeze(0), reduction="none")[0]
+                self._add(ce[keep].sum(), int(keep.sum()))
 
     def evaluate(self):
         s, n = self._totals()

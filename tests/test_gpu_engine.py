@@ -195,7 +195,9 @@ def test_conv_bwd_data_residual_and_mask():
     assert rel_err(_nchw(dx), ref) < TOL
 
 
-@pytest.mark.parametrize("Ci,Co,N", [(256, 256, 3), (256, 128, 5), (128, 256, 2), (32, 128, 1)])
+# (the N = 512 rows are BASELINE configs[1]'s full frame count on channel-subsampled layers: the frame-resident kernels meet
+# torch-CPU at the size the bench runs them, not only through chunk-additivity)
+@pytest.mark.parametrize("Ci,Co,N", [(256, 256, 3), (256, 128, 5), (128, 256, 2), (32, 128, 1), (128, 128, 512)])
 def test_frame_resident_conv_forward_and_backward_data(Ci, Co, N, math_mode):
     """3x3 / pad 1 convolutions of 16x16 frames: forward (bias + residual + ReLU) and backward-data (as a forward
     convolution over the transposed, tap-reversed weights, with residual and ReLU mask) against torch on the CPU.  In the
@@ -224,7 +226,7 @@ def test_frame_resident_conv_forward_and_backward_data(Ci, Co, N, math_mode):
     assert rel_err(dx, dx2) < TOL
 
 
-@pytest.mark.parametrize("Ci,Co,N", [(256, 256, 37), (256, 128, 5), (64, 256, 2), (256, 32, 70)])
+@pytest.mark.parametrize("Ci,Co,N", [(256, 256, 37), (256, 128, 5), (64, 256, 2), (256, 32, 70), (32, 256, 512), (256, 32, 512)])
 def test_frame_resident_weight_gradient(Ci, Co, N, math_mode):
     """Weight gradient of the 3x3 / pad 1 layers on 16x16 frames.  With 256 channels on one side and the default math mode
     it runs on the frame-resident kernel (patch = x when Co == 256, else the roles are swapped and the taps reversed);
@@ -246,7 +248,7 @@ def test_frame_resident_weight_gradient(Ci, Co, N, math_mode):
     assert rel_err(dw.squeeze(2), w.grad) < 5e-5
 
 
-@pytest.mark.parametrize("Cin,Cout,N", [(256, 128, 3), (32, 128, 1), (64, 256, 5)])
+@pytest.mark.parametrize("Cin,Cout,N", [(256, 128, 3), (32, 128, 1), (64, 256, 5), (32, 128, 512)])
 def test_transposed_conv_by_phases(Cin, Cout, N, math_mode):
     """ConvTranspose2d(Cin -> Cout, k4 s2 p1) of 16x16 frames == backward-data of the strided convolution, run phase by
     phase on the frame-resident kernel (default math mode) with bias + residual + ReLU mask, against torch on the CPU and
@@ -268,7 +270,7 @@ def test_transposed_conv_by_phases(Cin, Cout, N, math_mode):
         assert rel_err(y1, y2) < TOL
 
 
-@pytest.mark.parametrize("Ci,Co,N", [(128, 256, 3), (32, 128, 1), (64, 128, 5)])
+@pytest.mark.parametrize("Ci,Co,N", [(128, 256, 3), (32, 128, 1), (64, 128, 5), (32, 128, 512)])
 def test_strided_conv_by_parity_classes(Ci, Co, N, math_mode):
     """Conv2d(Ci -> Co, k4 s2 p1) of 32x32 frames on the frame-resident kernel (four parity classes x four taps on 17x17
     sub-images), with bias + residual + ReLU, against torch on the CPU and the implicit-GEMM route."""
@@ -288,7 +290,7 @@ def test_strided_conv_by_parity_classes(Ci, Co, N, math_mode):
         assert rel_err(y1, y2) < TOL
 
 
-@pytest.mark.parametrize("Ci,N", [(128, 37), (32, 3), (64, 70)])
+@pytest.mark.parametrize("Ci,N", [(128, 37), (32, 3), (64, 70), (32, 512)])
 def test_frame_resident_weight_gradient_stride2(Ci, N, math_mode):
     """Weight gradient of the 4x4 / stride 2 / pad 1 layers between 32x32 and 16x16 frames with 256 output channels: one
     workgroup per parity class of the taps on the frame-resident kernel (default math mode), against torch on the CPU."""
