@@ -13,6 +13,7 @@
 // per row in registers; a 5-step wave shuffle finishes the row reduction.  z_e is read exactly once
 // and only the int64 indices are written: 270,336 algorithmic bytes per 64x64 frame.
 #include "lvt_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -248,6 +249,217 @@ __global__ __launch_bounds__(VQ_THREADS) void lvt_vq_nearest_half_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Coarse-then-exact search (round 3; default arithmetic).  Nothing forces a full-precision scan of all 512 codes:
+//   1. COARSE: score~_k = x~ . e~_k - |e_k|^2 / 2 with x~ = bf16(x), e~ = bf16(e): ONE bf16 MFMA per 16 dims instead of the
+//      six of the exact split (the -|e|^2/2 term rides in as the fp32 initial accumulator).  RNE bf16 has a relative error of
+//      at most 2^-9 per operand, so |score~_k - score_k| <= eps = (2^-8 + 2^-18) sum_d |x_d e_kd| <= 1.001 * 2^-8 |x| |e_k|.
+//   2. Every code whose coarse score is within 2 eps (+ the fp32 evaluation noise of the exact distance) of the coarse
+//      maximum is a CANDIDATE; the true nearest code always is one (score~_best >= score_best - eps >= score_j - eps >=
+//      score~_j - 2 eps for every j).  The scores are recomputed by a second pass of the same MFMAs (bit-identical) instead of
+//      being kept: 128 MFMAs per 32 rows in total against 384, and no 512-entry register file per row.
+//   3. EXACT: the candidates (typically 1-3 per row, at most 8 per half-wave, else the row takes the exhaustive path) are
+//      evaluated as fp32 FMA chains dist = (|e|^2 + |x|^2) - 2 x.e, the reference's algebraic form (vq_utils.py:13-20), lowest
+//      index on equal distances (torch.min).  The argmin is exact: which fp32 summation order decides a sub-rounding near-tie
+//      is implementation-defined in the reference as well (tests/util_models.py:margin_ok).
+// The whole codebook group fits as one bf16 plane (72 KB): one workgroup per (group, row range), no half / merge passes, and
+// the indices are written directly in their final layout.
+// ------------------------------------------------------------------------------------------------
+#define VQC_LD (VQ_D + 8)              // plane row stride (bf16): 144 B, conflict-free 16-byte fragment reads
+#define VQC_MAXC 8                     // candidates kept per (row, half-wave); measured: 1.3-1.6 per ROW on average, > 8 per half ~never
+
+template <int KC>
+__global__ __launch_bounds__(VQ_THREADS) void lvt_vq_nearest_coarse_kernel(
+    const float *__restrict__ z, long long rows, int ldz, const float *__restrict__ codebooks, long long *__restrict__ idx_out,
+    int P, int num) {
+    __shared__ __attribute__((aligned(16))) unsigned short plane[KC * VQC_LD];
+    __shared__ __attribute__((aligned(16))) float cbsq[KC], hcb[KC];       // |e|^2 (FMA chain), -|e|^2 / 2
+    __shared__ float emax2_s;
+    __shared__ int cand[VQ_THREADS / 64][32][2][VQC_MAXC];
+    const int g = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const float *E = codebooks + (long long)g * KC * VQ_D;
+
+    // stage the codebook group as ONE bf16 plane [code][dim]; thread (code = tid >> 1 (+256), dims 32 * (tid & 1) ..)
+    for (int code = tid >> 1; code < KC; code += VQ_THREADS / 2) {
+        const int d0 = 32 * (tid & 1);
+        float sq = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 v = *reinterpret_cast<const float4 *>(E + (long long)code * VQ_D + d0 + 4 * u);
+            sq = fmaf(v.x, v.x, sq); sq = fmaf(v.y, v.y, sq); sq = fmaf(v.z, v.z, sq); sq = fmaf(v.w, v.w, sq);
+            uint2 p1;
+            p1.x = vq_cvt_pk(v.x, v.y); p1.y = vq_cvt_pk(v.z, v.w);
+            *reinterpret_cast<uint2 *>(plane + code * VQC_LD + d0 + 4 * u) = p1;
+        }
+        sq += __shfl_xor(sq, 1);            // (dims 0..31) + (dims 32..63), the order of the exact phase below
+        if ((tid & 1) == 0) { cbsq[code] = sq; hcb[code] = -0.5f * sq; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float m = 0.f;
+        for (int c = lane; c < KC; c += 64) m = fmaxf(m, cbsq[c]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) emax2_s = m;
+    }
+    __syncthreads();
+    const float emax2 = emax2_s, emax = sqrtf(emax2);
+
+    const long long ntiles = (rows + 31) / 32;
+    const int wpb = VQ_THREADS / 64;
+    for (long long tile = (long long)blockIdx.x * wpb + wave; tile < ntiles; tile += (long long)gridDim.x * wpb) {
+        const long long row = tile * 32 + l31;
+        const bool rok = row < rows;
+        const float *zrow = z + (rok ? row : 0) * (long long)ldz + g * VQ_D;
+        // exact-phase copy of the row: dims 32 half .. 32 half + 31 in fp32; |x|^2 as (dims 0..31) + (dims 32..63)
+        float xr[32];
+        float xs = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 v = rok ? *reinterpret_cast<const float4 *>(zrow + 32 * half + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xr[4 * u] = v.x; xr[4 * u + 1] = v.y; xr[4 * u + 2] = v.z; xr[4 * u + 3] = v.w;
+            xs = fmaf(v.x, v.x, xs); xs = fmaf(v.y, v.y, xs); xs = fmaf(v.z, v.z, xs); xs = fmaf(v.w, v.w, xs);
+        }
+        xs += __shfl_xor(xs, 32);
+        // coarse B operand: bf16(x), dims 16 s + 8 half .. + 7
+        bf16x8 zb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 lo = rok ? *reinterpret_cast<const float4 *>(zrow + 16 * s + 8 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 hi = rok ? *reinterpret_cast<const float4 *>(zrow + 16 * s + 8 * half + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint4 u1 = make_uint4(vq_cvt_pk(lo.x, lo.y), vq_cvt_pk(lo.z, lo.w), vq_cvt_pk(hi.x, hi.y), vq_cvt_pk(hi.z, hi.w));
+            zb[s] = *reinterpret_cast<const bf16x8 *>(&u1);
+        }
+        // FOUR 32 x 32 tiles of coarse scores at a time (rows = codes ct*32 .., columns = the wave's activation rows): four
+        // independent accumulator chains keep the matrix pipe issuing back to back and sixteen LDS reads are in flight together
+        // (one tile at a time, each of the four k-steps waited for its predecessor and for its own LDS round trip)
+        auto coarse_tiles = [&](int ct, f32x16 (&acc)[4]) {
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 h4 = *reinterpret_cast<const float4 *>(&hcb[(ct + t4) * 32 + 8 * q + 4 * half]);
+                    acc[t4][4 * q] = h4.x; acc[t4][4 * q + 1] = h4.y; acc[t4][4 * q + 2] = h4.z; acc[t4][4 * q + 3] = h4.w;
+                }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 a[4];
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4)
+                    a[t4] = *reinterpret_cast<const bf16x8 *>(plane + ((ct + t4) * 32 + l31) * VQC_LD + 16 * s + 8 * half);
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t4], zb[s], acc[t4], 0, 0, 0);
+            }
+        };
+        // ---- pass 1: coarse maximum ----
+        float m = -3.4e38f;
+        for (int ct = 0; ct < KC / 32; ct += 4) {
+            f32x16 acc[4];
+            coarse_tiles(ct, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaxf(fmaxf(acc[0][r], acc[1][r]), fmaxf(acc[2][r], acc[3][r])));
+        }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        // band: 2 eps of the coarse product + the fp32 rounding of the coarse accumulation and of the exact distances (both << 1e-5 (|x| + |e|)^2)
+        const float xn = sqrtf(xs);
+        const float thr = rok ? m - (2.0f * 1.002f * 0.00390625f * xn * emax + 1e-5f * (xs + emax2 + 2.f * xn * emax)) : 3.4e38f;
+        // ---- pass 2: the same scores again; codes inside the band are appended to the lane's candidate list.  One test per
+        // tile (its maximum) guards the sixteen per-code tests: most tiles hold no candidate of a given lane ----
+        int cnt = 0;
+        for (int ct = 0; ct < KC / 32; ct += 4) {
+            f32x16 acc[4];
+            coarse_tiles(ct, acc);
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                float tm = acc[t4][0];
+#pragma unroll
+                for (int r = 1; r < 16; r += 3) tm = fmaxf(tm, fmaxf(fmaxf(acc[t4][r], acc[t4][r + 1]), acc[t4][r + 2]));
+                if (tm >= thr) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (acc[t4][r] >= thr) {
+                            if (cnt < VQC_MAXC) cand[wave][l31][half][cnt] = (ct + t4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            ++cnt;
+                        }
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                   // lgkmcnt(0): the list stores have landed (LDS is in order per wave)
+        __builtin_amdgcn_wave_barrier();
+        const int cnt_o = __shfl_xor(cnt, 32);
+        const int c0 = half ? cnt_o : cnt, c1 = half ? cnt : cnt_o;            // entries of half 0 / half 1 for this row
+        const bool overflow = c0 > VQC_MAXC || c1 > VQC_MAXC;
+        // ---- exact phase: both half-waves walk the row's candidates together (32 dims each), two candidates per trip so
+        // that their code rows (L2 hits, ~1 us away) are in flight together ----
+        float best = 3.4e38f; int bidx = 0x7fffffff;
+        const int total = overflow ? 0 : c0 + c1;
+        int tmax = total;
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) tmax = max(tmax, __shfl_xor(tmax, o));
+        for (int j = 0; j < tmax; j += 2) {
+            int code[2]; float4 ev[2][8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int jj = j + q < total ? j + q : (total > 0 ? total - 1 : 0);        // (clamped: a duplicate changes nothing)
+                code[q] = total > 0 ? (jj < c0 ? cand[wave][l31][0][jj] : cand[wave][l31][1][jj - c0]) : 0;
+                const float *e = E + (long long)code[q] * VQ_D + 32 * half;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ev[q][u] = *reinterpret_cast<const float4 *>(e + 4 * u);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float dot = 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    dot = fmaf(xr[4 * u], ev[q][u].x, dot); dot = fmaf(xr[4 * u + 1], ev[q][u].y, dot);
+                    dot = fmaf(xr[4 * u + 2], ev[q][u].z, dot); dot = fmaf(xr[4 * u + 3], ev[q][u].w, dot);
+                }
+                dot += __shfl_xor(dot, 32);
+                const float dist = fmaf(-2.0f, dot, cbsq[code[q]] + xs);
+                if (j < total && (dist < best || (dist == best && code[q] < bidx))) { best = dist; bidx = code[q]; }
+            }
+        }
+        // ---- rows whose band holds more than VQC_MAXC codes per half-wave: exhaustive exact scan, the wave shares the codes ----
+        unsigned long long of = __builtin_amdgcn_ballot_w64(overflow && half == 0);
+        while (of) {
+            const int rl = __builtin_ctzll(of);
+            of &= of - 1;
+            const long long orow = tile * 32 + rl;
+            const float *zr = z + (orow < rows ? orow : 0) * (long long)ldz + g * VQ_D;
+            const float oxs = __shfl(xs, rl);
+            float ob = 3.4e38f; int oi = 0x7fffffff;
+            float4 zv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) zv[u] = *reinterpret_cast<const float4 *>(zr + 4 * u);
+            for (int code = lane; code < KC; code += 64) {                      // ascending per lane: strict < keeps the lowest index
+                const float *e = E + (long long)code * VQ_D;
+                float4 ev[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) ev[u] = *reinterpret_cast<const float4 *>(e + 4 * u);
+                float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    d0 = fmaf(zv[u].x, ev[u].x, d0); d0 = fmaf(zv[u].y, ev[u].y, d0); d0 = fmaf(zv[u].z, ev[u].z, d0); d0 = fmaf(zv[u].w, ev[u].w, d0);
+                    d1 = fmaf(zv[8 + u].x, ev[8 + u].x, d1); d1 = fmaf(zv[8 + u].y, ev[8 + u].y, d1);
+                    d1 = fmaf(zv[8 + u].z, ev[8 + u].z, d1); d1 = fmaf(zv[8 + u].w, ev[8 + u].w, d1);
+                }
+                const float dist = fmaf(-2.0f, d0 + d1, cbsq[code] + oxs);
+                if (dist < ob) { ob = dist; oi = code; }
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const float tb = __shfl_xor(ob, o); const int ti = __shfl_xor(oi, o);
+                if (tb < ob || (tb == ob && ti < oi)) { ob = tb; oi = ti; }
+            }
+            if (l31 == rl) { best = ob; bidx = oi; }
+        }
+        if (half == 0 && rok) idx_out[((row / P) * num + g) * (long long)P + row % P] = bidx;
+        __builtin_amdgcn_wave_barrier();                                       // the lists are reused by the next tile
+    }
+}
+
 __global__ void lvt_vq_nearest_merge_kernel(const float *__restrict__ pbest, const int *__restrict__ pidx, long long rows,
                                             int num, int nparts, int P, long long *__restrict__ idx_out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -444,6 +656,19 @@ extern "C" int lvt_vq_nearest(const float *z, long long rows, int ldz, int num, 
     LVT_REQUIRE(rows > 0 && num > 0 && P > 0 && rows % P == 0, "vq_nearest: bad rows/P");
     LVT_REQUIRE(ldz % 4 == 0 && ldz >= num * D && lvt_aligned16(z) && lvt_aligned16(codebooks),
                 "vq_nearest: alignment / ldz");
+    static const int no_coarse = getenv("LVT_VQ_FULL_SCAN") ? 1 : 0;        // A/B switch: the full bf16x3 scan of round 1
+    if (!(flags & LVT_MATH_F32) && !no_coarse) {
+        const long long need_ = lvt_cdiv((rows + 31) / 32, VQ_THREADS / 64);
+        int bpp = LVT_NUM_CU / num;                     // one workgroup per CU (LDS-bound)
+        if (bpp > need_) bpp = (int)need_;
+        if (bpp < 1) bpp = 1;
+        hipStream_t s = (hipStream_t)stream;
+        if (KC == 512) hipLaunchKernelGGL(lvt_vq_nearest_coarse_kernel<512>, dim3(bpp, num), dim3(VQ_THREADS), 0, s, z, rows, ldz, codebooks, idx_out, P, num);
+        else if (KC == 256) hipLaunchKernelGGL(lvt_vq_nearest_coarse_kernel<256>, dim3(bpp, num), dim3(VQ_THREADS), 0, s, z, rows, ldz, codebooks, idx_out, P, num);
+        else hipLaunchKernelGGL(lvt_vq_nearest_coarse_kernel<128>, dim3(bpp, num), dim3(VQ_THREADS), 0, s, z, rows, ldz, codebooks, idx_out, P, num);
+        LVT_CHECK_LAUNCH("lvt_vq_nearest_coarse_kernel");
+        return LVT_OK;
+    }
     if (!(flags & LVT_MATH_F32) && KC % VQH_CODES == 0 && workspace &&
         workspace_bytes >= lvt_vq_nearest_workspace_bytes(rows, num, KC)) {
         const int nparts = KC / VQH_CODES;
