@@ -258,7 +258,7 @@ __global__ __launch_bounds__(VQ_THREADS) void lvt_vq_nearest_half_kernel(
 //      maximum is a CANDIDATE; the true nearest code always is one (score~_best >= score_best - eps >= score_j - eps >=
 //      score~_j - 2 eps for every j).  The scores are recomputed by a second pass of the same MFMAs (bit-identical) instead of
 //      being kept: 128 MFMAs per 32 rows in total against 384, and no 512-entry register file per row.
-//   3. EXACT: the candidates (typically 1-3 per row, at most 8 per half-wave, else the row takes the exhaustive path) are
+//   3. EXACT: the candidates (typically 1-3 per row, at most 8 per half-wave, else the row's tile takes the exhaustive path) are
 //      evaluated as fp32 FMA chains dist = (|e|^2 + |x|^2) - 2 x.e, the reference's algebraic form (vq_utils.py:13-20), lowest
 //      index on equal distances (torch.min).  The argmin is exact: which fp32 summation order decides a sub-rounding near-tie
 //      is implementation-defined in the reference as well (tests/util_models.py:margin_ok).
@@ -421,39 +421,65 @@ __global__ __launch_bounds__(VQ_THREADS) void lvt_vq_nearest_coarse_kernel(
                 if (j < total && (dist < best || (dist == best && code[q] < bidx))) { best = dist; bidx = code[q]; }
             }
         }
-        // ---- rows whose band holds more than VQC_MAXC codes per half-wave: exhaustive exact scan, the wave shares the codes ----
-        unsigned long long of = __builtin_amdgcn_ballot_w64(overflow && half == 0);
-        while (of) {
-            const int rl = __builtin_ctzll(of);
-            of &= of - 1;
-            const long long orow = tile * 32 + rl;
-            const float *zr = z + (orow < rows ? orow : 0) * (long long)ldz + g * VQ_D;
-            const float oxs = __shfl(xs, rl);
-            float ob = 3.4e38f; int oi = 0x7fffffff;
-            float4 zv[16];
+        // ---- a row whose band holds more than VQC_MAXC codes per half-wave (many codes (almost) equally near: dead or
+        // duplicated codebook entries, e.g. the all-equal codes of an EMA codebook that has just been initialised): the whole
+        // tile takes the exhaustive EXACT scan -- all codes, bf16x3 products (six MFMAs per step, code rows split on the fly
+        // from the L2-resident fp32 codebook), running arg-min in ascending code order.  Worst case = the cost of the full
+        // scan of rounds 1-2; an ordinary codebook never gets here.
+        if (__builtin_amdgcn_ballot_w64(overflow) != 0) {
+            bf16x8 zb3[4][3];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) zv[u] = *reinterpret_cast<const float4 *>(zr + 4 * u);
-            for (int code = lane; code < KC; code += 64) {                      // ascending per lane: strict < keeps the lowest index
-                const float *e = E + (long long)code * VQ_D;
-                float4 ev[16];
+            for (int s = 0; s < 4; ++s) {
+                const float4 lo = rok ? *reinterpret_cast<const float4 *>(zrow + 16 * s + 8 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 hi = rok ? *reinterpret_cast<const float4 *>(zrow + 16 * s + 8 * half + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                uint2 a1, a2, a3, b1, b2, b3;
+                vq_split4(lo, a1, a2, a3); vq_split4(hi, b1, b2, b3);
+                const uint4 u1 = make_uint4(a1.x, a1.y, b1.x, b1.y), u2 = make_uint4(a2.x, a2.y, b2.x, b2.y), u3 = make_uint4(a3.x, a3.y, b3.x, b3.y);
+                zb3[s][0] = *reinterpret_cast<const bf16x8 *>(&u1); zb3[s][1] = *reinterpret_cast<const bf16x8 *>(&u2);
+                zb3[s][2] = *reinterpret_cast<const bf16x8 *>(&u3);
+            }
+            best = 3.4e38f; bidx = 0;
+            for (int ct = 0; ct < KC / 32; ct += 2) {
+                f32x16 acc0, acc1;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) ev[u] = *reinterpret_cast<const float4 *>(e + 4 * u);
-                float d0 = 0.f, d1 = 0.f;
+                for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    d0 = fmaf(zv[u].x, ev[u].x, d0); d0 = fmaf(zv[u].y, ev[u].y, d0); d0 = fmaf(zv[u].z, ev[u].z, d0); d0 = fmaf(zv[u].w, ev[u].w, d0);
-                    d1 = fmaf(zv[8 + u].x, ev[8 + u].x, d1); d1 = fmaf(zv[8 + u].y, ev[8 + u].y, d1);
-                    d1 = fmaf(zv[8 + u].z, ev[8 + u].z, d1); d1 = fmaf(zv[8 + u].w, ev[8 + u].w, d1);
+                for (int s = 0; s < 4; ++s) {
+                    bf16x8 a0[3], a1[3];
+                    {
+                        const float *e0 = E + (long long)(ct * 32 + l31) * VQ_D + 16 * s + 8 * half, *e1 = e0 + 32 * VQ_D;
+                        uint2 p1, p2, p3, q1, q2, q3;
+                        vq_split4(*reinterpret_cast<const float4 *>(e0), p1, p2, p3); vq_split4(*reinterpret_cast<const float4 *>(e0 + 4), q1, q2, q3);
+                        uint4 u1 = make_uint4(p1.x, p1.y, q1.x, q1.y), u2 = make_uint4(p2.x, p2.y, q2.x, q2.y), u3 = make_uint4(p3.x, p3.y, q3.x, q3.y);
+                        a0[0] = *reinterpret_cast<const bf16x8 *>(&u1); a0[1] = *reinterpret_cast<const bf16x8 *>(&u2); a0[2] = *reinterpret_cast<const bf16x8 *>(&u3);
+                        vq_split4(*reinterpret_cast<const float4 *>(e1), p1, p2, p3); vq_split4(*reinterpret_cast<const float4 *>(e1 + 4), q1, q2, q3);
+                        u1 = make_uint4(p1.x, p1.y, q1.x, q1.y); u2 = make_uint4(p2.x, p2.y, q2.x, q2.y); u3 = make_uint4(p3.x, p3.y, q3.x, q3.y);
+                        a1[0] = *reinterpret_cast<const bf16x8 *>(&u1); a1[1] = *reinterpret_cast<const bf16x8 *>(&u2); a1[2] = *reinterpret_cast<const bf16x8 *>(&u3);
+                    }
+                    constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};     // smallest terms first
+#pragma unroll
+                    for (int tm = 0; tm < 6; ++tm) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[TA[tm]], zb3[s][TB[tm]], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[TA[tm]], zb3[s][TB[tm]], acc1, 0, 0, 0);
+                    }
                 }
-                const float dist = fmaf(-2.0f, d0 + d1, cbsq[code] + oxs);
-                if (dist < ob) { ob = dist; oi = code; }
-            }
+                // codes ascend with (tile, r): a strict < keeps the lowest index among equal distances
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const float tb = __shfl_xor(ob, o); const int ti = __shfl_xor(oi, o);
-                if (tb < ob || (tb == ob && ti < oi)) { ob = tb; oi = ti; }
+                for (int r = 0; r < 16; ++r) {
+                    const int cl = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float dist = fmaf(-2.0f, acc0[r], cbsq[cl] + xs);
+                    if (dist < best) { best = dist; bidx = cl; }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cl = ct * 32 + 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float dist = fmaf(-2.0f, acc1[r], cbsq[cl] + xs);
+                    if (dist < best) { best = dist; bidx = cl; }
+                }
             }
-            if (l31 == rl) { best = ob; bidx = oi; }
+            const float ob = __shfl_xor(best, 32);
+            const int oi = __shfl_xor(bidx, 32);
+            if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
         }
         if (half == 0 && rok) idx_out[((row / P) * num + g) * (long long)P + row % P] = bidx;
         __builtin_amdgcn_wave_barrier();                                       // the lists are reused by the next tile

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round-3 profiles (run on the GPU box through gpurun): kernel traces and HBM-traffic PMC passes of the two legs of the bench step.
+# usage: bash scratch/profile_r03.sh   -> gpurun_out/prof/r03_*.txt|json (copy the summaries into profiles/)
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+OUT=gpurun_out/prof; mkdir -p $OUT
+for wl in vqvae dsfvt; do
+  CMD="python scratch/bench_leg.py $wl 8 3"
+  rocprofv3 --kernel-trace --output-format rocpd -d /tmp/kt_$wl -- $CMD > /tmp/kt_$wl.log 2>&1
+  python scratch/prof_summary.py $(find /tmp/kt_$wl -name "*.db" | head -1) $OUT/r03_${wl}_kernel_stats.txt \
+    "rocprofv3 --kernel-trace -- $CMD ($wl train step of bench.py x (3 warm-up + 8); round 3)" > /dev/null
+  CMD="python scratch/bench_leg.py $wl 3 1"
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format rocpd -d /tmp/pf_$wl -- $CMD > /tmp/pf_$wl.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format rocpd -d /tmp/pw_$wl -- $CMD > /tmp/pw_$wl.log 2>&1
+  python scratch/pmc_summary.py $(find /tmp/pf_$wl -name "*.db" | head -1) $(find /tmp/pw_$wl -name "*.db" | head -1) \
+    $OUT/r03_${wl}_pmc_hbm_traffic.txt $OUT/r03_${wl}_pmc_hbm_traffic.json 4 \
+    "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- $CMD ($wl train step; 1 + 3 steps; round 3)" > /dev/null
+done
+ls -la $OUT/r03_*
+head -32 $OUT/r03_vqvae_kernel_stats.txt | cut -c1-70,97-170
+head -40 $OUT/r03_dsfvt_kernel_stats.txt | cut -c1-70,97-170
