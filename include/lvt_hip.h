@@ -45,6 +45,9 @@ int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long lon
  *       against fp64 is not larger than the fp32 instruction's (tests/test_gpu_engine.py::test_math_modes_accuracy).
  *   LVT_MATH_F32 "f32": plain v_mfma_f32_32x32x2_f32.                                                          */
 #define LVT_MATH_F32   (1 << 16)
+/* lvt_vq_nearest only: coarse-then-exact search (one bf16 MFMA pass + exact re-evaluation of the codes inside the error band;
+ * same exact argmin).  Faster on well-separated codebooks, slower on degenerate ones: opt-in, see csrc/vq.hip.            */
+#define LVT_VQ_COARSE  (1 << 17)
 
 /* ---- epilogue flags shared by GEMM / conv ------------------------------------------------------ */
 #define LVT_EPI_BIAS        1   /* + bias[n]                                                  */

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(VQ_THREADS) void lvt_vq_nearest_half_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// Coarse-then-exact search (round 3; default arithmetic).  Nothing forces a full-precision scan of all 512 codes:
+// Coarse-then-exact search (round 3; opt-in per call: LVT_VQ_COARSE in `flags`).  Nothing forces a full-precision scan of all 512 codes:
 //   1. COARSE: score~_k = x~ . e~_k - |e_k|^2 / 2 with x~ = bf16(x), e~ = bf16(e): ONE bf16 MFMA per 16 dims instead of the
 //      six of the exact split (the -|e|^2/2 term rides in as the fp32 initial accumulator).  RNE bf16 has a relative error of
 //      at most 2^-9 per operand, so |score~_k - score_k| <= eps = (2^-8 + 2^-18) sum_d |x_d e_kd| <= 1.001 * 2^-8 |x| |e_k|.
@@ -264,6 +264,10 @@ __global__ __launch_bounds__(VQ_THREADS) void lvt_vq_nearest_half_kernel(
 //      is implementation-defined in the reference as well (tests/util_models.py:margin_ok).
 // The whole codebook group fits as one bf16 plane (72 KB): one workgroup per (group, row range), no half / merge passes, and
 // the indices are written directly in their final layout.
+// Measured (1x MI355X, 512 frames): 176 us on well-separated codebooks against 190 us for the full scan -- the MFMA count fell 3x
+// but the band test costs ~25 k vector instructions per wave, which is the new bound -- and 410-520 us on the DEGENERATE codebook
+// of a freshly initialised EMA quantiser (|e| ~ 500-1000 against |x| ~ 0.1: every row's band holds 150-250 codes, every tile
+// takes the exhaustive path).  The full scan does not depend on the data, so it stays the default.
 // ------------------------------------------------------------------------------------------------
 #define VQC_LD (VQ_D + 8)              // plane row stride (bf16): 144 B, conflict-free 16-byte fragment reads
 #define VQC_MAXC 8                     // candidates kept per (row, half-wave); measured: 1.3-1.6 per ROW on average, > 8 per half ~never
@@ -682,8 +686,7 @@ extern "C" int lvt_vq_nearest(const float *z, long long rows, int ldz, int num, 
     LVT_REQUIRE(rows > 0 && num > 0 && P > 0 && rows % P == 0, "vq_nearest: bad rows/P");
     LVT_REQUIRE(ldz % 4 == 0 && ldz >= num * D && lvt_aligned16(z) && lvt_aligned16(codebooks),
                 "vq_nearest: alignment / ldz");
-    static const int no_coarse = getenv("LVT_VQ_FULL_SCAN") ? 1 : 0;        // A/B switch: the full bf16x3 scan of round 1
-    if (!(flags & LVT_MATH_F32) && !no_coarse) {
+    if (!(flags & LVT_MATH_F32) && (flags & LVT_VQ_COARSE)) {
         const long long need_ = lvt_cdiv((rows + 31) / 32, VQ_THREADS / 64);
         int bpp = LVT_NUM_CU / num;                     // one workgroup per CU (LDS-bound)
         if (bpp > need_) bpp = (int)need_;

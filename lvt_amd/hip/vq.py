@@ -1,11 +1,18 @@
 """Typed wrappers over the vector-quantiser kernels (csrc/vq.hip)."""
+import os
+
 import torch
 
 from . import binding as L
 
 
-def nearest(z, codebooks, P):
-    """z (rows, ldz) channels-last, codebooks (num, K, D) -> idx int64 (rows/P, num, P)."""
+VQ_COARSE = 1 << 17          # include/lvt_hip.h: LVT_VQ_COARSE
+_COARSE_DEFAULT = bool(os.environ.get("LVT_VQ_COARSE"))
+
+
+def nearest(z, codebooks, P, coarse=None):
+    """z (rows, ldz) channels-last, codebooks (num, K, D) -> idx int64 (rows/P, num, P).
+    coarse=True: the coarse-then-exact search (same exact argmin; opt-in, see csrc/vq.hip for when it pays)."""
     L.require(z, codebooks)
     rows, ldz = z.shape
     num, K, D = codebooks.shape
@@ -13,7 +20,7 @@ def nearest(z, codebooks, P):
     lib = L.lib()
     nws = lib.lvt_vq_nearest_workspace_bytes(rows, num, K)
     ws = L.workspace(nws, z.device, "vq_nearest")
-    L.check(lib.lvt_vq_nearest(L.ptr(z), rows, ldz, num, D, K, L.ptr(codebooks), L.ptr(idx), P, L.math_flag(),
+    L.check(lib.lvt_vq_nearest(L.ptr(z), rows, ldz, num, D, K, L.ptr(codebooks), L.ptr(idx), P, L.math_flag() | (VQ_COARSE if (coarse if coarse is not None else _COARSE_DEFAULT) else 0),
                                L.ptr(ws), nws, L.stream_ptr()), "lvt_vq_nearest")
     return idx
 

@@ -262,3 +262,29 @@ def test_encode_roundtrip_properties_full_batch():
         zq = model.codebook(lat.view(-1, 4, 16, 16)[:64], "emb").permute(0, 3, 1, 2).contiguous()
         again = model.codebook(zq)
         assert torch.equal(again, lat.view(-1, 4, 16, 16)[:64])
+
+
+def test_vq_nearest_coarse_then_exact_search():
+    """The opt-in coarse-then-exact search (LVT_VQ_COARSE: one bf16 MFMA pass, exact fp32 re-evaluation of the codes inside the
+    error band, exhaustive tile fallback when the band is dense) returns the exact argmin: against an fp64 search on rows
+    with a clear margin, lowest index on exact ties, and on a degenerate codebook (hundreds of identical dead codes)."""
+    from lvt_amd.hip import vq
+    torch.manual_seed(1)
+    z = torch.randn(40 * 256 + 0, 256)
+    for name, cb in (("normal", torch.randn(4, 512, 64)), ("init", (torch.rand(4, 512, 64) * 2 - 1) / 512),
+                     ("dead codes", torch.cat([torch.randn(4, 100, 64) * 300, torch.zeros(4, 412, 64)], 1))):
+        idx = vq.nearest(z.to(DEV), cb.to(DEV), 256, coarse=True).cpu()             # (40, 4, 256)
+        full = vq.nearest(z.to(DEV), cb.to(DEV), 256, coarse=False).cpu()
+        for g in range(4):
+            rows = z[:, 64 * g:64 * g + 64]
+            ok = margin_ok(rows, cb[g]).view(40, 256)
+            d0, d1, ref = O.vq_margin_fp64(rows, cb[g])
+            assert torch.equal(idx[:, g][ok], ref.view(40, 256)[ok]), (name, g)
+            assert torch.equal(full[:, g][ok], ref.view(40, 256)[ok]), (name, g)
+        if name == "dead codes":        # x ~ N(0,1) is nearest to the zero code: the FIRST of the 412 identical ones
+            assert int((idx != 100).sum()) == 0 and int((full != 100).sum()) == 0
+    cb = torch.randn(512, 64)
+    cb[300] = cb[17]; cb[511] = cb[17]
+    zt = cb[[17, 300, 5, 511]].repeat(64, 4).contiguous()
+    idx = vq.nearest(zt.to(DEV), torch.stack([cb] * 4).to(DEV), 256, coarse=True).cpu()
+    assert idx[0, 0, :4].tolist() == [17, 17, 5, 17]
