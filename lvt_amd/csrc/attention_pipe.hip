@@ -27,6 +27,7 @@
 // Causal layers skip the chunks that are entirely above the diagonal; inside the remaining chunks the masked elements are
 // computed and filled (exp(fill - m) == 0 exactly, P == 0 makes dS == 0), so the pipelined blocks contain no branches.
 #include "attn_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -326,6 +327,222 @@ __global__ __launch_bounds__(256, 1) void lvt_attn_fwd_planes_kernel(const Plane
         attn_fwd_body<BT, BH, BW, MASKED, 2>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X);
     else
         attn_fwd_body<BT, BH, BW, MASKED, 4>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X);
+}
+
+// =====================================================================================================================
+// forward, 16-query tiles: EIGHT waves per workgroup (two per SIMD) on v_mfma_f32_16x16x32_bf16
+// =====================================================================================================================
+// The 32-query kernel above needs ~370 registers per wave (the 32 x 256 score tile alone is 128 accumulators), so one wave
+// per SIMD: every LDS / HBM round trip and every barrier is exposed (profiles/r03_attention_instruction_mix.txt).  With
+// 16 x 16 tiles a wave owns 16 queries: 64 score accumulators + 32 output accumulators, ~200 registers, and the same
+// 128-query workgroup is eight waves = two per SIMD that cover each other's waits.  Operand layouts of the 16x16x32 MFMA:
+// A / B: lane (row or column = lane & 15, k block = lane >> 4) holds 8 consecutive k; C: lane (column = lane & 15, row block
+// = lane >> 4) holds rows 4 * block + 0..3.  The key order of a P^T B operand built from two score tiles is
+// {tile0: 4 kg + 0..3, tile1: 4 kg + 0..3}; the transposing read of V fetches the same rows.  BW == 16 geometries.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define A16_LD 144                       // row pitch (bf16): 288 B -- conflict-free for the 16-row ds_read_b128 AND the tr reads
+#define A16_PL (AT_KC * A16_LD)
+#define A16_SLOT (3 * A16_PL)            // 55296 B
+#define A16_NG 6                         // 16-byte units per thread and chunk (512 threads)
+struct G6 { u32x4 v[A16_NG]; };
+__device__ __forceinline__ void a16_load(G6 &g, const unsigned short *base, long long ps, long long ld, int tid) {
+    static_for<A16_NG>([&](auto ic) {
+        constexpr int idx = decltype(ic)::value, pl = idx >> 1, j = idx & 1;
+        const int u = tid + 512 * j;
+        g.v[idx] = *reinterpret_cast<const u32x4 *>(base + pl * ps + (long long)(u >> 4) * ld + (u & 15) * 8);
+    });
+}
+template <int U0, int N>
+__device__ __forceinline__ void a16_park(const G6 &g, unsigned short *slot, int tid) {
+    static_for<N>([&](auto ic) {
+        constexpr int idx = U0 + decltype(ic)::value, pl = idx >> 1;
+        const int u = tid + 512 * (idx & 1);
+        *reinterpret_cast<u32x4 *>(slot + pl * A16_PL + (u >> 4) * A16_LD + (u & 15) * 8) = g.v[idx];
+    });
+}
+
+template <int BT, int BH, int MASKED, int NCH>
+__device__ __forceinline__ void attn_fwd16_body(const PlaneArgs pa, int H, float inv_temper, const float *__restrict__ dt,
+                                                const float *__restrict__ dh, const float *__restrict__ dw, float fill,
+                                                float *__restrict__ P, float *__restrict__ o, unsigned short *X) {
+    constexpr int BW = 16;
+    static_assert(BT * BH * BW == AT_S, "256 tokens");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, kg = lane >> 4;
+    const int bh_ = ap_pair(blockIdx.x), qhalf = ap_half(blockIdx.x);
+    const int b = bh_ / H, h = bh_ % H;
+    const int hd = H * AT_D;
+    const long long row0 = (long long)b * AT_S;
+    const int i = qhalf * 128 + wave * 16 + c16;                      // this lane's query (accumulator column)
+    const unsigned short *kbase = pa.k + row0 * hd + h * AT_D, *vbase = pa.v + row0 * hd + h * AT_D;
+    constexpr int NIT = 2 * NCH;
+
+    G6 g0, g1;
+    auto load_item = [&](int t, G6 &gg) {
+        a16_load(gg, (t < NCH ? kbase : vbase) + (long long)((t < NCH ? t : t - NCH) * AT_KC) * hd, pa.ps, hd, tid);
+    };
+    load_item(0, g0);
+    load_item(1, g1);
+    // the wave's queries as B operands: lane (query c16, k block kg) holds d = 32 s + 8 kg .. + 7
+    bf16x8 qb[AT_D / 32][3];
+    {
+        const unsigned short *qrow = pa.q + (row0 + i) * hd + h * AT_D;
+#pragma unroll
+        for (int s = 0; s < AT_D / 32; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) qb[s][pl] = *reinterpret_cast<const bf16x8 *>(qrow + pl * pa.ps + 32 * s + 8 * kg);
+    }
+    // bias of (query i, key j = 16 T + 4 kg + r): t and h classes of the key are compile-time per tile (BW == 16: key / 16 == T),
+    // the w class is 4 kg + r: four per-lane table entries
+    const int wi = i % BW, hi = (i / BW) % BH, ti = i / (BW * BH);
+    float bt_[BT], bh__[BH], bw_[4];
+#pragma unroll
+    for (int x = 0; x < BT; ++x) bt_[x] = dt[h * (2 * BT - 1) + ti - x + BT - 1];
+#pragma unroll
+    for (int x = 0; x < BH; ++x) bh__[x] = dh[h * (2 * BH - 1) + hi - x + BH - 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bw_[r] = dw[h * (2 * BW - 1) + wi - (4 * kg + r) + BW - 1];
+    a16_park<0, A16_NG>(g0, X, tid);
+    __syncthreads();
+
+    f32x4v st[AT_S / 16];
+#pragma unroll
+    for (int T = 0; T < AT_S / 16; ++T) st[T] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    float m_run = -3.4e38f, mc[NCH], sumc[NCH];
+    float cmax = -3.4e38f, csum = 0.f;
+    // online softmax of chunk c (tiles 4c .. 4c+3: 16 scores per lane) in 4 pieces, spread over the 4 k-steps of the next chunk
+    auto softmax_piece = [&](auto cc, auto pc) {
+        constexpr int c = decltype(cc)::value, piece = decltype(pc)::value;
+        if constexpr (piece < 2) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                constexpr int dummy = 0; (void)dummy;
+                const int T = 4 * c + 2 * piece + tt;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = st[T][r] * inv_temper + ((bt_[T / BH] + bh__[T % BH]) + bw_[r]);
+                    if (MASKED && 16 * T + 4 * kg + r > i) x = fill;
+                    st[T][r] = x;
+                    cmax = fmaxf(cmax, x);
+                }
+            }
+        }
+        if constexpr (piece == 2) {
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+            m_run = fmaxf(m_run, cmax);
+            mc[c] = m_run;
+            cmax = -3.4e38f;
+            csum = 0.f;
+        }
+        if constexpr (piece >= 2) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int T = 4 * c + 2 * (piece - 2) + tt;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float ex = __expf(st[T][r] - m_run); st[T][r] = ex; csum += ex; }
+            }
+        }
+        if constexpr (piece == 3) sumc[c] = csum;
+    };
+
+    // ---------------- phase 1: S^T = K Q^T ----------------
+    static_for<NCH>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const unsigned short *cur = X + (t & 1) * A16_SLOT;
+        unsigned short *nxt = X + ((t + 1) & 1) * A16_SLOT;
+        if constexpr (t + 2 < NIT) load_item(t + 2, AP_G(t));
+        static_for<AT_D / 32>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            bf16x8 a[4][3];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    a[kt][pl] = *reinterpret_cast<const bf16x8 *>(cur + pl * A16_PL + (kt * 16 + c16) * A16_LD + 32 * s + 8 * kg);
+            if constexpr (s < 3) a16_park<2 * s, 2>(AP_G(t + 1), nxt, tid);
+#pragma unroll
+            for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+                    st[4 * t + kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kt][AT_TA(tm)], qb[s][AT_TB(tm)], st[4 * t + kt], 0, 0, 0);
+            if constexpr (t > 0) softmax_piece(IC<t - 1>{}, sc);
+        });
+        __syncthreads();
+    });
+    static_for<4>([&](auto pc) { softmax_piece(IC<NCH - 1>{}, pc); });
+    {
+        float total = 0.f, corr[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { corr[c] = __expf(mc[c] - m_run); total += sumc[c] * corr[c]; }
+        total += __shfl_xor(total, 16, 64);
+        total += __shfl_xor(total, 32, 64);
+        const float inv = 1.f / total;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const float f = corr[c] * inv;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) st[4 * c + kt] *= f;
+        }
+    }
+
+    // ---------------- phase 2: O^T = V^T P^T ----------------
+    f32x4v oacc[AT_D / 16];
+#pragma unroll
+    for (int dtile = 0; dtile < AT_D / 16; ++dtile) oacc[dtile] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    float *prow = P + (((long long)b * H + h) * AT_S + i) * AT_S + 4 * kg;
+    static_for<NCH>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, t = NCH + c;
+        const unsigned short *cur = X + (t & 1) * A16_SLOT;
+        unsigned short *nxt = X + ((t + 1) & 1) * A16_SLOT;
+        if constexpr (t + 2 < NIT) load_item(t + 2, AP_G(t));
+        static_for<2>([&](auto pc) {                                  // key pair: tiles T0, T0 + 1 (32 keys) of the chunk
+            constexpr int pr = decltype(pc)::value, T0 = 4 * c + 2 * pr;
+            bf16x8 pb[3];
+            at_split8(make_float4(st[T0][0], st[T0][1], st[T0][2], st[T0][3]),
+                      make_float4(st[T0 + 1][0], st[T0 + 1][1], st[T0 + 1][2], st[T0 + 1][3]), pb[0], pb[1], pb[2]);
+            *reinterpret_cast<f32x4v *>(prow + 16 * T0) = st[T0];
+            *reinterpret_cast<f32x4v *>(prow + 16 * (T0 + 1)) = st[T0 + 1];
+            static_for<2>([&](auto hc) {                              // d tiles 4 hq .. 4 hq + 3
+                constexpr int hq = decltype(hc)::value;
+                bf16x8 a[4][3];
+#pragma unroll
+                for (int dq = 0; dq < 4; ++dq) {
+                    const unsigned short *p0 = cur + (32 * pr + 4 * kg + (c16 >> 2)) * A16_LD + (4 * hq + dq) * 16 + 4 * (c16 & 3);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[dq][pl] = ap_tr(p0 + pl * A16_PL, 16 * A16_LD);
+                }
+                if constexpr (t + 1 < NIT && hq == 0) a16_park<3 * pr, 3>(AP_G(t + 1), nxt, tid);
+#pragma unroll
+                for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+                    for (int dq = 0; dq < 4; ++dq)
+                        oacc[4 * hq + dq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[dq][AT_TA(tm)], pb[AT_TB(tm)], oacc[4 * hq + dq], 0, 0, 0);
+            });
+        });
+        __syncthreads();
+    });
+    if (NCH < AT_S / AT_KC) {
+#pragma unroll
+        for (int T = 4 * NCH; T < AT_S / 16; ++T) *reinterpret_cast<f32x4v *>(prow + 16 * T) = f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
+    {
+        float *orow = o + (row0 + i) * hd + h * AT_D + 4 * kg;
+#pragma unroll
+        for (int dtile = 0; dtile < AT_D / 16; ++dtile) *reinterpret_cast<f32x4v *>(orow + 16 * dtile) = oacc[dtile];
+    }
+}
+
+template <int BT, int BH, int MASKED>
+__global__ __launch_bounds__(512, 1) void lvt_attn_fwd16_planes_kernel(const PlaneArgs pa, int H, float inv_temper,
+                                                                       const float *__restrict__ dt, const float *__restrict__ dh,
+                                                                       const float *__restrict__ dw, float fill,
+                                                                       float *__restrict__ P, float *__restrict__ o) {
+    __shared__ __attribute__((aligned(16))) unsigned short X[2 * A16_SLOT];
+    if (MASKED && ap_half(blockIdx.x) == 0)
+        attn_fwd16_body<BT, BH, MASKED, 2>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X);
+    else
+        attn_fwd16_body<BT, BH, MASKED, 4>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X);
 }
 
 // =====================================================================================================================
@@ -648,6 +865,309 @@ __global__ __launch_bounds__(256, 1) void lvt_attn_bwd_b_kernel(const PlaneArgs 
     else attn_bwd_b_body<0, 4>(pa, dop, H, P, dS, dk, dv, X);
 }
 
+// =====================================================================================================================
+// backward on 16-wide tiles (eight waves per workgroup, two per SIMD): A16 = dS, dQ, bank sums; B16 = dV, dK.  BW == 16.
+// =====================================================================================================================
+template <int BT, int BH, int MASKED, int NCH>
+__device__ __forceinline__ void attn_bwd_a16_body(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
+                                                  float inv_temper, const float *__restrict__ P, const float *__restrict__ o,
+                                                  float *__restrict__ dS, float *__restrict__ dq, float *__restrict__ bank_partial,
+                                                  unsigned short *X) {
+    constexpr int BW = 16;
+    static_assert(BT * BH * BW == AT_S, "256 tokens");
+    using BI = BankIdx<BT, BH, BW>;
+    constexpr int NR = BT + BH + 4;                                   // per-lane class sums: t classes, h classes, w = 4 kg + r
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, kg = lane >> 4;
+    const int bh_ = ap_pair(blockIdx.x), qhalf = ap_half(blockIdx.x);
+    const int b = bh_ / H, h = bh_ % H;
+    const int hd = H * AT_D;
+    const long long row0 = (long long)b * AT_S;
+    const int il = wave * 16 + c16, i = qhalf * 128 + il;
+    const unsigned short *kbase = pa.k + row0 * hd + h * AT_D, *vbase = pa.v + row0 * hd + h * AT_D;
+    constexpr int NIT = 2 * NCH;                                      // V chunks (by rows), then K chunks (transposed)
+
+    G6 g0, g1;
+    auto load_item = [&](int t, G6 &gg) {
+        a16_load(gg, (t < NCH ? vbase : kbase) + (long long)((t < NCH ? t : t - NCH) * AT_KC) * hd, pa.ps, hd, tid);
+    };
+    load_item(0, g0);
+    load_item(1, g1);
+    bf16x8 dob[AT_D / 32][3];
+    float delta = 0.f;
+    {
+        const unsigned short *drow = dop + (row0 + i) * hd + h * AT_D;
+        const float *orow = o + (row0 + i) * hd + h * AT_D + 8 * kg;
+#pragma unroll
+        for (int s = 0; s < AT_D / 32; ++s) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) dob[s][pl] = *reinterpret_cast<const bf16x8 *>(drow + pl * pa.ps + 32 * s + 8 * kg);
+            const float4 o0 = *reinterpret_cast<const float4 *>(orow + 32 * s), o1 = *reinterpret_cast<const float4 *>(orow + 32 * s + 4);
+            const float ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+            uint4 u[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) u[pl] = *reinterpret_cast<const uint4 *>(&dob[s][pl]);
+            const unsigned w[3][4] = {{u[0].x, u[0].y, u[0].z, u[0].w}, {u[1].x, u[1].y, u[1].z, u[1].w}, {u[2].x, u[2].y, u[2].z, u[2].w}};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float d = 0.f;
+#pragma unroll
+                for (int pl = 2; pl >= 0; --pl)
+                    d += (e & 1) ? __uint_as_float(w[pl][e >> 1] & 0xffff0000u) : __uint_as_float(w[pl][e >> 1] << 16);
+                delta = fmaf(d, ov[e], delta);
+            }
+        }
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
+    }
+    a16_park<0, A16_NG>(g0, X, tid);
+    __syncthreads();
+
+    f32x4v st[AT_S / 16];
+#pragma unroll
+    for (int T = 0; T < AT_S / 16; ++T) st[T] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const float *prow = P + (((long long)b * H + h) * AT_S + i) * AT_S + 4 * kg;
+    float *dsrow = dS + (((long long)b * H + h) * AT_S + i) * AT_S + 4 * kg;
+    f32x4v pv[4];                          // P of a chunk: slot k is consumed by piece k during step c+1 and refilled right after
+    auto ds_piece = [&](auto cc, auto pc, const f32x4v p4) {
+        constexpr int T = 4 * decltype(cc)::value + decltype(pc)::value;
+        f32x4v ds;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ds[e] = p4[e] * (st[T][e] - delta) * inv_temper;
+        st[T] = ds;
+        *reinterpret_cast<f32x4v *>(dsrow + 16 * T) = ds;
+    };
+
+    // ---------------- phase 1: dP^T = V dO^T ----------------
+    static_for<NCH>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const unsigned short *cur = X + (t & 1) * A16_SLOT;
+        unsigned short *nxt = X + ((t + 1) & 1) * A16_SLOT;
+        if constexpr (t + 2 < NIT) load_item(t + 2, AP_G(t));
+        static_for<AT_D / 32>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            bf16x8 a[4][3];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    a[kt][pl] = *reinterpret_cast<const bf16x8 *>(cur + pl * A16_PL + (kt * 16 + c16) * A16_LD + 32 * s + 8 * kg);
+            if constexpr (s < 3) a16_park<2 * s, 2>(AP_G(t + 1), nxt, tid);
+#pragma unroll
+            for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+                    st[4 * t + kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kt][AT_TA(tm)], dob[s][AT_TB(tm)], st[4 * t + kt], 0, 0, 0);
+            if constexpr (t > 0) ds_piece(IC<t - 1>{}, sc, pv[s]);
+            pv[s] = *reinterpret_cast<const f32x4v *>(prow + 16 * (4 * t + s));
+        });
+        __syncthreads();
+    });
+    static_for<4>([&](auto pc) { ds_piece(IC<NCH - 1>{}, pc, pv[decltype(pc)::value]); });
+    if (NCH < AT_S / AT_KC) {
+#pragma unroll
+        for (int T = 4 * NCH; T < AT_S / 16; ++T) *reinterpret_cast<f32x4v *>(dsrow + 16 * T) = f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
+    // per-lane class sums of dS (g = dS * temper): key 16 T + 4 kg + r has t class T / BH, h class T % BH, w class 4 kg + r
+    float rsum[NR];
+#pragma unroll
+    for (int x = 0; x < NR; ++x) rsum[x] = 0.f;
+    static_for<4 * NCH>([&](auto Tc) {
+        constexpr int T = decltype(Tc)::value;
+        const float tot = (st[T][0] + st[T][1]) + (st[T][2] + st[T][3]);
+        rsum[T / BH] += tot;
+        rsum[BT + T % BH] += tot;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rsum[BT + BH + r] += st[T][r];
+    });
+
+    // ---------------- phase 2: dQ^T = K^T dS^T ----------------
+    f32x4v oacc[AT_D / 16];
+#pragma unroll
+    for (int dtile = 0; dtile < AT_D / 16; ++dtile) oacc[dtile] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    static_for<NCH>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, t = NCH + c;
+        const unsigned short *cur = X + (t & 1) * A16_SLOT;
+        unsigned short *nxt = X + ((t + 1) & 1) * A16_SLOT;
+        if constexpr (t + 2 < NIT) load_item(t + 2, AP_G(t));
+        static_for<2>([&](auto pc) {
+            constexpr int pr = decltype(pc)::value, T0 = 4 * c + 2 * pr;
+            bf16x8 pb[3];
+            at_split8(make_float4(st[T0][0], st[T0][1], st[T0][2], st[T0][3]),
+                      make_float4(st[T0 + 1][0], st[T0 + 1][1], st[T0 + 1][2], st[T0 + 1][3]), pb[0], pb[1], pb[2]);
+            static_for<2>([&](auto hc) {
+                constexpr int hq = decltype(hc)::value;
+                bf16x8 a[4][3];
+#pragma unroll
+                for (int dq_ = 0; dq_ < 4; ++dq_) {
+                    const unsigned short *p0 = cur + (32 * pr + 4 * kg + (c16 >> 2)) * A16_LD + (4 * hq + dq_) * 16 + 4 * (c16 & 3);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[dq_][pl] = ap_tr(p0 + pl * A16_PL, 16 * A16_LD);
+                }
+                if constexpr (t + 1 < NIT && hq == 0) a16_park<3 * pr, 3>(AP_G(t + 1), nxt, tid);
+#pragma unroll
+                for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+                    for (int dq_ = 0; dq_ < 4; ++dq_)
+                        oacc[4 * hq + dq_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[dq_][AT_TA(tm)], pb[AT_TB(tm)], oacc[4 * hq + dq_], 0, 0, 0);
+            });
+        });
+        __syncthreads();
+    });
+    {
+        float *qrow = dq + (row0 + i) * hd + h * AT_D + 4 * kg;
+#pragma unroll
+        for (int dtile = 0; dtile < AT_D / 16; ++dtile) *reinterpret_cast<f32x4v *>(qrow + 16 * dtile) = oacc[dtile];
+    }
+    // ---- bias-bank gradient of this (sample, head, query half): two fixed-order stages through LDS ----
+    float *R = reinterpret_cast<float *>(X);                          // [128 queries][4 kg][NR]
+    float *R2 = R + 128 * 4 * NR;                                     // [8 parts][NB]
+    {
+        const float temper = 1.f / inv_temper;
+        float *mine = R + (il * 4 + kg) * NR;
+#pragma unroll
+        for (int x = 0; x < NR; ++x) mine[x] = rsum[x] * temper;
+    }
+    __syncthreads();
+    {
+        const int e = tid & 63, part = tid >> 6;                      // entry, 16-query part
+        if (e < BI::NB) {
+            float acc = 0.f;
+            for (int q = 16 * part; q < 16 * part + 16; ++q) {
+                const int iq = qhalf * 128 + q;
+                const int wi = iq % BW, hi = (iq / BW) % BH, ti = iq / (BW * BH);
+                const float *r = R + (q * 4) * NR;
+                if (e < BI::NT) {
+                    const int tj = ti - e + BT - 1;
+                    if (tj >= 0 && tj < BT) acc += (r[tj] + r[NR + tj]) + (r[2 * NR + tj] + r[3 * NR + tj]);
+                } else if (e < BI::NT + BI::NH) {
+                    const int hj = hi - (e - BI::NT) + BH - 1;
+                    if (hj >= 0 && hj < BH) acc += (r[BT + hj] + r[NR + BT + hj]) + (r[2 * NR + BT + hj] + r[3 * NR + BT + hj]);
+                } else {
+                    const int wj = wi - (e - BI::NT - BI::NH) + BW - 1;
+                    if (wj >= 0 && wj < BW) acc += r[(wj >> 2) * NR + BT + BH + (wj & 3)];
+                }
+            }
+            R2[part * BI::NB + e] = acc;
+        }
+    }
+    __syncthreads();
+    if (tid < BI::NB) {
+        float acc = 0.f;
+#pragma unroll
+        for (int part = 0; part < 8; ++part) acc += R2[part * BI::NB + tid];
+        bank_partial[((long long)bh_ * 2 + qhalf) * BI::NB + tid] = acc;
+    }
+}
+
+template <int BT, int BH, int MASKED>
+__global__ __launch_bounds__(512, 1) void lvt_attn_bwd_a16_kernel(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
+                                                                  float inv_temper, const float *__restrict__ P,
+                                                                  const float *__restrict__ o, float *__restrict__ dS,
+                                                                  float *__restrict__ dq, float *__restrict__ bank_partial) {
+    __shared__ __attribute__((aligned(16))) unsigned short X[2 * A16_SLOT];
+    if (MASKED && ap_half(blockIdx.x) == 0)
+        attn_bwd_a16_body<BT, BH, MASKED, 2>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X);
+    else
+        attn_bwd_a16_body<BT, BH, MASKED, 4>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X);
+}
+
+template <int C0, int NCH>
+__device__ __forceinline__ void attn_bwd_b16_body(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
+                                                  const float *__restrict__ P, const float *__restrict__ dS,
+                                                  float *__restrict__ dk, float *__restrict__ dv, unsigned short *X) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, kg = lane >> 4;
+    const int bh_ = ap_pair(blockIdx.x), khalf = ap_half(blockIdx.x);
+    const int b = bh_ / H, h = bh_ % H;
+    const int hd = H * AT_D;
+    const long long row0 = (long long)b * AT_S;
+    const int kb = khalf * 128 + wave * 16;                           // first key of this wave
+    const unsigned short *qbase = pa.q + row0 * hd + h * AT_D, *dobase = dop + row0 * hd + h * AT_D;
+    constexpr int NIT = 2 * NCH;                                      // dO chunk, Q chunk, dO chunk, ...
+
+    G6 g0, g1;
+    auto load_item = [&](int t, G6 &gg) {
+        a16_load(gg, ((t & 1) ? qbase : dobase) + (long long)((C0 + (t >> 1)) * AT_KC) * hd, pa.ps, hd, tid);
+    };
+    // B fragments from P (even items) / dS (odd items): lane (key c16, kg), k slots j < 4: query 32 s + 4 kg + j,
+    // j >= 4: query 32 s + 16 + 4 kg + (j - 4)  (the row blocks the transposing reads of dO / Q fetch)
+    const float *pcol = P + (((long long)b * H + h) * AT_S) * AT_S + kb + c16;
+    const float *dscol = dS + (((long long)b * H + h) * AT_S) * AT_S + kb + c16;
+    float bf0[16], bf1[16];
+#define AP_BF(t) ((((t) & 1) == 0) ? bf0 : bf1)
+    auto load_b = [&](int t, float (&ff)[16]) {
+        const float *src = ((t & 1) ? dscol : pcol) + (long long)((C0 + (t >> 1)) * AT_KC + 4 * kg) * AT_S;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ff[8 * s + j] = src[(long long)(32 * s + 16 * (j >> 2) + (j & 3)) * AT_S];
+    };
+    load_item(0, g0);
+    load_item(1, g1);
+    load_b(0, bf0);
+    a16_park<0, A16_NG>(g0, X, tid);
+    __syncthreads();
+
+    f32x4v accv[AT_D / 16], acck[AT_D / 16];
+#pragma unroll
+    for (int dtile = 0; dtile < AT_D / 16; ++dtile) { accv[dtile] = f32x4v{0.f, 0.f, 0.f, 0.f}; acck[dtile] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+
+    static_for<NIT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const unsigned short *cur = X + (t & 1) * A16_SLOT;
+        unsigned short *nxt = X + ((t + 1) & 1) * A16_SLOT;
+        if constexpr (t + 2 < NIT) load_item(t + 2, AP_G(t));
+        if constexpr (t + 1 < NIT) load_b(t + 1, AP_BF(t + 1));
+        static_for<2>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            bf16x8 pb[3];
+            const float (&ff)[16] = AP_BF(t);
+            at_split8(make_float4(ff[8 * s + 0], ff[8 * s + 1], ff[8 * s + 2], ff[8 * s + 3]),
+                      make_float4(ff[8 * s + 4], ff[8 * s + 5], ff[8 * s + 6], ff[8 * s + 7]), pb[0], pb[1], pb[2]);
+            static_for<2>([&](auto hc) {
+                constexpr int hq = decltype(hc)::value;
+                bf16x8 a[4][3];
+#pragma unroll
+                for (int dq_ = 0; dq_ < 4; ++dq_) {
+                    const unsigned short *p0 = cur + (32 * s + 4 * kg + (c16 >> 2)) * A16_LD + (4 * hq + dq_) * 16 + 4 * (c16 & 3);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[dq_][pl] = ap_tr(p0 + pl * A16_PL, 16 * A16_LD);
+                }
+                if constexpr (t + 1 < NIT && hq == 0) a16_park<3 * s, 3>(AP_G(t + 1), nxt, tid);
+#pragma unroll
+                for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+                    for (int dq_ = 0; dq_ < 4; ++dq_) {
+                        if constexpr ((t & 1) == 0)
+                            accv[4 * hq + dq_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[dq_][AT_TA(tm)], pb[AT_TB(tm)], accv[4 * hq + dq_], 0, 0, 0);
+                        else
+                            acck[4 * hq + dq_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[dq_][AT_TA(tm)], pb[AT_TB(tm)], acck[4 * hq + dq_], 0, 0, 0);
+                    }
+            });
+        });
+        __syncthreads();
+    });
+#undef AP_BF
+    {
+        float *vrow = dv + (row0 + kb + c16) * hd + h * AT_D + 4 * kg, *krow = dk + (row0 + kb + c16) * hd + h * AT_D + 4 * kg;
+#pragma unroll
+        for (int dtile = 0; dtile < AT_D / 16; ++dtile) {
+            *reinterpret_cast<f32x4v *>(vrow + 16 * dtile) = accv[dtile];
+            *reinterpret_cast<f32x4v *>(krow + 16 * dtile) = acck[dtile];
+        }
+    }
+}
+
+template <int MASKED>
+__global__ __launch_bounds__(512, 1) void lvt_attn_bwd_b16_kernel(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
+                                                                  const float *__restrict__ P, const float *__restrict__ dS,
+                                                                  float *__restrict__ dk, float *__restrict__ dv) {
+    __shared__ __attribute__((aligned(16))) unsigned short X[2 * A16_SLOT];
+    if (MASKED && ap_half(blockIdx.x) == 1) attn_bwd_b16_body<2, 2>(pa, dop, H, P, dS, dk, dv, X);
+    else attn_bwd_b16_body<0, 4>(pa, dop, H, P, dS, dk, dv, X);
+}
+
 // bank gradients: out[h][e] = sum over (sample, query half) of the workgroup partials, in a fixed order
 __global__ void lvt_attn_bank_reduce_kernel(const float *__restrict__ partial, int B, int H, int NB, int nt, int nh,
                                             float *__restrict__ ddt, float *__restrict__ ddh, float *__restrict__ ddw) {
@@ -683,6 +1203,12 @@ extern "C" int lvt_attn_fwd_planes(const void *qkv_planes, long long plane_strid
     const dim3 grid((unsigned)(B * H * 2)), blk(256);
     hipStream_t s = (hipStream_t)stream;
     const float it = 1.f / temper;
+    if (bt == 1 && bh == 16 && bw == 16 && !getenv("LVT_ATTN_FWD32")) {          // 16-query tiles, two waves per SIMD
+        if (masked) hipLaunchKernelGGL((lvt_attn_fwd16_planes_kernel<1, 16, 1>), grid, dim3(512), 0, s, pa, H, it, dt, dh, dw, fill, P, o);
+        else hipLaunchKernelGGL((lvt_attn_fwd16_planes_kernel<1, 16, 0>), grid, dim3(512), 0, s, pa, H, it, dt, dh, dw, fill, P, o);
+        LVT_CHECK_LAUNCH("lvt_attn_fwd16_planes_kernel");
+        return LVT_OK;
+    }
 #define LVT_X(BT, BH, BW)                                                                                                          \
     if (bt == BT && bh == BH && bw == BW) {                                                                                        \
         if (masked) hipLaunchKernelGGL((lvt_attn_fwd_planes_kernel<BT, BH, BW, 1>), grid, blk, 0, s, pa, H, it, dt, dh, dw, fill, P, o); \
@@ -719,6 +1245,18 @@ extern "C" int lvt_attn_bwd_planes(const void *qkv_planes, long long plane_strid
     const dim3 grid((unsigned)(B * H * 2)), blk(256);
     hipStream_t s = (hipStream_t)stream;
     const float it = 1.f / temper;
+    if (bt == 1 && bh == 16 && bw == 16 && !getenv("LVT_ATTN_FWD32")) {          // 16-wide tiles, two waves per SIMD
+        if (masked) hipLaunchKernelGGL((lvt_attn_bwd_a16_kernel<1, 16, 1>), grid, dim3(512), 0, s, pa, dop, H, it, P, o, dS, dq, partial);
+        else hipLaunchKernelGGL((lvt_attn_bwd_a16_kernel<1, 16, 0>), grid, dim3(512), 0, s, pa, dop, H, it, P, o, dS, dq, partial);
+        LVT_CHECK_LAUNCH("lvt_attn_bwd_a16_kernel");
+        if (masked) hipLaunchKernelGGL((lvt_attn_bwd_b16_kernel<1>), grid, dim3(512), 0, s, pa, dop, H, P, dS, dk, dv);
+        else hipLaunchKernelGGL((lvt_attn_bwd_b16_kernel<0>), grid, dim3(512), 0, s, pa, dop, H, P, dS, dk, dv);
+        LVT_CHECK_LAUNCH("lvt_attn_bwd_b16_kernel");
+        hipLaunchKernelGGL(lvt_attn_bank_reduce_kernel, dim3((unsigned)lvt_cdiv((long long)H * nb, 64)), dim3(64), 0, s, partial, B, H, nb,
+                           nt, nh, ddt, ddh, ddw);
+        LVT_CHECK_LAUNCH("lvt_attn_bank_reduce_kernel");
+        return LVT_OK;
+    }
 #define LVT_X(BT, BH, BW)                                                                                                          \
     if (bt == BT && bh == BH && bw == BW) {                                                                                        \
         if (masked) hipLaunchKernelGGL((lvt_attn_bwd_a_kernel<BT, BH, BW, 1>), grid, blk, 0, s, pa, dop, H, it, P, o, dS, dq, partial); \

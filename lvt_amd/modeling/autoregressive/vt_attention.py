@@ -123,12 +123,24 @@ def linear_wgrad(dy, x, n_out, k_in, rows, want_bias=False):
 
 CAUSAL_SKIP = not os.environ.get("LVT_NO_CAUSAL_SKIP")      # A/B switch of the causal reductions in the backward products
 FUSED_ATTENTION = True      # scores + bias + mask + softmax + P.V in one launch when the block is 256 tokens x 128 dims
-# q / k / v / dO as bf16x3 planes into the software-pipelined attention kernels (csrc/attention_pipe.hip): forward and the
-# whole core backward (dQ, dK, dV, bank gradients) as three fused launches.  Same results (tests/test_gpu_vt.py), but on
-# one MI355X it is NOT faster than the default path at the DSFVT shape -- forward 175 vs 176 us, backward 520 vs 480 us per
-# layer: both are bound by the P / dS round trips through HBM (2.1-3.8 TB/s measured) with one wave per SIMD, see
-# DESIGN.md section 3 -- so it is opt-in: LVT_PLANE_ATTENTION=1.
-PLANE_ATTENTION = bool(os.environ.get("LVT_PLANE_ATTENTION"))
+# q / k / v / dO as bf16x3 planes into the pipelined attention kernels (csrc/attention_pipe.hip): forward and the whole core
+# backward (dQ, dK, dV, bank gradients) as three fused launches.  For the (1, 16, 16) block of DSFVT / KDSFVT the 16-wide-tile
+# kernels (eight waves per workgroup, two per SIMD) take 147 + 184 + 151 us per layer against 176 + 480 us for the round-2
+# path (fused forward, four batched GEMMs + softmax-bwd + bank kernel): that geometry uses them by default.  The 32-query
+# plane kernels that serve the other geometries ((4, 8, 8): DSSVT / DSTSVT) are not faster than the round-2 path (one wave
+# per SIMD), so those stay on it unless LVT_PLANE_ATTENTION=1.  LVT_NO_PLANE_ATTENTION=1: round-2 path
+# everywhere.  None = decide per geometry; True / False force (tests).
+PLANE_ATTENTION = None
+
+
+def _use_planes(S, da, block, pairs):
+    if os.environ.get("LVT_NO_PLANE_ATTENTION") or PLANE_ATTENTION is False:
+        return False
+    if not tx.attn_planes_supported(S, da, block, pairs):
+        return False
+    if PLANE_ATTENTION is True or os.environ.get("LVT_PLANE_ATTENTION"):
+        return True
+    return tuple(block)[2] == 16          # the 16-wide-tile kernels exist for BW == 16 geometries
 
 
 class _BlockLocalAttentionFn(torch.autograd.Function):
@@ -144,7 +156,7 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         temper = math.sqrt(da)
         dev = x.device
         xn, mean1, rstd1 = ew.layernorm_fwd(x, ln_w, ln_b)
-        planes = FUSED_ATTENTION and PLANE_ATTENTION and tx.attn_planes_supported(S, da, block, b * na)
+        planes = FUSED_ATTENTION and _use_planes(S, da, block, b * na)
         if planes:
             # q, k, v of all heads in ONE launch whose epilogue writes them as their exact 3-way bf16 split (3 operands x
             # 3 planes x (M, hd)): the operand format of the pipelined attention kernels, which then stage by copying

@@ -9,7 +9,7 @@ for masked in (False, True):
     layer = A.BlockLocalAttention((1, 16, 16), 128, 512, 8, masked=masked).to(dev)
     x = torch.randn(64 * 256, 512, device=dev)
     gy = torch.randn_like(x)
-    for _ in range(6):
+    for _ in range(30):
         xx = x.clone().requires_grad_(True)
         layer.forward_tokens(xx, layer.block_size).backward(gy)
     torch.cuda.synchronize()
