@@ -85,8 +85,8 @@ class _SumEvaluator(DatasetEvaluator):
 
     def _totals(self):
         if self._acc is None:                 # a rank that saw no sample still takes part in the all-reduce
-            dev = "cuda" if (self._distributed and torch.cuda.is_available() and
-                             torch.distributed.get_backend() == "nccl") else "cpu"
+            dist_on = self._distributed and torch.distributed.is_available() and torch.distributed.is_initialized()
+            dev = "cuda" if (dist_on and torch.cuda.is_available() and torch.distributed.get_backend() == "nccl") else "cpu"
             self._acc = torch.zeros(2, dtype=torch.float64, device=dev)
         acc = self._acc.clone()
         if self._distributed:

@@ -88,7 +88,7 @@ class MultiHeadAttention(nn.Module):
         buf = getattr(self, "_wqkv", None)
         n = self.w_q.numel()
         if (buf is None or buf.device != self.w_q.device or
-                any(w.data_ptr() != buf.data_ptr() + 4 * n * i for i, w in enumerate(ws))):
+                any(w.data_ptr() != buf.data_ptr() + buf.element_size() * n * i for i, w in enumerate(ws))):
             with torch.no_grad():
                 buf = torch.stack([w.detach() for w in ws], 0).contiguous()
                 for i, w in enumerate(ws):

@@ -13,10 +13,12 @@ class _ConvStackFn(torch.autograd.Function):
     back at once."""
 
     @staticmethod
-    def forward(ctx, x, layers, *flat):
+    def forward(ctx, x, layers, layers_grad, *flat):
+        # layers_grad: torch.is_grad_enabled() at the CALL site (inside forward autograd has already switched it off, and
+        # needs_input_grad is True for parameters even under torch.no_grad()): eval passes skip the backward weight layouts
         params = [(flat[2 * i], flat[2 * i + 1]) for i in range(len(layers))]
         with torch.no_grad():
-            outs, saved = convnet.stack_forward(layers, x, params, want_grad=any(ctx.needs_input_grad))
+            outs, saved = convnet.stack_forward(layers, x, params, want_grad=layers_grad and any(ctx.needs_input_grad))
         ctx.layers, ctx.saved, ctx.outs, ctx.x = layers, saved, outs, x
         ctx.shapes = [tuple(p.shape) for p in flat]
         return outs[-1]
@@ -32,12 +34,12 @@ class _ConvStackFn(torch.autograd.Function):
             flat.append(dw.view(ctx.shapes[2 * i]))
             flat.append(db.contiguous().view(ctx.shapes[2 * i + 1]))
         ctx.outs = ctx.saved = None
-        return (gx, None) + tuple(flat)
+        return (gx, None, None) + tuple(flat)
 
 
 def run_stack(x_cl, layers, params):
     flat = [t for wb in params for t in wb]
-    return _ConvStackFn.apply(x_cl, layers, *flat)
+    return _ConvStackFn.apply(x_cl, layers, torch.is_grad_enabled(), *flat)
 
 
 def nchw_to_cl(x, cpad=None):
