@@ -661,14 +661,23 @@ __device__ __forceinline__ TileCtx lvt_tile_ctx(const KParams &p) {
     // panel, and the neighbouring m tiles that share im2col halo rows / the same image, then hit the same L2.
     const int ntn = (p.N + BN - 1) / BN;
     int wg = blockIdx.x;
-    {
+    t.split = blockIdx.z;
+    if (p.splits > 1 && gridDim.y == 1 && (gridDim.z & 7) == 0) {
+        // split-K of a few tiles (the weight gradients dW = dY^T X: 16 tiles x 32 k ranges): ALL tiles of one k range read the
+        // same rows of both operands, so a k range is given to ONE XCD (the dispatcher walks x, then z: linear id L -> XCD
+        // L % 8) and its tiles share the panels through that L2.  With the per-dimension remap below every XCD held two
+        // tiles of every k range and fetched 4-5x the algorithmic bytes (profiles/r02_dsfvt_pmc_hbm_traffic.txt).
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.z;
+        const unsigned xcd = lin & 7, slot = lin >> 3;
+        t.split = (int)(xcd + 8 * (slot / gridDim.x));
+        wg = (int)(slot % gridDim.x);
+    } else {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
         const int xcd = wg & 7, slot = wg >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
     t.n0 = (wg % ntn) * BN; t.m0 = (wg / ntn) * BM;
     t.z = blockIdx.y;                   // batch (or conv phase class)
-    t.split = blockIdx.z;
     t.A = p.A; t.B = p.B; t.coff = 0; t.cls = 0;
     if (AMODE == A_CONVT_K) {
         t.cls = t.z;
