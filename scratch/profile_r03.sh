@@ -19,3 +19,14 @@ done
 ls -la $OUT/r03_*
 head -32 $OUT/r03_vqvae_kernel_stats.txt | cut -c1-70,97-170
 head -40 $OUT/r03_dsfvt_kernel_stats.txt | cut -c1-70,97-170
+python - <<PY
+import json
+v=json.load(open("$OUT/r03_vqvae_pmc_hbm_traffic.json")); d=json.load(open("$OUT/r03_dsfvt_pmc_hbm_traffic.json"))
+# one bench step = 2 VQ-VAE train steps + 1 DSFVT train step; both passes ran 1 + 3 steps
+vb=(2*v["fetch_KiB_raw"]+v["write_KiB"])*1024/v["steps"]; db=(2*d["fetch_KiB_raw"]+d["write_KiB"])*1024/d["steps"]
+vl=v["engine_launches"]/v["steps"]; dl=d["engine_launches"]/d["steps"]
+json.dump({"hbm_bytes_per_launch": (2*vb+db)/(2*vl+dl), "engine_launches_per_step": 2*vl+dl, "hbm_bytes_per_step": 2*vb+db,
+           "note": "combined bench step = 2 x r03_vqvae_pmc_hbm_traffic.json + 1 x r03_dsfvt_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes)"},
+          open("$OUT/r03_combined_pmc_hbm_traffic.json","w"), indent=1)
+print(open("$OUT/r03_combined_pmc_hbm_traffic.json").read())
+PY
