@@ -5,29 +5,34 @@
 // instructions per wave (768 MFMAs), 2600 are the 3-way bf16 split of K, V, Q and P, and K / V are split again by every
 // workgroup and every kernel that stages them (profiles/r03_attention_instruction_mix.txt).  Here q, k, v and dO are split
 // ONCE, by the epilogue of the GEMM that produces them (LVT_EPI_PLANES), and travel as three bf16 planes:
-//   * staging a chunk is a copy (16-byte global loads -> ds_write_b128), no arithmetic;
+//   * staging a chunk is a copy (16-byte global loads -> ds_write_b128) into a two-slot LDS ring: while the MFMAs of step t
+//     read slot t & 1 the chunk of step t+1 is copied into the other slot (one barrier per step) and the global loads of
+//     step t+2 are in flight (two register sets);
 //   * the B operands that live in registers (the wave's queries / dO rows) are loaded in fragment layout, no arithmetic;
 //   * operands that are needed TRANSPOSED (V^T in O^T = V^T P^T, K^T in dQ^T = K^T dS^T, dO^T and Q^T in the dK / dV
-//     products) are staged row-major and fetched with the gfx950 transposing LDS read (ds_read_b64_tr_b16), so the
-//     register transposes of the old kernel are gone as well.
-// What is left on the vector pipe is the softmax (or the dS algebra) and the split of the probabilities / dS that leave the
-// accumulators as B operands -- about 3 vector instructions per MFMA -- and it is placed BESIDE matrix work:
-//   * two-slot LDS ring: while the MFMAs of step t read slot t & 1 the chunk of step t+1 is copied into the other slot (one
-//     barrier per step), the global loads of step t+2 are in flight (two register sets);
-//   * ONLINE softmax per 64-key chunk (running maximum, per-chunk correction factor, one multiply per element at the end):
-//     the scores of chunk c are finished while the MFMAs of chunk c+1 run; the dS algebra of the backward pass needs only
-//     delta_i = sum_d dO[i][d] O[i][d], known before the first product, and is chunk-wise in the same way.
-// One wave per SIMD (the accumulators of a 32-query x 256-key tile are 128 registers), 4 waves per workgroup; the register
-// file pays for double buffers instead of occupancy.
+//     products) are staged by rows and fetched with the gfx950 transposing LDS read (ds_read_b64_tr_b16);
+//   * the softmax is ONLINE per 64-key chunk (running maximum, per-chunk correction factor, one multiply per element at the
+//     end): the scores of chunk c are finished while the MFMAs of chunk c+1 run; the dS algebra of the backward pass needs
+//     only delta_i = sum_d dO[i][d] O[i][d], known before the first product, and is chunk-wise in the same way.
+//
+// Tiling: 16-wide tiles on v_mfma_f32_16x16x32_bf16.  A first version used 32 x 32 x 16 tiles, one wave = 32 queries x 256
+// keys = 128 score accumulators, ~370 registers, ONE wave per SIMD -- and was no faster than the unfused path although it
+// removed two thirds of the vector instructions: with one wave per SIMD nothing covers a memory or LDS round trip (SQ: 64 %
+// of the wave cycles in issue stalls, matrix pipe 29 % busy).  With 16 x 16 tiles a wave owns 16 queries (64 score + 32
+// output accumulators, 190-250 registers), a 128-query workgroup is EIGHT waves = two per SIMD, and the same staging serves
+// the same number of queries: forward 176 -> 147 us, backward ~410 -> 184 + 151 us per layer at the DSFVT shape.
+// Operand layouts of the 16x16x32 MFMA: A / B: lane (row or column = lane & 15, k block kg = lane >> 4) holds 8 consecutive
+// k; C: lane (column = lane & 15, row block = lane >> 4) holds rows 4 kg + 0..3.  A P^T / dS^T B operand built from two
+// score tiles has the key order {tile0: 4 kg + 0..3, tile1: 4 kg + 0..3}; the transposing read fetches the same rows.
 //
 // Backward = two kernels over the saved P:
-//   A (one wave = 32 queries): dP^T = V dO^T -> dS = P o (dP - delta) / temper -> dS to HBM, dQ^T = K^T dS^T, and the
-//     bias-bank gradient of this (sample, head, query half) from the registers (fixed-order reduction through LDS);
-//   B (one wave = 32 keys):    dV^T = dO^T P, dK^T = Q^T dS over the queries, P / dS fragments read in B-operand layout.
+//   A (one wave = 16 queries): dP^T = V dO^T -> dS = P o (dP - delta) / temper -> dS to HBM, dQ^T = K^T dS^T, and the
+//     bias-bank gradient of this (sample, head, query half) from the registers (two fixed-order stages through LDS);
+//   B (one wave = 16 keys):    dV^T = dO^T P, dK^T = Q^T dS over the queries, P / dS fragments read in B-operand layout,
+// and a fixed-order reduction of the per-workgroup bank sums (no atomics).
 // Causal layers skip the chunks that are entirely above the diagonal; inside the remaining chunks the masked elements are
 // computed and filled (exp(fill - m) == 0 exactly, P == 0 makes dS == 0), so the pipelined blocks contain no branches.
 #include "attn_common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -40,42 +45,8 @@ template <int N, int I = 0, class F> __device__ __forceinline__ void static_for(
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // (HIP's uint4 is a struct of unions and is not promoted to registers)
 
-#define AP_LDR 136                       // row pitch (bf16) of a chunk read by rows:      272 B, conflict-free ds_read_b128
-#define AP_LDT 160                       // row pitch (bf16) of a chunk read transposed:   320 B = 16 banks mod 64 (tr reads)
-#define AP_SLOT (3 * AT_KC * AP_LDT)     // ring slot (bf16 elements): 61440 B, holds either layout
-#define AP_NG 12                         // 16-byte units per thread and chunk (3 planes x 64 rows x 256 B / 256 threads)
-
-// ---- staging: a chunk of 64 rows x 128 columns x 3 planes, global bf16 planes -> LDS rows of pitch LD -------------------
-// (the register sets are structs of named members addressed through compile-time indices: an array indexed inside loops is
-// not promoted to registers by the compiler and ends up in scratch memory)
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // (HIP's uint4 is a struct of unions and is not promoted either)
-struct G12 { u32x4 v[AP_NG]; };
-__device__ __forceinline__ void ap_load(G12 &g, const unsigned short *base, long long ps, long long ld, int tid) {
-    static_for<AP_NG>([&](auto ic) {
-        constexpr int idx = decltype(ic)::value, pl = idx >> 2, j = idx & 3;
-        const int u = tid + 256 * j;
-        g.v[idx] = *reinterpret_cast<const u32x4 *>(base + pl * ps + (long long)(u >> 4) * ld + (u & 15) * 8);
-    });
-}
-template <int LD, int IDX>
-__device__ __forceinline__ void ap_park1(const G12 &g, unsigned short *slot, int tid) {
-    constexpr int pl = IDX >> 2;
-    const int u = tid + 256 * (IDX & 3);
-    *reinterpret_cast<u32x4 *>(slot + pl * (AT_KC * LD) + (u >> 4) * LD + (u & 15) * 8) = g.v[IDX];
-}
-// units [U0, U0 + N) of a chunk
-template <int LD, int U0, int N>
-__device__ __forceinline__ void ap_park(const G12 &g, unsigned short *slot, int tid) {
-    static_for<N>([&](auto ic) { ap_park1<LD, U0 + decltype(ic)::value>(g, slot, tid); });
-}
-// A fragment by rows: rows tile*32 + l31, k = 16 s + 8 half .. + 7
-template <int LD>
-__device__ __forceinline__ void ap_frag_rows(bf16x8 (&a)[3], const unsigned short *slot, int tile, int s, int l31, int half) {
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-        a[pl] = *reinterpret_cast<const bf16x8 *>(slot + pl * (AT_KC * LD) + (tile * 32 + l31) * LD + 16 * s + 8 * half);
-}
 // A fragment TRANSPOSED (the reduction index is the LDS row): lane column ctile*32 + l31, k slots = rows r0 .. r0+3 and
 // r1 .. r1+3.  Lane li of a 16-lane group supplies the address of row (li >> 2), columns 4 (li & 3) .. +3 of its group's
 // [4 rows][16 columns] block and receives column li, rows 0..3 (scratch/ubench/tr_probe.hip).
@@ -87,26 +58,7 @@ __device__ __forceinline__ bf16x8 ap_tr(const unsigned short *p, int hi_off) {
     return u.v;
 }
 // accumulator order (B operand straight from a 32x32 accumulator tile): slots e = rows kt*32 + 16 s2 + 4 half + (e & 3) + 8 (e >> 2)
-__device__ __forceinline__ void ap_frag_tr_acc(bf16x8 (&a)[3], const unsigned short *slot, int ctile, int kt, int s2, int lane) {
-    const int li = lane & 15, g1 = (lane >> 4) & 1, half = lane >> 5;
-    const unsigned short *p = slot + (kt * 32 + 16 * s2 + 4 * half + (li >> 2)) * AP_LDT + ctile * 32 + 16 * g1 + 4 * (li & 3);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) a[pl] = ap_tr(p + pl * (AT_KC * AP_LDT), 8 * AP_LDT);
-}
-// natural order: slots e = rows 16 s + 8 half + e
-__device__ __forceinline__ void ap_frag_tr(bf16x8 (&a)[3], const unsigned short *slot, int ctile, int s, int lane) {
-    const int li = lane & 15, g1 = (lane >> 4) & 1, half = lane >> 5;
-    const unsigned short *p = slot + (16 * s + 8 * half + (li >> 2)) * AP_LDT + ctile * 32 + 16 * g1 + 4 * (li & 3);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) a[pl] = ap_tr(p + pl * (AT_KC * AP_LDT), 4 * AP_LDT);
-}
-// the wave's rows as B operands, straight from the planes: lane (l31, half) holds columns 16 s + 8 half .. + 7 of row i
-__device__ __forceinline__ void ap_load_b(bf16x8 (&bq)[AT_D / 16][3], const unsigned short *rowp, long long ps, int half) {
-#pragma unroll
-    for (int s = 0; s < AT_D / 16; ++s)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bq[s][pl] = *reinterpret_cast<const bf16x8 *>(rowp + pl * ps + 16 * s + 8 * half);
-}
+
 
 // Workgroup x runs on XCD x % 8 and every XCD has its own L2: the two halves of one (sample, head) stage the same K / V (or
 // Q / dO) chunks, so they are given block ids 8 apart -- same XCD, dispatched back to back -- and the second reads from L2.
@@ -114,231 +66,16 @@ __device__ __forceinline__ void ap_load_b(bf16x8 (&bq)[AT_D / 16][3], const unsi
 __device__ __forceinline__ int ap_pair(unsigned x) { return (int)(((x >> 4) << 3) | (x & 7)); }
 __device__ __forceinline__ int ap_half(unsigned x) { return (int)((x >> 3) & 1); }
 
-template <int BT, int BH, int BW> struct BiasTab {
-    float t[BT], h[BH], w[BW / 2];
-    // key coordinates are compile-time per accumulator register; only the +4*half of the key index is per lane and for
-    // BW % 8 == 0 it never carries out of the w coordinate, so it is folded into the w table
-    __device__ __forceinline__ void init(const float *dt, const float *dh, const float *dw, int head, int i, int half) {
-        const int wi = i % BW, hi = (i / BW) % BH, ti = i / (BW * BH);
-#pragma unroll
-        for (int x = 0; x < BT; ++x) t[x] = dt[head * (2 * BT - 1) + ti - x + BT - 1];
-#pragma unroll
-        for (int x = 0; x < BH; ++x) h[x] = dh[head * (2 * BH - 1) + hi - x + BH - 1];
-#pragma unroll
-        for (int x = 0; x < BW / 2; ++x) w[x] = dw[head * (2 * BW - 1) + wi - ((x & 3) + 8 * (x >> 2) + 4 * half) + BW - 1];
-    }
-    __device__ __forceinline__ void zero() {
-#pragma unroll
-        for (int x = 0; x < BT; ++x) t[x] = 0.f;
-#pragma unroll
-        for (int x = 0; x < BH; ++x) h[x] = 0.f;
-#pragma unroll
-        for (int x = 0; x < BW / 2; ++x) w[x] = 0.f;
-    }
-    static __device__ __forceinline__ constexpr int tj(int T, int r) { return (32 * T + (r & 3) + 8 * (r >> 2)) / (BW * BH); }
-    static __device__ __forceinline__ constexpr int hj(int T, int r) { return ((32 * T + (r & 3) + 8 * (r >> 2)) / BW) % BH; }
-    static __device__ __forceinline__ constexpr int wx(int T, int r) {
-        const int wc = (32 * T + (r & 3) + 8 * (r >> 2)) % BW;
-        return (wc & 3) + 4 * (wc >> 3);
-    }
-    __device__ __forceinline__ float at(int T, int r) const { return (t[tj(T, r)] + h[hj(T, r)]) + w[wx(T, r)]; }
-    __device__ __forceinline__ void add(int T, int r, float g) { t[tj(T, r)] += g; h[hj(T, r)] += g; w[wx(T, r)] += g; }
-};
-
 struct PlaneArgs {
     const unsigned short *q, *k, *v;     // plane 0 of each operand, token-major (M, hd)
     long long ps;                        // plane stride (elements)
 };
 
-// =====================================================================================================================
-// forward
-// =====================================================================================================================
-template <int BT, int BH, int BW, int MASKED, int NCH>
-__device__ __forceinline__ void attn_fwd_body(const PlaneArgs pa, int H, float inv_temper, const float *__restrict__ dt,
-                                              const float *__restrict__ dh, const float *__restrict__ dw, float fill,
-                                              float *__restrict__ P, float *__restrict__ o, unsigned short *X) {
-    static_assert(BW % 8 == 0 && BT * BH * BW == AT_S, "compile-time geometry: BW % 8 == 0, 256 tokens");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int bh_ = ap_pair(blockIdx.x), qhalf = ap_half(blockIdx.x);
-    const int b = bh_ / H, h = bh_ % H;
-    const int hd = H * AT_D;
-    const long long row0 = (long long)b * AT_S;
-    const int i = qhalf * 128 + wave * 32 + l31;                      // this lane's query (accumulator column)
-    const unsigned short *kbase = pa.k + row0 * hd + h * AT_D, *vbase = pa.v + row0 * hd + h * AT_D;
-    constexpr int NIT = 2 * NCH;                                      // staged items: K chunks 0..NCH-1, then V chunks
+template <int BT, int BH, int BW> struct BankIdx {
+    static constexpr int NT = 2 * BT - 1, NH = 2 * BH - 1, NW = 2 * BW - 1, NB = NT + NH + NW, NR = BT + BH + BW / 2;
+};
 
-    G12 g0, g1;
-    auto load_item = [&](int t, G12 &gg) {                            // t compile-time at every call site
-        ap_load(gg, (t < NCH ? kbase : vbase) + (long long)((t < NCH ? t : t - NCH) * AT_KC) * hd, pa.ps, hd, tid);
-    };
 
-    load_item(0, g0);
-    load_item(1, g1);
-    bf16x8 qb[AT_D / 16][3];
-    ap_load_b(qb, pa.q + (row0 + i) * hd + h * AT_D, pa.ps, half);
-    BiasTab<BT, BH, BW> bias;
-    bias.init(dt, dh, dw, h, i, half);
-    ap_park<AP_LDR, 0, AP_NG>(g0, X, tid);
-    __syncthreads();
-
-    f32x16 st[AT_S / 32];
-#pragma unroll
-    for (int T = 0; T < AT_S / 32; ++T)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[T][r] = 0.f;
-    float m_run = -3.4e38f, mc[NCH], sumc[NCH];
-
-    // online softmax of chunk c in 8 pieces (spread over the 8 k-steps of the next chunk's MFMAs): pieces 0..3 scale / bias /
-    // mask 8 scores each and track the chunk maximum, piece 4 folds it into the running maximum, pieces 4..7 exponentiate
-    float cmax = -3.4e38f, csum = 0.f;
-    auto softmax_piece = [&](int c, int piece) {
-        if (piece < 4) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int T = 2 * c + (piece >> 1), r = 8 * (piece & 1) + e;
-                float x = st[T][r] * inv_temper + bias.at(T, r);
-                if (MASKED && 32 * T + (r & 3) + 8 * (r >> 2) + 4 * half > i) x = fill;
-                st[T][r] = x;
-                cmax = fmaxf(cmax, x);
-            }
-        }
-        if (piece == 4) {
-            cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
-            m_run = fmaxf(m_run, cmax);
-            mc[c] = m_run;
-            cmax = -3.4e38f;
-            csum = 0.f;
-        }
-        if (piece >= 4) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int T = 2 * c + ((piece - 4) >> 1), r = 8 * ((piece - 4) & 1) + e;
-                const float ex = __expf(st[T][r] - m_run);
-                st[T][r] = ex;
-                csum += ex;
-            }
-        }
-        if (piece == 7) sumc[c] = csum;
-    };
-
-    // ---------------- phase 1: S^T = K Q^T, one 64-key chunk per step ----------------
-    static_for<NCH>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        const unsigned short *cur = X + (t & 1) * AP_SLOT;
-        unsigned short *nxt = X + ((t + 1) & 1) * AP_SLOT;
-        if constexpr (t + 2 < NIT) load_item(t + 2, AP_G(t));
-        static_for<AT_D / 16>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            bf16x8 a[2][3];
-            ap_frag_rows<AP_LDR>(a[0], cur, 0, s, l31, half);
-            ap_frag_rows<AP_LDR>(a[1], cur, 1, s, l31, half);
-            if constexpr (t + 1 < NCH) {
-                ap_park<AP_LDR, s, 1>(AP_G(t + 1), nxt, tid);
-                if constexpr (s < AP_NG - 8) ap_park<AP_LDR, 8 + s, 1>(AP_G(t + 1), nxt, tid);
-            } else {
-                ap_park<AP_LDT, s, 1>(AP_G(t + 1), nxt, tid);
-                if constexpr (s < AP_NG - 8) ap_park<AP_LDT, 8 + s, 1>(AP_G(t + 1), nxt, tid);
-            }
-#pragma unroll
-            for (int tm = 0; tm < 6; ++tm)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-                    st[2 * t + kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kt][AT_TA(tm)], qb[s][AT_TB(tm)], st[2 * t + kt], 0, 0, 0);
-            if constexpr (t > 0) softmax_piece(t - 1, s);
-        });
-        __syncthreads();
-    });
-    static_for<8>([&](auto pc) { softmax_piece(NCH - 1, decltype(pc)::value); });
-    {   // P = e_c * exp(m_c - m_final) / sum
-        float total = 0.f, corr[NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) { corr[c] = __expf(mc[c] - m_run); total += sumc[c] * corr[c]; }
-        total += __shfl_xor(total, 32, 64);
-        const float inv = 1.f / total;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const float f = corr[c] * inv;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[2 * c + kt][r] *= f;
-        }
-    }
-
-    // ---------------- phase 2: O^T = V^T P^T (V staged by rows, fetched transposed) ----------------
-    f32x16 oacc[AT_D / 32];
-#pragma unroll
-    for (int dtile = 0; dtile < AT_D / 32; ++dtile)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[dtile][r] = 0.f;
-    float *prow = P + (((long long)b * H + h) * AT_S + i) * AT_S + 4 * half;
-    static_for<NCH>([&](auto cc) {
-        constexpr int c = decltype(cc)::value, t = NCH + c;
-        const unsigned short *cur = X + (t & 1) * AP_SLOT;
-        unsigned short *nxt = X + ((t + 1) & 1) * AP_SLOT;
-        if constexpr (t + 2 < NIT) load_item(t + 2, AP_G(t));
-        static_for<4>([&](auto gc) {
-            constexpr int grp = decltype(gc)::value, kt = grp >> 1, s2 = grp & 1, T = 2 * c + kt;
-            bf16x8 pb[3];
-            at_split8(make_float4(st[T][8 * s2 + 0], st[T][8 * s2 + 1], st[T][8 * s2 + 2], st[T][8 * s2 + 3]),
-                      make_float4(st[T][8 * s2 + 4], st[T][8 * s2 + 5], st[T][8 * s2 + 6], st[T][8 * s2 + 7]),
-                      pb[0], pb[1], pb[2]);
-            bf16x8 a[AT_D / 32][3];
-#pragma unroll
-            for (int dtile = 0; dtile < AT_D / 32; ++dtile) ap_frag_tr_acc(a[dtile], cur, dtile, kt, s2, lane);
-            if constexpr (t + 1 < NIT) ap_park<AP_LDT, (AP_NG / 4) * grp, AP_NG / 4>(AP_G(t + 1), nxt, tid);
-#pragma unroll
-            for (int tm = 0; tm < 6; ++tm)
-#pragma unroll
-                for (int dtile = 0; dtile < AT_D / 32; ++dtile)
-                    oacc[dtile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dtile][AT_TA(tm)], pb[AT_TB(tm)], oacc[dtile], 0, 0, 0);
-#pragma unroll
-            for (int gq = 2 * s2; gq < 2 * s2 + 2; ++gq)
-                *reinterpret_cast<float4 *>(prow + 32 * T + 8 * gq) =
-                    make_float4(st[T][4 * gq + 0], st[T][4 * gq + 1], st[T][4 * gq + 2], st[T][4 * gq + 3]);
-        });
-        __syncthreads();
-    });
-    if (NCH < AT_S / AT_KC) {       // causal: the key chunks that were never staged carry exactly zero probability
-#pragma unroll
-        for (int T = 2 * NCH; T < AT_S / 32; ++T)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<float4 *>(prow + 32 * T + 8 * gq) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    {
-        float *orow = o + (row0 + i) * hd + h * AT_D + 4 * half;
-#pragma unroll
-        for (int dtile = 0; dtile < AT_D / 32; ++dtile)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-                *reinterpret_cast<float4 *>(orow + 32 * dtile + 8 * gq) =
-                    make_float4(oacc[dtile][4 * gq + 0], oacc[dtile][4 * gq + 1], oacc[dtile][4 * gq + 2], oacc[dtile][4 * gq + 3]);
-    }
-}
-
-template <int BT, int BH, int BW, int MASKED>
-__global__ __launch_bounds__(256, 1) void lvt_attn_fwd_planes_kernel(const PlaneArgs pa, int H, float inv_temper,
-                                                                     const float *__restrict__ dt, const float *__restrict__ dh,
-                                                                     const float *__restrict__ dw, float fill,
-                                                                     float *__restrict__ P, float *__restrict__ o) {
-    __shared__ __attribute__((aligned(16))) unsigned short X[2 * AP_SLOT];
-    if (MASKED && ap_half(blockIdx.x) == 0)       // queries 0..127 only see keys 0..127
-        attn_fwd_body<BT, BH, BW, MASKED, 2>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X);
-    else
-        attn_fwd_body<BT, BH, BW, MASKED, 4>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X);
-}
-
-// =====================================================================================================================
-// forward, 16-query tiles: EIGHT waves per workgroup (two per SIMD) on v_mfma_f32_16x16x32_bf16
-// =====================================================================================================================
-// The 32-query kernel above needs ~370 registers per wave (the 32 x 256 score tile alone is 128 accumulators), so one wave
-// per SIMD: every LDS / HBM round trip and every barrier is exposed (profiles/r03_attention_instruction_mix.txt).  With
-// 16 x 16 tiles a wave owns 16 queries: 64 score accumulators + 32 output accumulators, ~200 registers, and the same
-// 128-query workgroup is eight waves = two per SIMD that cover each other's waits.  Operand layouts of the 16x16x32 MFMA:
-// A / B: lane (row or column = lane & 15, k block = lane >> 4) holds 8 consecutive k; C: lane (column = lane & 15, row block
-// = lane >> 4) holds rows 4 * block + 0..3.  The key order of a P^T B operand built from two score tiles is
-// {tile0: 4 kg + 0..3, tile1: 4 kg + 0..3}; the transposing read of V fetches the same rows.  BW == 16 geometries.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define A16_LD 144                       // row pitch (bf16): 288 B -- conflict-free for the 16-row ds_read_b128 AND the tr reads
 #define A16_PL (AT_KC * A16_LD)
@@ -361,11 +98,22 @@ __device__ __forceinline__ void a16_park(const G6 &g, unsigned short *slot, int 
     });
 }
 
-template <int BT, int BH, int MASKED, int NCH>
+// key j = 16 T + 4 kg + r (tile T, lane block kg, register r): for BW == 16 its coordinates are (t, h, w) = (T / HP, T % HP, 4 kg + r)
+// with HP = BH tiles per t slab; for BW == 8 a tile spans two h rows: (T / HP, 2 (T % HP) + (kg >> 1), 4 (kg & 1) + r), HP = BH / 2.
+// The t index and the h SLOT T % HP are compile-time per tile; what depends on the lane is folded into per-lane tables.
+template <int BH, int BW> struct Geo16 {
+    static_assert(BW == 16 || BW == 8, "16-wide tiles: BW is 8 or 16");
+    static constexpr int HP = BW == 16 ? BH : BH / 2;
+    static __device__ __forceinline__ int hj(int hslot, int kg) { return BW == 16 ? hslot : 2 * hslot + (kg >> 1); }
+    static __device__ __forceinline__ int wj(int r, int kg) { return BW == 16 ? 4 * kg + r : 4 * (kg & 1) + r; }
+};
+
+template <int BT, int BH, int BW, int MASKED, int NCH>
 __device__ __forceinline__ void attn_fwd16_body(const PlaneArgs pa, int H, float inv_temper, const float *__restrict__ dt,
                                                 const float *__restrict__ dh, const float *__restrict__ dw, float fill,
                                                 float *__restrict__ P, float *__restrict__ o, unsigned short *X) {
-    constexpr int BW = 16;
+    using GE = Geo16<BH, BW>;
+    constexpr int HP = GE::HP;
     static_assert(BT * BH * BW == AT_S, "256 tokens");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, kg = lane >> 4;
@@ -392,16 +140,15 @@ __device__ __forceinline__ void attn_fwd16_body(const PlaneArgs pa, int H, float
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) qb[s][pl] = *reinterpret_cast<const bf16x8 *>(qrow + pl * pa.ps + 32 * s + 8 * kg);
     }
-    // bias of (query i, key j = 16 T + 4 kg + r): t and h classes of the key are compile-time per tile (BW == 16: key / 16 == T),
-    // the w class is 4 kg + r: four per-lane table entries
+    // bias of (query i, key j = 16 T + 4 kg + r): per-lane tables over the t index, the h slot and the register (Geo16)
     const int wi = i % BW, hi = (i / BW) % BH, ti = i / (BW * BH);
-    float bt_[BT], bh__[BH], bw_[4];
+    float bt_[BT], bh__[HP], bw_[4];
 #pragma unroll
     for (int x = 0; x < BT; ++x) bt_[x] = dt[h * (2 * BT - 1) + ti - x + BT - 1];
 #pragma unroll
-    for (int x = 0; x < BH; ++x) bh__[x] = dh[h * (2 * BH - 1) + hi - x + BH - 1];
+    for (int x = 0; x < HP; ++x) bh__[x] = dh[h * (2 * BH - 1) + hi - GE::hj(x, kg) + BH - 1];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bw_[r] = dw[h * (2 * BW - 1) + wi - (4 * kg + r) + BW - 1];
+    for (int r = 0; r < 4; ++r) bw_[r] = dw[h * (2 * BW - 1) + wi - GE::wj(r, kg) + BW - 1];
     a16_park<0, A16_NG>(g0, X, tid);
     __syncthreads();
 
@@ -420,7 +167,7 @@ __device__ __forceinline__ void attn_fwd16_body(const PlaneArgs pa, int H, float
                 const int T = 4 * c + 2 * piece + tt;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float x = st[T][r] * inv_temper + ((bt_[T / BH] + bh__[T % BH]) + bw_[r]);
+                    float x = st[T][r] * inv_temper + ((bt_[T / HP] + bh__[T % HP]) + bw_[r]);
                     if (MASKED && 16 * T + 4 * kg + r > i) x = fill;
                     st[T][r] = x;
                     cmax = fmaxf(cmax, x);
@@ -533,350 +280,31 @@ __device__ __forceinline__ void attn_fwd16_body(const PlaneArgs pa, int H, float
     }
 }
 
-template <int BT, int BH, int MASKED>
+template <int BT, int BH, int BW, int MASKED>
 __global__ __launch_bounds__(512, 1) void lvt_attn_fwd16_planes_kernel(const PlaneArgs pa, int H, float inv_temper,
                                                                        const float *__restrict__ dt, const float *__restrict__ dh,
                                                                        const float *__restrict__ dw, float fill,
                                                                        float *__restrict__ P, float *__restrict__ o) {
     __shared__ __attribute__((aligned(16))) unsigned short X[2 * A16_SLOT];
     if (MASKED && ap_half(blockIdx.x) == 0)
-        attn_fwd16_body<BT, BH, MASKED, 2>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X);
+        attn_fwd16_body<BT, BH, BW, MASKED, 2>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X);
     else
-        attn_fwd16_body<BT, BH, MASKED, 4>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X);
-}
-
-// =====================================================================================================================
-// backward A: dS and dQ (one wave = 32 queries)
-// =====================================================================================================================
-template <int BT, int BH, int BW> struct BankIdx {
-    static constexpr int NT = 2 * BT - 1, NH = 2 * BH - 1, NW = 2 * BW - 1, NB = NT + NH + NW, NR = BT + BH + BW / 2;
-};
-
-template <int BT, int BH, int BW, int MASKED, int NCH>
-__device__ __forceinline__ void attn_bwd_a_body(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
-                                                float inv_temper, const float *__restrict__ P, const float *__restrict__ o,
-                                                float *__restrict__ dS, float *__restrict__ dq, float *__restrict__ bank_partial,
-                                                unsigned short *X) {
-    static_assert(BW % 8 == 0 && BT * BH * BW == AT_S, "compile-time geometry: BW % 8 == 0, 256 tokens");
-    using BI = BankIdx<BT, BH, BW>;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int bh_ = ap_pair(blockIdx.x), qhalf = ap_half(blockIdx.x);
-    const int b = bh_ / H, h = bh_ % H;
-    const int hd = H * AT_D;
-    const long long row0 = (long long)b * AT_S;
-    const int il = wave * 32 + l31, i = qhalf * 128 + il;
-    const unsigned short *kbase = pa.k + row0 * hd + h * AT_D, *vbase = pa.v + row0 * hd + h * AT_D;
-    constexpr int NIT = 2 * NCH;                                      // staged items: V chunks 0..NCH-1 (by rows), then K chunks (transposed)
-
-    // ONE register set for the staging ring here (the P tiles and the bank sums need the registers): the loads of chunk t+1
-    // are issued at the start of step t and parked at its end
-    G12 g0;
-    auto load_item = [&](int t, G12 &gg) {
-        ap_load(gg, (t < NCH ? vbase : kbase) + (long long)((t < NCH ? t : t - NCH) * AT_KC) * hd, pa.ps, hd, tid);
-    };
-    auto park_item = [&](auto tcc, const G12 &gg, unsigned short *slot) {
-        if constexpr (decltype(tcc)::value < NCH) ap_park<AP_LDR, 0, AP_NG>(gg, slot, tid); else ap_park<AP_LDT, 0, AP_NG>(gg, slot, tid);
-    };
-    load_item(0, g0);
-    // the wave's dO rows as B operands, and delta_i = sum_d dO[i][d] O[i][d] (== sum_j P[i][j] dP[i][j])
-    bf16x8 dob[AT_D / 16][3];
-    ap_load_b(dob, dop + (row0 + i) * hd + h * AT_D, pa.ps, half);
-    float delta = 0.f;
-    {
-        const float *orow = o + (row0 + i) * hd + h * AT_D + 8 * half;
-#pragma unroll
-        for (int s = 0; s < AT_D / 16; ++s) {
-            const float4 o0 = *reinterpret_cast<const float4 *>(orow + 16 * s), o1 = *reinterpret_cast<const float4 *>(orow + 16 * s + 4);
-            const float ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
-            uint4 u[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) u[pl] = *reinterpret_cast<const uint4 *>(&dob[s][pl]);
-            const unsigned w[3][4] = {{u[0].x, u[0].y, u[0].z, u[0].w}, {u[1].x, u[1].y, u[1].z, u[1].w}, {u[2].x, u[2].y, u[2].z, u[2].w}};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float d = 0.f;
-#pragma unroll
-                for (int pl = 2; pl >= 0; --pl)
-                    d += (e & 1) ? __uint_as_float(w[pl][e >> 1] & 0xffff0000u) : __uint_as_float(w[pl][e >> 1] << 16);
-                delta = fmaf(d, ov[e], delta);
-            }
-        }
-        delta += __shfl_xor(delta, 32, 64);
-    }
-    park_item(IC<0>{}, g0, X);
-    __syncthreads();
-
-    f32x16 st[AT_S / 32];
-#pragma unroll
-    for (int T = 0; T < AT_S / 32; ++T)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[T][r] = 0.f;
-    const float *prow = P + (((long long)b * H + h) * AT_S + i) * AT_S + 4 * half;
-    float *dsrow = dS + (((long long)b * H + h) * AT_S + i) * AT_S + 4 * half;
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 pv[8];                          // P of a chunk (two tiles x four 4-vectors): slot k is consumed by piece k of chunk c
-                                          // during step c+1 and refilled with chunk c+1 right after (a full step of latency cover)
-    auto load_p = [&](int c, int piece) -> f32x4 {
-        return *reinterpret_cast<const f32x4 *>(prow + 32 * (2 * c + (piece >> 2)) + 8 * (piece & 3));
-    };
-    // dS algebra of chunk c in 8 pieces (one 4-vector of P each): dS = P (dP - delta) / temper
-    auto ds_piece = [&](auto cc, auto pc, const f32x4 p4) {
-        constexpr int c = decltype(cc)::value, piece = decltype(pc)::value;
-        constexpr int kt = piece >> 2, gq = piece & 3, T = 2 * c + kt;
-        f32x4 ds;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            ds[e] = p4[e] * (st[T][4 * gq + e] - delta) * inv_temper;
-            st[T][4 * gq + e] = ds[e];
-        }
-        *reinterpret_cast<f32x4 *>(dsrow + 32 * T + 8 * gq) = ds;
-    };
-
-    // ---------------- phase 1: dP^T = V dO^T ----------------
-    static_for<NCH>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        const unsigned short *cur = X + (t & 1) * AP_SLOT;
-        unsigned short *nxt = X + ((t + 1) & 1) * AP_SLOT;
-        load_item(t + 1, g0);
-        static_for<AT_D / 16>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            bf16x8 a[2][3];
-            ap_frag_rows<AP_LDR>(a[0], cur, 0, s, l31, half);
-            ap_frag_rows<AP_LDR>(a[1], cur, 1, s, l31, half);
-#pragma unroll
-            for (int tm = 0; tm < 6; ++tm)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-                    st[2 * t + kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kt][AT_TA(tm)], dob[s][AT_TB(tm)], st[2 * t + kt], 0, 0, 0);
-            if constexpr (t > 0) ds_piece(IC<t - 1>{}, sc, pv[s]);
-            pv[s] = load_p(t, s);
-        });
-        park_item(IC<t + 1>{}, g0, nxt);
-        __syncthreads();
-    });
-    static_for<8>([&](auto pc) { ds_piece(IC<NCH - 1>{}, pc, pv[decltype(pc)::value]); });
-    BiasTab<BT, BH, BW> bank;            // per-lane sums of dS over the keys of each coordinate class
-    bank.zero();
-    // bank sums from the finished dS tiles (dO's registers are free now; accumulating them inside the pipelined steps cost
-    // 140 spilled registers): the four elements of a register group share their t and h classes (keys 8 gq .. 8 gq + 3 of a
-    // tile, BW % 8 == 0), so a class takes the group total once and every element one add for its w slot.  g = dS * temper.
-    static_for<2 * NCH>([&](auto Tc) {
-        constexpr int T = decltype(Tc)::value;
-        static_for<4>([&](auto gc) {
-            constexpr int r0 = 4 * decltype(gc)::value;
-            using BTab = BiasTab<BT, BH, BW>;
-            static_assert(BTab::tj(T, r0) == BTab::tj(T, r0 + 3) && BTab::hj(T, r0) == BTab::hj(T, r0 + 3), "group inside one (t, h) class");
-            const float tot = (st[T][r0] + st[T][r0 + 1]) + (st[T][r0 + 2] + st[T][r0 + 3]);
-            bank.t[BTab::tj(T, r0)] += tot;
-            bank.h[BTab::hj(T, r0)] += tot;
-            bank.w[BTab::wx(T, r0 + 0)] += st[T][r0 + 0];
-            bank.w[BTab::wx(T, r0 + 1)] += st[T][r0 + 1];
-            bank.w[BTab::wx(T, r0 + 2)] += st[T][r0 + 2];
-            bank.w[BTab::wx(T, r0 + 3)] += st[T][r0 + 3];
-        });
-    });
-    if (NCH < AT_S / AT_KC) {       // causal: dS of the key chunks above the diagonal is zero
-#pragma unroll
-        for (int T = 2 * NCH; T < AT_S / 32; ++T)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<float4 *>(dsrow + 32 * T + 8 * gq) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-
-    // ---------------- phase 2: dQ^T = K^T dS^T (K staged by rows, fetched transposed) ----------------
-    f32x16 oacc[AT_D / 32];
-#pragma unroll
-    for (int dtile = 0; dtile < AT_D / 32; ++dtile)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[dtile][r] = 0.f;
-    static_for<NCH>([&](auto cc) {
-        constexpr int c = decltype(cc)::value, t = NCH + c;
-        const unsigned short *cur = X + (t & 1) * AP_SLOT;
-        unsigned short *nxt = X + ((t + 1) & 1) * AP_SLOT;
-        if constexpr (t + 1 < NIT) load_item(t + 1, g0);
-        static_for<4>([&](auto gc) {
-            constexpr int grp = decltype(gc)::value, kt = grp >> 1, s2 = grp & 1, T = 2 * c + kt;
-            bf16x8 pb[3];
-            at_split8(make_float4(st[T][8 * s2 + 0], st[T][8 * s2 + 1], st[T][8 * s2 + 2], st[T][8 * s2 + 3]),
-                      make_float4(st[T][8 * s2 + 4], st[T][8 * s2 + 5], st[T][8 * s2 + 6], st[T][8 * s2 + 7]),
-                      pb[0], pb[1], pb[2]);
-            bf16x8 a[AT_D / 32][3];
-#pragma unroll
-            for (int dtile = 0; dtile < AT_D / 32; ++dtile) ap_frag_tr_acc(a[dtile], cur, dtile, kt, s2, lane);
-#pragma unroll
-            for (int tm = 0; tm < 6; ++tm)
-#pragma unroll
-                for (int dtile = 0; dtile < AT_D / 32; ++dtile)
-                    oacc[dtile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dtile][AT_TA(tm)], pb[AT_TB(tm)], oacc[dtile], 0, 0, 0);
-        });
-        if constexpr (t + 1 < NIT) park_item(IC<t + 1>{}, g0, nxt);
-        __syncthreads();
-    });
-    {
-        float *qrow = dq + (row0 + i) * hd + h * AT_D + 4 * half;
-#pragma unroll
-        for (int dtile = 0; dtile < AT_D / 32; ++dtile)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-                *reinterpret_cast<float4 *>(qrow + 32 * dtile + 8 * gq) =
-                    make_float4(oacc[dtile][4 * gq + 0], oacc[dtile][4 * gq + 1], oacc[dtile][4 * gq + 2], oacc[dtile][4 * gq + 3]);
-    }
-    // ---- bias-bank gradient of this (sample, head, query half): entry e collects the class sums whose coordinate
-    // difference selects it, queries in ascending order (fixed order: bit-reproducible, no atomics) ----
-    float *R = reinterpret_cast<float *>(X);                          // [128 queries][2 halves][NR]; the ring is free now
-    {
-        float *mine = R + (il * 2 + half) * BI::NR;
-        const float temper = 1.f / inv_temper;
-#pragma unroll
-        for (int x = 0; x < BT; ++x) mine[x] = bank.t[x] * temper;
-#pragma unroll
-        for (int x = 0; x < BH; ++x) mine[BT + x] = bank.h[x] * temper;
-#pragma unroll
-        for (int x = 0; x < BW / 2; ++x) mine[BT + BH + x] = bank.w[x] * temper;
-    }
-    __syncthreads();
-    if (tid < BI::NB) {
-        float acc = 0.f;
-        for (int q = 0; q < 128; ++q) {
-            const int iq = qhalf * 128 + q;
-            const int wi = iq % BW, hi = (iq / BW) % BH, ti = iq / (BW * BH);
-            const float *r0 = R + (q * 2) * BI::NR, *r1 = r0 + BI::NR;
-            if (tid < BI::NT) {
-                const int tj = ti - tid + BT - 1;
-                if (tj >= 0 && tj < BT) acc += r0[tj] + r1[tj];
-            } else if (tid < BI::NT + BI::NH) {
-                const int hj = hi - (tid - BI::NT) + BH - 1;
-                if (hj >= 0 && hj < BH) acc += r0[BT + hj] + r1[BT + hj];
-            } else {
-                const int wj = wi - (tid - BI::NT - BI::NH) + BW - 1;
-                if (wj >= 0 && wj < BW) acc += (((wj >> 2) & 1) ? r1 : r0)[BT + BH + (wj & 3) + 4 * (wj >> 3)];
-            }
-        }
-        bank_partial[((long long)bh_ * 2 + qhalf) * BI::NB + tid] = acc;
-    }
-}
-
-template <int BT, int BH, int BW, int MASKED>
-__global__ __launch_bounds__(256, 1) void lvt_attn_bwd_a_kernel(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
-                                                                float inv_temper, const float *__restrict__ P,
-                                                                const float *__restrict__ o, float *__restrict__ dS,
-                                                                float *__restrict__ dq, float *__restrict__ bank_partial) {
-    __shared__ __attribute__((aligned(16))) unsigned short X[2 * AP_SLOT];
-    if (MASKED && ap_half(blockIdx.x) == 0)
-        attn_bwd_a_body<BT, BH, BW, MASKED, 2>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X);
-    else
-        attn_bwd_a_body<BT, BH, BW, MASKED, 4>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X);
-}
-
-// =====================================================================================================================
-// backward B: dV^T = dO^T P and dK^T = Q^T dS (one wave = 32 keys; reduction over the queries)
-// =====================================================================================================================
-template <int C0, int NCH>       // query chunks C0 .. C0 + NCH - 1 (causal key half 1 never sees queries 0..127)
-__device__ __forceinline__ void attn_bwd_b_body(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
-                                                const float *__restrict__ P, const float *__restrict__ dS,
-                                                float *__restrict__ dk, float *__restrict__ dv, unsigned short *X) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int bh_ = ap_pair(blockIdx.x), khalf = ap_half(blockIdx.x);
-    const int b = bh_ / H, h = bh_ % H;
-    const int hd = H * AT_D;
-    const long long row0 = (long long)b * AT_S;
-    const int kb = khalf * 128 + wave * 32;                           // first key of this wave
-    const unsigned short *qbase = pa.q + row0 * hd + h * AT_D, *dobase = dop + row0 * hd + h * AT_D;
-    constexpr int NIT = 2 * NCH;                                      // items: dO chunk, Q chunk, dO chunk, ... (all transposed reads)
-
-    G12 g0, g1;
-    auto load_item = [&](int t, G12 &gg) {
-        ap_load(gg, ((t & 1) ? qbase : dobase) + (long long)((C0 + (t >> 1)) * AT_KC) * hd, pa.ps, hd, tid);
-    };
-    // B fragments: element (query, key) of P (even items) or dS (odd items): lane (key l31, half) holds the queries
-    // 16 s + 8 half .. + 7 of the chunk; eight 4-byte loads per fragment, coalesced across the lanes (consecutive keys)
-    const float *pcol = P + (((long long)b * H + h) * AT_S) * AT_S + kb + l31;
-    const float *dscol = dS + (((long long)b * H + h) * AT_S) * AT_S + kb + l31;
-    float bf0[32], bf1[32];
-#define AP_BF(t) ((((t) & 1) == 0) ? bf0 : bf1)
-    auto load_b = [&](int t, float (&ff)[32]) {
-        const float *src = ((t & 1) ? dscol : pcol) + (long long)((C0 + (t >> 1)) * AT_KC + 8 * half) * AT_S;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ff[8 * s + e] = src[(long long)(16 * s + e) * AT_S];
-    };
-    load_item(0, g0);
-    load_item(1, g1);
-    load_b(0, bf0);
-    ap_park<AP_LDT, 0, AP_NG>(g0, X, tid);
-    __syncthreads();
-
-    f32x16 accv[AT_D / 32], acck[AT_D / 32];          // dV^T, dK^T  (rows d, columns = the wave's keys)
-#pragma unroll
-    for (int dtile = 0; dtile < AT_D / 32; ++dtile)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { accv[dtile][r] = 0.f; acck[dtile][r] = 0.f; }
-
-    static_for<NIT>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        const unsigned short *cur = X + (t & 1) * AP_SLOT;
-        unsigned short *nxt = X + ((t + 1) & 1) * AP_SLOT;
-        if constexpr (t + 2 < NIT) load_item(t + 2, AP_G(t));
-        if constexpr (t + 1 < NIT) load_b(t + 1, AP_BF(t + 1));
-        static_for<4>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            bf16x8 pb[3];
-            const float (&ff)[32] = AP_BF(t);
-            at_split8(make_float4(ff[8 * s + 0], ff[8 * s + 1], ff[8 * s + 2], ff[8 * s + 3]),
-                      make_float4(ff[8 * s + 4], ff[8 * s + 5], ff[8 * s + 6], ff[8 * s + 7]), pb[0], pb[1], pb[2]);
-            bf16x8 a[AT_D / 32][3];
-#pragma unroll
-            for (int dtile = 0; dtile < AT_D / 32; ++dtile) ap_frag_tr(a[dtile], cur, dtile, s, lane);
-            if constexpr (t + 1 < NIT) ap_park<AP_LDT, (AP_NG / 4) * s, AP_NG / 4>(AP_G(t + 1), nxt, tid);
-#pragma unroll
-            for (int tm = 0; tm < 6; ++tm)
-#pragma unroll
-                for (int dtile = 0; dtile < AT_D / 32; ++dtile) {
-                    if constexpr ((t & 1) == 0)
-                        accv[dtile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dtile][AT_TA(tm)], pb[AT_TB(tm)], accv[dtile], 0, 0, 0);
-                    else
-                        acck[dtile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dtile][AT_TA(tm)], pb[AT_TB(tm)], acck[dtile], 0, 0, 0);
-                }
-        });
-        __syncthreads();
-    });
-#undef AP_BF
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-        float *orow = (w ? dk : dv) + (row0 + kb + l31) * hd + h * AT_D + 4 * half;
-#pragma unroll
-        for (int dtile = 0; dtile < AT_D / 32; ++dtile)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-                *reinterpret_cast<float4 *>(orow + 32 * dtile + 8 * gq) =
-                    w ? make_float4(acck[dtile][4 * gq + 0], acck[dtile][4 * gq + 1], acck[dtile][4 * gq + 2], acck[dtile][4 * gq + 3])
-                      : make_float4(accv[dtile][4 * gq + 0], accv[dtile][4 * gq + 1], accv[dtile][4 * gq + 2], accv[dtile][4 * gq + 3]);
-    }
-}
-
-template <int MASKED>
-__global__ __launch_bounds__(256, 1) void lvt_attn_bwd_b_kernel(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
-                                                                const float *__restrict__ P, const float *__restrict__ dS,
-                                                                float *__restrict__ dk, float *__restrict__ dv) {
-    __shared__ __attribute__((aligned(16))) unsigned short X[2 * AP_SLOT];
-    if (MASKED && ap_half(blockIdx.x) == 1) attn_bwd_b_body<2, 2>(pa, dop, H, P, dS, dk, dv, X);      // keys 128..255: queries 128..255 only
-    else attn_bwd_b_body<0, 4>(pa, dop, H, P, dS, dk, dv, X);
+        attn_fwd16_body<BT, BH, BW, MASKED, 4>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X);
 }
 
 // =====================================================================================================================
 // backward on 16-wide tiles (eight waves per workgroup, two per SIMD): A16 = dS, dQ, bank sums; B16 = dV, dK.  BW == 16.
 // =====================================================================================================================
-template <int BT, int BH, int MASKED, int NCH>
+template <int BT, int BH, int BW, int MASKED, int NCH>
 __device__ __forceinline__ void attn_bwd_a16_body(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
                                                   float inv_temper, const float *__restrict__ P, const float *__restrict__ o,
                                                   float *__restrict__ dS, float *__restrict__ dq, float *__restrict__ bank_partial,
                                                   unsigned short *X) {
-    constexpr int BW = 16;
     static_assert(BT * BH * BW == AT_S, "256 tokens");
     using BI = BankIdx<BT, BH, BW>;
-    constexpr int NR = BT + BH + 4;                                   // per-lane class sums: t classes, h classes, w = 4 kg + r
+    using GE = Geo16<BH, BW>;
+    constexpr int HP = GE::HP;
+    constexpr int NR = BT + HP + 4;                                   // per-lane class sums: t index, h slot, register (Geo16)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, kg = lane >> 4;
     const int bh_ = ap_pair(blockIdx.x), qhalf = ap_half(blockIdx.x);
@@ -968,17 +396,17 @@ __device__ __forceinline__ void attn_bwd_a16_body(const PlaneArgs pa, const unsi
 #pragma unroll
         for (int T = 4 * NCH; T < AT_S / 16; ++T) *reinterpret_cast<f32x4v *>(dsrow + 16 * T) = f32x4v{0.f, 0.f, 0.f, 0.f};
     }
-    // per-lane class sums of dS (g = dS * temper): key 16 T + 4 kg + r has t class T / BH, h class T % BH, w class 4 kg + r
+    // per-lane class sums of dS (g = dS * temper) over the t index T / HP, the h slot T % HP and the register r
     float rsum[NR];
 #pragma unroll
     for (int x = 0; x < NR; ++x) rsum[x] = 0.f;
     static_for<4 * NCH>([&](auto Tc) {
         constexpr int T = decltype(Tc)::value;
         const float tot = (st[T][0] + st[T][1]) + (st[T][2] + st[T][3]);
-        rsum[T / BH] += tot;
-        rsum[BT + T % BH] += tot;
+        rsum[T / HP] += tot;
+        rsum[BT + T % HP] += tot;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rsum[BT + BH + r] += st[T][r];
+        for (int r = 0; r < 4; ++r) rsum[BT + HP + r] += st[T][r];
     });
 
     // ---------------- phase 2: dQ^T = K^T dS^T ----------------
@@ -1042,10 +470,16 @@ __device__ __forceinline__ void attn_bwd_a16_body(const PlaneArgs pa, const unsi
                     if (tj >= 0 && tj < BT) acc += (r[tj] + r[NR + tj]) + (r[2 * NR + tj] + r[3 * NR + tj]);
                 } else if (e < BI::NT + BI::NH) {
                     const int hj = hi - (e - BI::NT) + BH - 1;
-                    if (hj >= 0 && hj < BH) acc += (r[BT + hj] + r[NR + BT + hj]) + (r[2 * NR + BT + hj] + r[3 * NR + BT + hj]);
+                    if (hj >= 0 && hj < BH) {
+                        if (BW == 16) acc += (r[BT + hj] + r[NR + BT + hj]) + (r[2 * NR + BT + hj] + r[3 * NR + BT + hj]);
+                        else acc += r[(2 * (hj & 1)) * NR + BT + (hj >> 1)] + r[(2 * (hj & 1) + 1) * NR + BT + (hj >> 1)];   // lanes with kg >> 1 == hj & 1
+                    }
                 } else {
                     const int wj = wi - (e - BI::NT - BI::NH) + BW - 1;
-                    if (wj >= 0 && wj < BW) acc += r[(wj >> 2) * NR + BT + BH + (wj & 3)];
+                    if (wj >= 0 && wj < BW) {
+                        if (BW == 16) acc += r[(wj >> 2) * NR + BT + HP + (wj & 3)];
+                        else acc += r[(wj >> 2) * NR + BT + HP + (wj & 3)] + r[((wj >> 2) + 2) * NR + BT + HP + (wj & 3)];          // lanes with kg & 1 == wj >> 2
+                    }
                 }
             }
             R2[part * BI::NB + e] = acc;
@@ -1060,16 +494,16 @@ __device__ __forceinline__ void attn_bwd_a16_body(const PlaneArgs pa, const unsi
     }
 }
 
-template <int BT, int BH, int MASKED>
+template <int BT, int BH, int BW, int MASKED>
 __global__ __launch_bounds__(512, 1) void lvt_attn_bwd_a16_kernel(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
                                                                   float inv_temper, const float *__restrict__ P,
                                                                   const float *__restrict__ o, float *__restrict__ dS,
                                                                   float *__restrict__ dq, float *__restrict__ bank_partial) {
     __shared__ __attribute__((aligned(16))) unsigned short X[2 * A16_SLOT];
     if (MASKED && ap_half(blockIdx.x) == 0)
-        attn_bwd_a16_body<BT, BH, MASKED, 2>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X);
+        attn_bwd_a16_body<BT, BH, BW, MASKED, 2>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X);
     else
-        attn_bwd_a16_body<BT, BH, MASKED, 4>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X);
+        attn_bwd_a16_body<BT, BH, BW, MASKED, 4>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X);
 }
 
 template <int C0, int NCH>
@@ -1200,23 +634,17 @@ extern "C" int lvt_attn_fwd_planes(const void *qkv_planes, long long plane_strid
                 "attn_fwd_planes: alignment");
     const unsigned short *base = (const unsigned short *)qkv_planes;
     PlaneArgs pa = {base, base + operand_stride, base + 2 * operand_stride, plane_stride};
-    const dim3 grid((unsigned)(B * H * 2)), blk(256);
+    const dim3 grid((unsigned)(B * H * 2)), blk(512);
     hipStream_t s = (hipStream_t)stream;
     const float it = 1.f / temper;
-    if (bt == 1 && bh == 16 && bw == 16 && !getenv("LVT_ATTN_FWD32")) {          // 16-query tiles, two waves per SIMD
-        if (masked) hipLaunchKernelGGL((lvt_attn_fwd16_planes_kernel<1, 16, 1>), grid, dim3(512), 0, s, pa, H, it, dt, dh, dw, fill, P, o);
-        else hipLaunchKernelGGL((lvt_attn_fwd16_planes_kernel<1, 16, 0>), grid, dim3(512), 0, s, pa, H, it, dt, dh, dw, fill, P, o);
-        LVT_CHECK_LAUNCH("lvt_attn_fwd16_planes_kernel");
-        return LVT_OK;
-    }
-#define LVT_X(BT, BH, BW)                                                                                                          \
-    if (bt == BT && bh == BH && bw == BW) {                                                                                        \
-        if (masked) hipLaunchKernelGGL((lvt_attn_fwd_planes_kernel<BT, BH, BW, 1>), grid, blk, 0, s, pa, H, it, dt, dh, dw, fill, P, o); \
-        else hipLaunchKernelGGL((lvt_attn_fwd_planes_kernel<BT, BH, BW, 0>), grid, blk, 0, s, pa, H, it, dt, dh, dw, fill, P, o);        \
+#define LVT_X(BT, BH, BW)                                                                                                            \
+    if (bt == BT && bh == BH && bw == BW) {                                                                                          \
+        if (masked) hipLaunchKernelGGL((lvt_attn_fwd16_planes_kernel<BT, BH, BW, 1>), grid, blk, 0, s, pa, H, it, dt, dh, dw, fill, P, o); \
+        else hipLaunchKernelGGL((lvt_attn_fwd16_planes_kernel<BT, BH, BW, 0>), grid, blk, 0, s, pa, H, it, dt, dh, dw, fill, P, o);        \
     }
     LVT_AP_GEOMS(LVT_X)
 #undef LVT_X
-    LVT_CHECK_LAUNCH("lvt_attn_fwd_planes_kernel");
+    LVT_CHECK_LAUNCH("lvt_attn_fwd16_planes_kernel");
     return LVT_OK;
 }
 
@@ -1242,32 +670,20 @@ extern "C" int lvt_attn_bwd_planes(const void *qkv_planes, long long plane_strid
     PlaneArgs pa = {base, base + operand_stride, base + 2 * operand_stride, plane_stride};
     float *dS = (float *)workspace, *partial = dS + (size_t)B * H * S * S;
     const int nt = 2 * bt - 1, nh = 2 * bh - 1, nw = 2 * bw - 1, nb = nt + nh + nw;
-    const dim3 grid((unsigned)(B * H * 2)), blk(256);
+    const dim3 grid((unsigned)(B * H * 2)), blk(512);
     hipStream_t s = (hipStream_t)stream;
     const float it = 1.f / temper;
-    if (bt == 1 && bh == 16 && bw == 16 && !getenv("LVT_ATTN_FWD32")) {          // 16-wide tiles, two waves per SIMD
-        if (masked) hipLaunchKernelGGL((lvt_attn_bwd_a16_kernel<1, 16, 1>), grid, dim3(512), 0, s, pa, dop, H, it, P, o, dS, dq, partial);
-        else hipLaunchKernelGGL((lvt_attn_bwd_a16_kernel<1, 16, 0>), grid, dim3(512), 0, s, pa, dop, H, it, P, o, dS, dq, partial);
-        LVT_CHECK_LAUNCH("lvt_attn_bwd_a16_kernel");
-        if (masked) hipLaunchKernelGGL((lvt_attn_bwd_b16_kernel<1>), grid, dim3(512), 0, s, pa, dop, H, P, dS, dk, dv);
-        else hipLaunchKernelGGL((lvt_attn_bwd_b16_kernel<0>), grid, dim3(512), 0, s, pa, dop, H, P, dS, dk, dv);
-        LVT_CHECK_LAUNCH("lvt_attn_bwd_b16_kernel");
-        hipLaunchKernelGGL(lvt_attn_bank_reduce_kernel, dim3((unsigned)lvt_cdiv((long long)H * nb, 64)), dim3(64), 0, s, partial, B, H, nb,
-                           nt, nh, ddt, ddh, ddw);
-        LVT_CHECK_LAUNCH("lvt_attn_bank_reduce_kernel");
-        return LVT_OK;
-    }
-#define LVT_X(BT, BH, BW)                                                                                                          \
-    if (bt == BT && bh == BH && bw == BW) {                                                                                        \
-        if (masked) hipLaunchKernelGGL((lvt_attn_bwd_a_kernel<BT, BH, BW, 1>), grid, blk, 0, s, pa, dop, H, it, P, o, dS, dq, partial); \
-        else hipLaunchKernelGGL((lvt_attn_bwd_a_kernel<BT, BH, BW, 0>), grid, blk, 0, s, pa, dop, H, it, P, o, dS, dq, partial);        \
+#define LVT_X(BT, BH, BW)                                                                                                            \
+    if (bt == BT && bh == BH && bw == BW) {                                                                                          \
+        if (masked) hipLaunchKernelGGL((lvt_attn_bwd_a16_kernel<BT, BH, BW, 1>), grid, blk, 0, s, pa, dop, H, it, P, o, dS, dq, partial);  \
+        else hipLaunchKernelGGL((lvt_attn_bwd_a16_kernel<BT, BH, BW, 0>), grid, blk, 0, s, pa, dop, H, it, P, o, dS, dq, partial);         \
     }
     LVT_AP_GEOMS(LVT_X)
 #undef LVT_X
-    LVT_CHECK_LAUNCH("lvt_attn_bwd_a_kernel");
-    if (masked) hipLaunchKernelGGL((lvt_attn_bwd_b_kernel<1>), grid, blk, 0, s, pa, dop, H, P, dS, dk, dv);
-    else hipLaunchKernelGGL((lvt_attn_bwd_b_kernel<0>), grid, blk, 0, s, pa, dop, H, P, dS, dk, dv);
-    LVT_CHECK_LAUNCH("lvt_attn_bwd_b_kernel");
+    LVT_CHECK_LAUNCH("lvt_attn_bwd_a16_kernel");
+    if (masked) hipLaunchKernelGGL((lvt_attn_bwd_b16_kernel<1>), grid, blk, 0, s, pa, dop, H, P, dS, dk, dv);
+    else hipLaunchKernelGGL((lvt_attn_bwd_b16_kernel<0>), grid, blk, 0, s, pa, dop, H, P, dS, dk, dv);
+    LVT_CHECK_LAUNCH("lvt_attn_bwd_b16_kernel");
     hipLaunchKernelGGL(lvt_attn_bank_reduce_kernel, dim3((unsigned)lvt_cdiv((long long)H * nb, 64)), dim3(64), 0, s, partial, B, H, nb,
                        nt, nh, ddt, ddh, ddw);
     LVT_CHECK_LAUNCH("lvt_attn_bank_reduce_kernel");

@@ -124,23 +124,18 @@ def linear_wgrad(dy, x, n_out, k_in, rows, want_bias=False):
 CAUSAL_SKIP = not os.environ.get("LVT_NO_CAUSAL_SKIP")      # A/B switch of the causal reductions in the backward products
 FUSED_ATTENTION = True      # scores + bias + mask + softmax + P.V in one launch when the block is 256 tokens x 128 dims
 # q / k / v / dO as bf16x3 planes into the pipelined attention kernels (csrc/attention_pipe.hip): forward and the whole core
-# backward (dQ, dK, dV, bank gradients) as three fused launches.  For the (1, 16, 16) block of DSFVT / KDSFVT the 16-wide-tile
-# kernels (eight waves per workgroup, two per SIMD) take 147 + 184 + 151 us per layer against 176 + 480 us for the round-2
-# path (fused forward, four batched GEMMs + softmax-bwd + bank kernel): that geometry uses them by default.  The 32-query
-# plane kernels that serve the other geometries ((4, 8, 8): DSSVT / DSTSVT) are not faster than the round-2 path (one wave
-# per SIMD), so those stay on it unless LVT_PLANE_ATTENTION=1.  LVT_NO_PLANE_ATTENTION=1: round-2 path
-# everywhere.  None = decide per geometry; True / False force (tests).
+# backward (dQ, dK, dV, bank gradients) as three fused launches on 16-wide tiles (eight waves per workgroup, two per SIMD):
+# 147 + 184 + 151 us per layer at the DSFVT shape against 176 + ~410 us for the round-2 path (fused forward, four batched
+# GEMMs + softmax-bwd + bank kernel).  Used whenever the block has an instantiation ((1,16,16): DSFVT / KDSFVT; (4,8,8): DSSVT /
+# DSTSVT), 256 tokens x 128 head dims, bf16x3 arithmetic and batch x heads % 8 == 0.  LVT_NO_PLANE_ATTENTION=1 (or
+# PLANE_ATTENTION = False) keeps the round-2 path; tests force either side.
 PLANE_ATTENTION = None
 
 
 def _use_planes(S, da, block, pairs):
     if os.environ.get("LVT_NO_PLANE_ATTENTION") or PLANE_ATTENTION is False:
         return False
-    if not tx.attn_planes_supported(S, da, block, pairs):
-        return False
-    if PLANE_ATTENTION is True or os.environ.get("LVT_PLANE_ATTENTION"):
-        return True
-    return tuple(block)[2] == 16          # the 16-wide-tile kernels exist for BW == 16 geometries
+    return tx.attn_planes_supported(S, da, block, pairs)
 
 
 class _BlockLocalAttentionFn(torch.autograd.Function):

@@ -390,7 +390,7 @@ def test_fused_attention_forward(masked, blk):
 
 @pytest.mark.parametrize("block,masked", [((1, 16, 16), False), ((1, 16, 16), True), ((4, 8, 8), True)])
 def test_plane_attention_path_equals_default_path(block, masked):
-    """The pipelined attention kernels on bf16x3-plane operands (default for the (1,16,16) block: 16-wide tiles; opt-in for (4,8,8)) (csrc/attention_pipe.hip: LVT_EPI_PLANES epilogue of the
+    """The pipelined attention kernels on bf16x3-plane operands (the default for both shipped block geometries) (csrc/attention_pipe.hip: LVT_EPI_PLANES epilogue of the
     QKV / dO GEMMs, lvt_attn_fwd_planes, lvt_attn_bwd_planes) against the default path on one layer: output and every
     gradient, including the bias banks reduced from per-workgroup partial sums."""
     import lvt_amd.modeling.autoregressive.vt_attention as A
