@@ -602,15 +602,19 @@ __global__ __launch_bounds__(512, 1) void lvt_attn_bwd_b16_kernel(const PlaneArg
     else attn_bwd_b16_body<0, 4>(pa, dop, H, P, dS, dk, dv, X);
 }
 
-// bank gradients: out[h][e] = sum over (sample, query half) of the workgroup partials, in a fixed order
-__global__ void lvt_attn_bank_reduce_kernel(const float *__restrict__ partial, int B, int H, int NB, int nt, int nh,
-                                            float *__restrict__ ddt, float *__restrict__ ddh, float *__restrict__ ddw) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// bank gradients: out[h][e] = sum over (sample, query half) of the workgroup partials.  One wave per output: lane l adds
+// partials l, l + 64, ... in that order and the 64 lane sums meet in a fixed butterfly (deterministic, no atomics).
+__global__ __launch_bounds__(256) void lvt_attn_bank_reduce_kernel(const float *__restrict__ partial, int B, int H, int NB, int nt,
+                                                                   int nh, float *__restrict__ ddt, float *__restrict__ ddh,
+                                                                   float *__restrict__ ddw) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (idx >= H * NB) return;
     const int h = idx / NB, e = idx % NB;
     float s = 0.f;
-    for (int b = 0; b < B; ++b)
-        for (int qh = 0; qh < 2; ++qh) s += partial[(((long long)b * H + h) * 2 + qh) * NB + e];
+    for (int j = lane; j < 2 * B; j += 64) s += partial[(((long long)(j >> 1) * H + h) * 2 + (j & 1)) * NB + e];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane) return;
     if (e < nt) ddt[h * nt + e] = s;
     else if (e < nt + nh) ddh[h * nh + e - nt] = s;
     else ddw[h * (NB - nt - nh) + e - nt - nh] = s;
@@ -684,7 +688,7 @@ extern "C" int lvt_attn_bwd_planes(const void *qkv_planes, long long plane_strid
     if (masked) hipLaunchKernelGGL((lvt_attn_bwd_b16_kernel<1>), grid, blk, 0, s, pa, dop, H, P, dS, dk, dv);
     else hipLaunchKernelGGL((lvt_attn_bwd_b16_kernel<0>), grid, blk, 0, s, pa, dop, H, P, dS, dk, dv);
     LVT_CHECK_LAUNCH("lvt_attn_bwd_b16_kernel");
-    hipLaunchKernelGGL(lvt_attn_bank_reduce_kernel, dim3((unsigned)lvt_cdiv((long long)H * nb, 64)), dim3(64), 0, s, partial, B, H, nb,
+    hipLaunchKernelGGL(lvt_attn_bank_reduce_kernel, dim3((unsigned)lvt_cdiv((long long)H * nb, 4)), dim3(256), 0, s, partial, B, H, nb,
                        nt, nh, ddt, ddh, ddw);
     LVT_CHECK_LAUNCH("lvt_attn_bank_reduce_kernel");
     return LVT_OK;
