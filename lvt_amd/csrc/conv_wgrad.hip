@@ -27,6 +27,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define WG_CQ 256
 #define WG_QP (WG_CQ + 32)               // slab pixel pitch (bf16): 576 B = 16 dwords mod 64
 #define WG_QPL (16 * WG_QP)
+#ifndef LVT_WG_ANTIPHASE_MODES
+#define LVT_WG_ANTIPHASE_MODES 2         // bit MODE: the stride-2 kernel (24 MFMAs per staged row) gains, the 3x3 one (54) does not
+#endif
+#define LVT_WG_ANTIPHASE(mode) (((LVT_WG_ANTIPHASE_MODES) >> (mode)) & 1)
 
 struct WgParams {
     const float *P, *Q;
@@ -142,9 +146,17 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
     const int boff = rowoff * WG_QP + wave * 32 + coloff;
     const int aoff = rowoff * WG_PP + coloff;
 
+    // The two waves of a SIMD (w and w + 4) belong to this workgroup and meet at every barrier, so left alone they would both
+    // split / store the next slab row and then both queue on the matrix pipe.  Waves 4..7 ("early") therefore store row r + 1
+    // BEFORE their MFMAs of row r (their fetch runs two rows ahead), waves 0..3 after them: on every SIMD one wave converts
+    // while the other multiplies.  (Both orders sit between the same two barriers; each thread stores its own part of a row.)
+    const bool early = LVT_WG_ANTIPHASE(MODE) && ((wave >> 2) & 1);
+    const int r_end = f1 * 16;
+    auto slab_fetch_row = [&](int r) { if (r < r_end) slab_fetch(r >> 4, r & 15); };
     if (f0 < f1) {
         patch_fetch(f0); slab_fetch(f0, 0);
         patch_store(); slab_store(slab0);
+        if (early) slab_fetch_row(f0 * 16 + 1);
     }
     __syncthreads();
     int buf = 0;
@@ -152,8 +164,14 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
         const bool next_frame = f + 1 < f1;
         for (int y = 0; y < 16; ++y) {
             const bool last_row = y == 15;
-            if (!last_row) slab_fetch(f, y + 1);
-            else if (next_frame) { slab_fetch(f + 1, 0); patch_fetch(f + 1); }
+            const int r = f * 16 + y;
+            if (early) {
+                if (r + 1 < r_end) slab_store(slab0 + (buf ^ 1) * (3 * WG_QPL));
+                slab_fetch_row(r + 2);
+            } else {
+                slab_fetch_row(r + 1);
+            }
+            if (last_row && next_frame) patch_fetch(f + 1);
             const unsigned short *slab = slab0 + buf * (3 * WG_QPL);
             bf16x8 b[3];
 #pragma unroll
@@ -175,7 +193,7 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
                     for (int dx = 0; dx < TD; ++dx)
                         acc[dy * TD + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dx][TA[t]], b[TB[t]], acc[dy * TD + dx], 0, 0, 0);
             }
-            if (!last_row || next_frame) slab_store(slab0 + (buf ^ 1) * (3 * WG_QPL));
+            if (!early && r + 1 < r_end) slab_store(slab0 + (buf ^ 1) * (3 * WG_QPL));
             if (last_row && next_frame) {
                 __syncthreads();             // every wave is done with this frame's patch
                 patch_store();
