@@ -63,8 +63,16 @@ __device__ __forceinline__ bf16x8 ap_tr(const unsigned short *p, int hi_off) {
 // Workgroup x runs on XCD x % 8 and every XCD has its own L2: the two halves of one (sample, head) stage the same K / V (or
 // Q / dO) chunks, so they are given block ids 8 apart -- same XCD, dispatched back to back -- and the second reads from L2.
 // (grid = 2 * pairs; the entry points require pairs % 8 == 0.)
+// CAUSAL blocks: one half meets 4 key (query) chunks, the other 2.  As separate workgroups the short ones bought nothing (masked
+// and unmasked launches took the same 145 / 180 / 150 us), so a causal launch has ONE workgroup per pair that runs the long half
+// and then the short one: 3-6 % per kernel.  (A fully persistent forward -- one workgroup per CU walking its items, the ring
+// running on into the next item's first chunks -- measured another 3 % at best: these kernels move 500-700 MB per launch at
+// 3.6-4.3 TB/s and are bound by that, not by workgroup turnover; profiles/r03_attention_workgroup_timeline.txt.)
 __device__ __forceinline__ int ap_pair(unsigned x) { return (int)(((x >> 4) << 3) | (x & 7)); }
 __device__ __forceinline__ int ap_half(unsigned x) { return (int)((x >> 3) & 1); }
+// the same value, but opaque to the optimiser: the second half of a causal pair recomputes its addresses instead of keeping the
+// first half's alive across a whole kernel body (which spilled)
+__device__ __forceinline__ int ap_opaque(int x) { asm volatile("" : "+s"(x)); return x; }
 
 struct PlaneArgs {
     const unsigned short *q, *k, *v;     // plane 0 of each operand, token-major (M, hd)
@@ -111,13 +119,13 @@ template <int BH, int BW> struct Geo16 {
 template <int BT, int BH, int BW, int MASKED, int NCH>
 __device__ __forceinline__ void attn_fwd16_body(const PlaneArgs pa, int H, float inv_temper, const float *__restrict__ dt,
                                                 const float *__restrict__ dh, const float *__restrict__ dw, float fill,
-                                                float *__restrict__ P, float *__restrict__ o, unsigned short *X) {
+                                                float *__restrict__ P, float *__restrict__ o, unsigned short *X, int bh_,
+                                                int qhalf) {
     using GE = Geo16<BH, BW>;
     constexpr int HP = GE::HP;
     static_assert(BT * BH * BW == AT_S, "256 tokens");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, kg = lane >> 4;
-    const int bh_ = ap_pair(blockIdx.x), qhalf = ap_half(blockIdx.x);
     const int b = bh_ / H, h = bh_ % H;
     const int hd = H * AT_D;
     const long long row0 = (long long)b * AT_S;
@@ -286,10 +294,13 @@ __global__ __launch_bounds__(512, 1) void lvt_attn_fwd16_planes_kernel(const Pla
                                                                        const float *__restrict__ dw, float fill,
                                                                        float *__restrict__ P, float *__restrict__ o) {
     __shared__ __attribute__((aligned(16))) unsigned short X[2 * A16_SLOT];
-    if (MASKED && ap_half(blockIdx.x) == 0)
-        attn_fwd16_body<BT, BH, BW, MASKED, 2>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X);
-    else
-        attn_fwd16_body<BT, BH, BW, MASKED, 4>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X);
+    if (MASKED) {        // one workgroup = both query halves of a (sample, head): 4 + 2 key chunks (see the note at ap_pair)
+        attn_fwd16_body<BT, BH, BW, MASKED, 4>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X, blockIdx.x, 1);
+        __syncthreads();
+        attn_fwd16_body<BT, BH, BW, MASKED, 2>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X, ap_opaque(blockIdx.x), 0);
+    } else {
+        attn_fwd16_body<BT, BH, BW, MASKED, 4>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X, ap_pair(blockIdx.x), ap_half(blockIdx.x));
+    }
 }
 
 // =====================================================================================================================
@@ -299,7 +310,7 @@ template <int BT, int BH, int BW, int MASKED, int NCH>
 __device__ __forceinline__ void attn_bwd_a16_body(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
                                                   float inv_temper, const float *__restrict__ P, const float *__restrict__ o,
                                                   float *__restrict__ dS, float *__restrict__ dq, float *__restrict__ bank_partial,
-                                                  unsigned short *X) {
+                                                  unsigned short *X, int bh_, int qhalf) {
     static_assert(BT * BH * BW == AT_S, "256 tokens");
     using BI = BankIdx<BT, BH, BW>;
     using GE = Geo16<BH, BW>;
@@ -307,7 +318,6 @@ __device__ __forceinline__ void attn_bwd_a16_body(const PlaneArgs pa, const unsi
     constexpr int NR = BT + HP + 4;                                   // per-lane class sums: t index, h slot, register (Geo16)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, kg = lane >> 4;
-    const int bh_ = ap_pair(blockIdx.x), qhalf = ap_half(blockIdx.x);
     const int b = bh_ / H, h = bh_ % H;
     const int hd = H * AT_D;
     const long long row0 = (long long)b * AT_S;
@@ -500,19 +510,23 @@ __global__ __launch_bounds__(512, 1) void lvt_attn_bwd_a16_kernel(const PlaneArg
                                                                   const float *__restrict__ o, float *__restrict__ dS,
                                                                   float *__restrict__ dq, float *__restrict__ bank_partial) {
     __shared__ __attribute__((aligned(16))) unsigned short X[2 * A16_SLOT];
-    if (MASKED && ap_half(blockIdx.x) == 0)
-        attn_bwd_a16_body<BT, BH, BW, MASKED, 2>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X);
-    else
-        attn_bwd_a16_body<BT, BH, BW, MASKED, 4>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X);
+    if (MASKED) {
+        attn_bwd_a16_body<BT, BH, BW, MASKED, 4>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X, blockIdx.x, 1);
+        __syncthreads();
+        attn_bwd_a16_body<BT, BH, BW, MASKED, 2>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X, ap_opaque(blockIdx.x), 0);
+    } else {
+        attn_bwd_a16_body<BT, BH, BW, MASKED, 4>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X, ap_pair(blockIdx.x),
+                                                 ap_half(blockIdx.x));
+    }
 }
 
 template <int C0, int NCH>
 __device__ __forceinline__ void attn_bwd_b16_body(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
                                                   const float *__restrict__ P, const float *__restrict__ dS,
-                                                  float *__restrict__ dk, float *__restrict__ dv, unsigned short *X) {
+                                                  float *__restrict__ dk, float *__restrict__ dv, unsigned short *X, int bh_,
+                                                  int khalf) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, kg = lane >> 4;
-    const int bh_ = ap_pair(blockIdx.x), khalf = ap_half(blockIdx.x);
     const int b = bh_ / H, h = bh_ % H;
     const int hd = H * AT_D;
     const long long row0 = (long long)b * AT_S;
@@ -598,8 +612,13 @@ __global__ __launch_bounds__(512, 1) void lvt_attn_bwd_b16_kernel(const PlaneArg
                                                                   const float *__restrict__ P, const float *__restrict__ dS,
                                                                   float *__restrict__ dk, float *__restrict__ dv) {
     __shared__ __attribute__((aligned(16))) unsigned short X[2 * A16_SLOT];
-    if (MASKED && ap_half(blockIdx.x) == 1) attn_bwd_b16_body<2, 2>(pa, dop, H, P, dS, dk, dv, X);
-    else attn_bwd_b16_body<0, 4>(pa, dop, H, P, dS, dk, dv, X);
+    if (MASKED) {        // key half 0 meets all four query chunks, key half 1 the last two
+        attn_bwd_b16_body<0, 4>(pa, dop, H, P, dS, dk, dv, X, blockIdx.x, 0);
+        __syncthreads();
+        attn_bwd_b16_body<2, 2>(pa, dop, H, P, dS, dk, dv, X, ap_opaque(blockIdx.x), 1);
+    } else {
+        attn_bwd_b16_body<0, 4>(pa, dop, H, P, dS, dk, dv, X, ap_pair(blockIdx.x), ap_half(blockIdx.x));
+    }
 }
 
 // bank gradients: out[h][e] = sum over (sample, query half) of the workgroup partials.  One wave per output: lane l adds
@@ -638,7 +657,7 @@ extern "C" int lvt_attn_fwd_planes(const void *qkv_planes, long long plane_strid
                 "attn_fwd_planes: alignment");
     const unsigned short *base = (const unsigned short *)qkv_planes;
     PlaneArgs pa = {base, base + operand_stride, base + 2 * operand_stride, plane_stride};
-    const dim3 grid((unsigned)(B * H * 2)), blk(512);
+    const dim3 grid((unsigned)(B * H * (masked ? 1 : 2))), blk(512);
     hipStream_t s = (hipStream_t)stream;
     const float it = 1.f / temper;
 #define LVT_X(BT, BH, BW)                                                                                                            \
@@ -674,7 +693,7 @@ extern "C" int lvt_attn_bwd_planes(const void *qkv_planes, long long plane_strid
     PlaneArgs pa = {base, base + operand_stride, base + 2 * operand_stride, plane_stride};
     float *dS = (float *)workspace, *partial = dS + (size_t)B * H * S * S;
     const int nt = 2 * bt - 1, nh = 2 * bh - 1, nw = 2 * bw - 1, nb = nt + nh + nw;
-    const dim3 grid((unsigned)(B * H * 2)), blk(512);
+    const dim3 grid((unsigned)(B * H * (masked ? 1 : 2))), blk(512);
     hipStream_t s = (hipStream_t)stream;
     const float it = 1.f / temper;
 #define LVT_X(BT, BH, BW)                                                                                                            \
