@@ -64,7 +64,9 @@ PEAK_NOTE = {
     "bf16x3": "dense bf16 MFMA peak 2516.6 TFLOP/s / 6 MFMA products per algorithmic fp32 product; `achieved` counts "
               "ALGORITHMIC fp32 FLOPs only (not the 6x executed bf16 FLOPs); an MFMA-only loop on random bf16 operands "
               "sustains 71 % of that peak on this part (power throttling by operand toggling, "
-              "profiles/r01_ubench_engine_bounds.txt), i.e. ~300 TFLOP/s in these units",
+              "profiles/r01_ubench_engine_bounds.txt), i.e. ~300 TFLOP/s in these units; the shader clock measured inside "
+              "lvt_gemm_kernel on random operands is 1.58-1.69 GHz of the nominal 2.4 (2.25 GHz on zeros), "
+              "profiles/r03_gemm_shape_and_power_probes.txt",
 }
 
 
