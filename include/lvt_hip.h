@@ -89,7 +89,9 @@ typedef struct {
     const float *mask; long long ldm;
     int splits;
     /* ta == 1 with splits > 1 only (weight gradient dW = dY^T X): when non-NULL receives the M column sums of A
-     * (= sum over the K rows of dY: the bias gradient), accumulated from the A tiles the kernel streams anyway. */
+     * (= sum over the K rows of dY: the bias gradient), accumulated from the A tiles the kernel streams anyway;
+     * batched launches write (batch, M).  The batch strides sA / sB / sC are plain element offsets: two unrelated
+     * weight gradients of the same shape run as ONE launch with sA_i = A1 - A0 etc. (half the k ranges, twice as long). */
     float *a_colsum;
     long long c_plane;                  /* LVT_EPI_PLANES: distance between the bf16 planes of C (elements)                 */
 } lvt_gemm_desc;

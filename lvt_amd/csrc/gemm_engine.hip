@@ -662,14 +662,17 @@ __device__ __forceinline__ TileCtx lvt_tile_ctx(const KParams &p) {
     const int ntn = (p.N + BN - 1) / BN;
     int wg = blockIdx.x;
     t.split = blockIdx.z;
-    if (p.splits > 1 && gridDim.y == 1 && (gridDim.z & 7) == 0) {
-        // split-K of a few tiles (the weight gradients dW = dY^T X: 16 tiles x 32 k ranges): ALL tiles of one k range read the
-        // same rows of both operands, so a k range is given to ONE XCD (the dispatcher walks x, then z: linear id L -> XCD
-        // L % 8) and its tiles share the panels through that L2.  With the per-dimension remap below every XCD held two
-        // tiles of every k range and fetched 4-5x the algorithmic bytes (profiles/r02_dsfvt_pmc_hbm_traffic.txt).
-        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.z;
+    t.z = blockIdx.y;                   // batch (or conv phase class)
+    if (p.splits > 1 && ((gridDim.y * gridDim.z) & 7) == 0) {
+        // split-K of a few tiles (the weight gradients dW = dY^T X: 16 tiles x 32 k ranges): ALL tiles of one (batch, k range)
+        // read the same rows of both operands, so such a group is given to ONE XCD (the dispatcher walks x, then y, then z:
+        // linear id L -> XCD L % 8) and its tiles share the panels through that L2.  With the per-dimension remap below every
+        // XCD held two tiles of every k range and fetched 4-5x the algorithmic bytes (profiles/r02_dsfvt_pmc_hbm_traffic.txt).
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const unsigned xcd = lin & 7, slot = lin >> 3;
-        t.split = (int)(xcd + 8 * (slot / gridDim.x));
+        const unsigned grp = xcd + 8 * (slot / gridDim.x);          // (batch, k range), batch fastest
+        t.z = (int)(grp % gridDim.y);
+        t.split = (int)(grp / gridDim.y);
         wg = (int)(slot % gridDim.x);
     } else {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
@@ -677,7 +680,6 @@ __device__ __forceinline__ TileCtx lvt_tile_ctx(const KParams &p) {
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
     t.n0 = (wg % ntn) * BN; t.m0 = (wg / ntn) * BM;
-    t.z = blockIdx.y;                   // batch (or conv phase class)
     t.A = p.A; t.B = p.B; t.coff = 0; t.cls = 0;
     if (AMODE == A_CONVT_K) {
         t.cls = t.z;
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
     constexpr bool COLSUM = (AMODE == A_CONV_M && BMODE == B_NPLAIN);
     constexpr bool COLSUM_A = (AMODE == A_MPLAIN);
     if constexpr (COLSUM) bl.sum_on = p.colsum_partial != nullptr && m0 == 0;
-    if constexpr (COLSUM_A) al.sum_on = p.colsum_partial != nullptr && n0 == 0 && z == 0;
+    if constexpr (COLSUM_A) al.sum_on = p.colsum_partial != nullptr && n0 == 0;          // per batch
     if (kbeg < kend) {
         al.seek(kbeg); bl.seek(kbeg);
         al.fetch(kend); bl.fetch(kend);
@@ -913,7 +915,7 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
         if (bl.sum_on) bl.write_colsum(lds, p.colsum_partial + (long long)split * p.N, n0, p.N, tid);   // staging LDS is free now
     }
     if constexpr (COLSUM_A) {
-        if (al.sum_on) al.write_colsum(lds, p.colsum_partial + (long long)split * p.M, m0, p.M, tid);
+        if (al.sum_on) al.write_colsum(lds, p.colsum_partial + ((long long)split * gridDim.y + z) * p.M, m0, p.M, tid);
     }
     if (p.vec_epi) lvt_epilogue_vec<AMODE, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, cls, coff, z, split);
     else lvt_epilogue<AMODE, BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, l31, half, cls, coff, z, split);
@@ -1352,7 +1354,7 @@ static int gemm_batch(const lvt_gemm_desc *d) {
 
 extern "C" size_t lvt_gemm_workspace_bytes(const lvt_gemm_desc *d) {
     if (!d || d->splits <= 1) return 0;
-    return (size_t)d->splits * (gemm_batch(d) * (size_t)d->M * d->N + (d->a_colsum ? (size_t)d->M : 0)) * sizeof(float);
+    return (size_t)d->splits * gemm_batch(d) * ((size_t)d->M * d->N + (d->a_colsum ? (size_t)d->M : 0)) * sizeof(float);
 }
 
 extern "C" int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t workspace_bytes, void *stream) {
@@ -1390,7 +1392,7 @@ extern "C" int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t work
         p.partial = (float *)workspace;
         p.partial_stride = (long long)zc * d->M * d->N;
         if (d->a_colsum) {
-            LVT_REQUIRE(d->ta == 1 && zc == 1 && d->M % 4 == 0, "gemm: a_colsum needs ta == 1, no batch, M %% 4 == 0");
+            LVT_REQUIRE(d->ta == 1 && d->M % 4 == 0, "gemm: a_colsum needs ta == 1 and M %% 4 == 0");
             p.colsum_partial = p.partial + (long long)p.splits * p.partial_stride;
         }
     } else {
@@ -1409,8 +1411,10 @@ extern "C" int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t work
                            p.partial_stride, p.splits, d->C, (d->flags & LVT_EPI_ACCUM) ? 1 : 0);
         LVT_CHECK_LAUNCH("lvt_reduce_splits_kernel");
         if (p.colsum_partial) {
-            hipLaunchKernelGGL(lvt_reduce_splits_kernel, dim3((unsigned)lvt_cdiv(d->M / 4, 256)), dim3(256), 0, s,
-                               (const float *)p.colsum_partial, (long long)(d->M / 4), (long long)d->M, p.splits, d->a_colsum, 0);
+            // [split][batch][M] partials -> a_colsum (batch, M)
+            hipLaunchKernelGGL(lvt_reduce_splits_kernel, dim3((unsigned)lvt_cdiv((long long)zc * d->M / 4, 256)), dim3(256), 0, s,
+                               (const float *)p.colsum_partial, (long long)zc * d->M / 4, (long long)zc * d->M, p.splits,
+                               d->a_colsum, 0);
             LVT_CHECK_LAUNCH("lvt_reduce_splits_kernel");
         }
     }

@@ -121,6 +121,32 @@ def linear_wgrad(dy, x, n_out, k_in, rows, want_bias=False):
     return dw, db
 
 
+def linear_wgrad_pair(dy0, x0, dy1, x1, n_out, k_in, rows):
+    """The weight + bias gradients of TWO linear layers of the same shape as one split-K launch: (dw (2, n_out, k_in),
+    db (2, n_out)).  The operands are unrelated allocations, so the batch strides are their address differences (the
+    engine's batch strides are plain element offsets).  16 tiles x 2 x 16 k ranges of 1024 rows fill the chip like
+    16 x 32 ranges of 512 did, with half the prologues, epilogues and partial sums: the 512 x 512 x 16384 product runs at
+    ~130 TFLOP/s alone and the pair at the ~170 of the 512 x 1024 shape (profiles/r03_gemm_shape_and_power_probes.txt)."""
+    es = dy0.element_size()
+    da, dx = dy1.data_ptr() - dy0.data_ptr(), x1.data_ptr() - x0.data_ptr()
+    if (da % (4 * es) or dx % (4 * es) or dy0.shape != dy1.shape or x0.shape != x1.shape or not
+            (dy0.is_contiguous() and dy1.is_contiguous() and x0.is_contiguous() and x1.is_contiguous())):
+        a, ab = linear_wgrad(dy0, x0, n_out, k_in, rows, want_bias=True)
+        b, bb = linear_wgrad(dy1, x1, n_out, k_in, rows, want_bias=True)
+        return torch.stack([a, b]), torch.stack([ab, bb])
+    dw = torch.empty(2, n_out, k_in, dtype=torch.float32, device=dy0.device)
+    db = torch.empty(2, n_out, dtype=torch.float32, device=dy0.device)
+    tiles = 2 * -(-n_out // 128) * -(-k_in // 128)
+    splits = _splits(tiles, rows)
+    if splits < 2:
+        a, ab = linear_wgrad(dy0, x0, n_out, k_in, rows, want_bias=True)
+        b, bb = linear_wgrad(dy1, x1, n_out, k_in, rows, want_bias=True)
+        return torch.stack([a, b]), torch.stack([ab, bb])
+    G.gemm(dy0, x0, dw, n_out, k_in, rows, ta=1, tb=1, lda=n_out, ldb=k_in, batch_inner=2, sA=(0, da // es), sB=(0, dx // es),
+           sC=(0, n_out * k_in), splits=splits, a_colsum=db)
+    return dw, db
+
+
 CAUSAL_SKIP = not os.environ.get("LVT_NO_CAUSAL_SKIP")      # A/B switch of the causal reductions in the backward products
 FUSED_ATTENTION = True      # scores + bias + mask + softmax + P.V in one launch when the block is 256 tokens x 128 dims
 # q / k / v / dO as bf16x3 planes into the pipelined attention kernels (csrc/attention_pipe.hip): forward and the whole core
@@ -130,6 +156,7 @@ FUSED_ATTENTION = True      # scores + bias + mask + softmax + P.V in one launch
 # DSTSVT), 256 tokens x 128 head dims, bf16x3 arithmetic and batch x heads % 8 == 0.  LVT_NO_PLANE_ATTENTION=1 (or
 # PLANE_ATTENTION = False) keeps the round-2 path; tests force either side.
 PLANE_ATTENTION = None
+PAIR_FFN_WGRAD = not os.environ.get("LVT_NO_PAIR_WGRAD")     # the two FFN weight gradients of a layer as one 2-batch launch
 
 
 def _use_planes(S, da, block, pairs):
@@ -202,10 +229,15 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         # FFN: y2 = h1 W3^T + b3 + y1 ; h1 = relu(fn W1^T + b1)
         dh1 = torch.empty(M, dff, dtype=torch.float32, device=dev)
         G.gemm(dy2, f3w, dh1, M, dff, d, ta=0, tb=1, ldb=dff, flags=L.EPI_MASK, mask=h1)
-        df3w, df3b = linear_wgrad(dy2, h1, d, dff, M, want_bias=True)
         dfn = torch.empty(M, d, dtype=torch.float32, device=dev)
         G.gemm(dh1, f1w, dfn, M, d, dff, ta=0, tb=1, ldb=d)
-        df1w, df1b = linear_wgrad(dh1, fn, dff, d, M, want_bias=True)
+        if d == dff and PAIR_FFN_WGRAD:
+            # both FFN weight gradients are (d x d) = dy^T x products over the same rows: one launch
+            dwp, dbp = linear_wgrad_pair(dy2, h1, dh1, fn, d, dff, M)
+            df3w, df3b, df1w, df1b = dwp[0], dbp[0], dwp[1], dbp[1]
+        else:
+            df3w, df3b = linear_wgrad(dy2, h1, d, dff, M, want_bias=True)
+            df1w, df1b = linear_wgrad(dh1, fn, dff, d, M, want_bias=True)
         dy1, df0w, df0b = ew.layernorm_bwd(dfn, y1, mean2, rstd2, f0w, add=dy2)
         # proj: y1 = o proj^T + x
         if ctx.planes:

@@ -412,3 +412,27 @@ def test_gemm_tn_splitk_with_a_colsum():
     G.gemm(dy.to(d), x.to(d), dw, n_out, k_in, rows, ta=1, tb=1, lda=n_out, ldb=k_in, splits=8, a_colsum=db)
     assert rel_err(dw, dy.t() @ x) < 5e-5
     assert rel_err(db, dy.double().sum(0).float()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_two_weight_gradients_as_one_batched_splitk_launch():
+    """linear_wgrad_pair: two unrelated dW = dy^T x products (+ their bias column sums) as ONE 2-batch split-K launch whose
+    batch strides are address differences; bit-identical partial order is not promised, values are (reference: two
+    torch.nn.functional.linear backward passes, vt_attention.py:114-129)."""
+    from lvt_amd.modeling.autoregressive.vt_attention import linear_wgrad, linear_wgrad_pair
+    torch.manual_seed(11)
+    d = "cuda:0"
+    rows, n_out, k_in = 4096, 256, 256
+    dy0, dy1 = torch.randn(rows, n_out, device=d), torch.randn(rows, n_out, device=d)
+    pad = torch.empty(12345, device=d)                      # make the two allocations unrelated
+    x0, x1 = torch.randn(rows, k_in, device=d), torch.randn(rows, k_in, device=d)
+    dw, db = linear_wgrad_pair(dy0, x0, dy1, x1, n_out, k_in, rows)
+    for i, (dy, x) in enumerate(((dy0, x0), (dy1, x1))):
+        ref_w = (dy.double().t() @ x.double()).float()
+        ref_b = dy.double().sum(0).float()
+        assert (dw[i] - ref_w).abs().max() <= 2e-5 * ref_w.abs().max()
+        assert (db[i] - ref_b).abs().max() <= 2e-5 * ref_b.abs().max()
+        one_w, one_b = linear_wgrad(dy, x, n_out, k_in, rows, want_bias=True)
+        assert (dw[i] - one_w).abs().max() <= 1e-5 * ref_w.abs().max()
+        assert (db[i] - one_b).abs().max() <= 1e-5 * ref_b.abs().max()
+    del pad
