@@ -46,10 +46,16 @@ CLIP_FRAMES = 16
 SEED = 29871897                    # configs/*/Base: SEED
 
 
-def engine_peak(mode):
-    """Ceiling of the engine in ALGORITHMIC fp32 FLOP/s: the fp32 MFMA peak in 'f32' mode; in 'bf16x3' mode every
-    algorithmic product is six bf16 MFMA products (a1b1 a1b2 a2b1 a1b3 a3b1 a2b2), so the ceiling is bf16 peak / 6."""
-    return FP32_MFMA_PEAK_TFLOPS if mode == "f32" else BF16_MFMA_PEAK_TFLOPS / 6.0
+def engine_peak(mode, kind=""):
+    """Ceiling of an engine launch in ALGORITHMIC fp32 FLOP/s: the fp32 MFMA peak in 'f32' mode; in 'bf16x3' mode every
+    algorithmic product is six bf16 MFMA products (a1b1 a1b2 a2b1 a1b3 a3b1 a2b2), so the ceiling is bf16 peak / 6; in
+    'f16x2' mode three fp16 MFMA products (hi hi, hi lo, lo hi; fp16 rate = bf16 rate), so peak / 3 -- except for the
+    launches that have no f16x2 path and run bf16x3 in that mode too (`kind` attn_*: the fused attention kernels)."""
+    if mode == "f32":
+        return FP32_MFMA_PEAK_TFLOPS
+    if mode == "f16x2" and not kind.startswith("attn_"):
+        return BF16_MFMA_PEAK_TFLOPS / 3.0
+    return BF16_MFMA_PEAK_TFLOPS / 6.0
 
 
 MATH_NOTE = {
@@ -58,6 +64,12 @@ MATH_NOTE = {
               "operands (six v_mfma_f32_32x32x16_bf16 per block, dropped terms < 2^-24 |a||b|); measured error against "
               "fp64 is not larger than the plain fp32 MFMA path's (profiles/r01_math_mode_accuracy.txt, "
               "tests/test_gpu_engine.py::test_math_modes_accuracy); LVT_MATH=f32 selects the plain fp32 instruction",
+    "f16x2": "fp32 in, fp32 out, fp32 accumulation; every fp32 operand is scaled by an exact power of two taken from its "
+             "max |.| and split into two fp16 terms (hi + 2^-11 lo: 22 bits + sign), a block is three "
+             "v_mfma_f32_32x32x16_f16 (hi hi | hi lo + lo hi in a second accumulator; dropped lo lo <= 2^-22 |a||b|, "
+             "2^-24.6 rms); measured error against fp64 is not larger than the plain fp32 MFMA path's on seven operand "
+             "classes (tests/test_gpu_engine.py::test_math_modes_accuracy) and every parity test runs in this mode at "
+             "unchanged tolerances; the fused attention kernels and the VQ search keep the bf16x3 arithmetic",
 }
 PEAK_NOTE = {
     "f32": "dense fp32 MFMA peak (MI355X_MICROARCH.md)",
@@ -67,6 +79,9 @@ PEAK_NOTE = {
               "profiles/r01_ubench_engine_bounds.txt), i.e. ~300 TFLOP/s in these units; the shader clock measured inside "
               "lvt_gemm_kernel on random operands is 1.58-1.69 GHz of the nominal 2.4 (2.25 GHz on zeros), "
               "profiles/r03_gemm_shape_and_power_probes.txt",
+    "f16x2": "dense bf16/fp16 MFMA peak 2516.6 TFLOP/s / 3 MFMA products per algorithmic fp32 product (/ 6 for the attention "
+             "launches, which stay on bf16x3); `peak` is the flop-weighted harmonic ceiling of the launches of the step, "
+             "`achieved` counts ALGORITHMIC fp32 FLOPs only",
 }
 
 
@@ -186,8 +201,11 @@ def engine_summary(timer, steps, mode):
                     "ms_per_step": round(v["ms"] / steps, 3)} for k, v in sorted(eng.items())}
     other = {k: {"launches_per_step": v["launches"] // steps, "avg_us": round(v["ms"] / v["launches"] * 1e3, 1),
                  "ms_per_step": round(v["ms"] / steps, 3)} for k, v in sorted(summ.items()) if k not in eng}
+    # time the launches would take at their own ceilings / measured time (= achieved / peak when all share one ceiling)
+    ideal_ms = sum(v["flops"] / (engine_peak(mode, k) * 1e12) * 1e3 for k, v in eng.items())
+    peak = tot_fl / (ideal_ms * 1e-3) / 1e12 if ideal_ms > 0 else engine_peak(mode)
     return {"achieved": achieved, "ms_per_step": tot_ms / steps, "launches_per_step": launches // steps,
-            "flops_per_launch": tot_fl / max(launches, 1), "per_kind": per_kind, "frac": achieved / engine_peak(mode),
+            "flops_per_launch": tot_fl / max(launches, 1), "per_kind": per_kind, "frac": achieved / peak, "peak": peak,
             "other": other}
 
 
@@ -206,7 +224,7 @@ def instrumented(step, steps, first_iter):
 
 def roofline_block(es, mode, traffic_file, kernel_note):
     traffic, src = traffic_from_profile(traffic_file)
-    return {"bound": "mfma", "achieved": round(es["achieved"], 2), "peak": round(engine_peak(mode), 1), "unit": "TFLOP/s",
+    return {"bound": "mfma", "achieved": round(es["achieved"], 2), "peak": round(es["peak"], 1), "unit": "TFLOP/s",
             "frac": round(es["frac"], 4), "traffic": traffic,
             "traffic_unit": "HBM bytes per engine launch (rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE in "
                             "separate passes of this command, profiles/%s); algorithmic flops per launch = %.3e"
@@ -381,7 +399,7 @@ def vq_gates(vq, device, oracle_clips):
     enc = {"us_per_launch": round(vq_us, 1), "frames": frames,
            "hbm_frac": round(alg_bytes / (vq_us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4),
            "hbm_gbs": round(alg_bytes / (vq_us * 1e-6) / 1e9, 1),
-           "flop_frac": round(alg_flops / (vq_us * 1e-6) / 1e12 / engine_peak(mode), 4),
+           "flop_frac": round(alg_flops / (vq_us * 1e-6) / 1e12 / engine_peak(mode, "attn_vq_search_runs_bf16x3"), 4),
            "tflops": round(alg_flops / (vq_us * 1e-6) / 1e12, 1),
            "note": "lvt_vq_nearest on the z_e of one timed batch (all four codebooks): algorithmic bytes 270,336 B/frame "
                    "against the 8 TB/s HBM peak and 33.5 M MAC/frame against the engine ceiling (SURVEY 8d: 248 FLOP/B)"}

@@ -14,8 +14,9 @@
  *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*).
  *   - activations are CHANNELS-LAST: (N, T, H, W, C) with C fastest; a frame batch is T == 1.
  *   - arithmetic is fp32 in / fp32 out with fp32 accumulation on the matrix cores: by default every product is formed
- *     exactly from a 3-way bf16 split (six v_mfma_f32_32x32x16_bf16 per block), or on v_mfma_f32_32x32x2_f32 when a
- *     call carries LVT_MATH_F32 (see below).
+ *     exactly from a 3-way bf16 split (six v_mfma_f32_32x32x16_bf16 per block); from a 2-way fp16 split after an exact
+ *     power-of-two scale (three v_mfma_f32_32x32x16_f16) when a call carries LVT_MATH_F16X2; or on v_mfma_f32_32x32x2_f32
+ *     when it carries LVT_MATH_F32 (see below).
  */
 #ifndef LVT_HIP_H
 #define LVT_HIP_H
@@ -32,7 +33,7 @@ extern "C" {
 #define LVT_ENODEVICE   (-4)   /* no gfx950 device visible                             */
 
 const char *lvt_last_error(void);
-int lvt_version(void);          /* 300 = round 3 (ABI changes are listed in INTEGRATION.md) */
+int lvt_version(void);          /* 400 = round 4 (ABI changes are listed in INTEGRATION.md) */
 /* Device probe: name, CU count, clock (kHz), HBM bytes.  Returns LVT_ENODEVICE without a GPU. */
 int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long long *hbm_bytes);
 
@@ -45,6 +46,30 @@ int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long lon
  *       against fp64 is not larger than the fp32 instruction's (tests/test_gpu_engine.py::test_math_modes_accuracy).
  *   LVT_MATH_F32 "f32": plain v_mfma_f32_32x32x2_f32.                                                          */
 #define LVT_MATH_F32   (1 << 16)
+/*   LVT_MATH_F16X2 "f16x2": every fp32 operand element a is scaled by an exact power of two s taken from the operand's
+ *       max |a| (max |a| s in [2^14, 2^15): no overflow, no rounding) and split while it is staged in LDS into two fp16
+ *       terms, a s = hi + 2^-11 lo (hi = RN16(a s); the residual is exact in fp32; lo = RN16(2^11 residual): 22 bits + sign,
+ *       full for every element within 2^-27 of the max, degrading gradually below).  A block is three
+ *       v_mfma_f32_32x32x16_f16: hi hi into one fp32 accumulator, hi lo + lo hi into a second one that enters with weight
+ *       2^-11; the dropped lo lo term is <= 2^-22 |a||b| (2^-24.6 rms), the size of one fp32 rounding; every fp16 x fp16
+ *       product is exact in fp32.  Half the matrix instructions of bf16x3.  The caller supplies the operands' max |.| as
+ *       DEVICE scalars (any upper bound is safe; lvt_amax computes one, the engine's outputs can report theirs through
+ *       c_amax / lvt_amax_io.c so that no extra pass is needed along a chain of launches).  Entry points without an
+ *       f16x2 path (decode-time kernels, the VQ search, attention) ignore the flag and use bf16x3.                        */
+#define LVT_MATH_F16X2 (1 << 18)
+/* max |.| of the operands / result of one engine launch (device pointers; see LVT_MATH_F16X2).  a / b: inputs, required in
+ * f16x2 mode, ignored otherwise.  c: optional in EVERY mode -- the launch folds max |C| into *c with an integer atomic max
+ * on the bit pattern (exact and order-independent for non-negative floats), so *c must be zeroed (or hold a bound to keep)
+ * before the launch; not produced by split-K launches (their consumers are optimizers, not GEMMs).                       */
+typedef struct { const float *a; const float *b; float *c; } lvt_amax_io;
+/* *out = max(*out, max_i |x[i]|): the stand-alone form for tensors that no engine launch produced.                        */
+int lvt_amax(const float *x, long long n, float *out, void *stream);
+/* The same for many tensors in one launch per 64 (the weights of a model, once per pass); `entries` is a HOST array.        */
+typedef struct { const float *x; long long n; float *out; } lvt_amax_entry;
+int lvt_amax_multi(const lvt_amax_entry *entries, int n, void *stream);
+/* *out = max(*out, *a, *b) (b may be NULL): the bound of an operand that spans two tensors (batched launches whose batch
+ * strides are address differences, lvt_gemm_desc).                                                                        */
+int lvt_amax_merge(const float *a, const float *b, float *out, void *stream);
 /* lvt_vq_nearest only: coarse-then-exact search (one bf16 MFMA pass + exact re-evaluation of the codes inside the error band;
  * same exact argmin).  Faster on well-separated codebooks, slower on degenerate ones: opt-in, see csrc/vq.hip.            */
 #define LVT_VQ_COARSE  (1 << 17)
@@ -94,6 +119,8 @@ typedef struct {
      * weight gradients of the same shape run as ONE launch with sA_i = A1 - A0 etc. (half the k ranges, twice as long). */
     float *a_colsum;
     long long c_plane;                  /* LVT_EPI_PLANES: distance between the bf16 planes of C (elements)                 */
+    const float *a_amax, *b_amax;       /* LVT_MATH_F16X2: device scalars >= max |A|, max |B| (required in that mode)        */
+    float *c_amax;                      /* optional, any mode: max |C| is folded into *c_amax (see lvt_amax_io)              */
 } lvt_gemm_desc;
 size_t lvt_gemm_workspace_bytes(const lvt_gemm_desc *d);
 int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t workspace_bytes, void *stream);
@@ -156,10 +183,12 @@ int lvt_conv3d_fwd_uses_parity_kernel(const lvt_conv_geom *g, int flags);
 int lvt_conv3d_pack_weight_parity(const lvt_conv_geom *g, const float *w, int Ci_real, int Co_real,
                                   float *wq, void *stream);
 int lvt_conv3d_fwd_parity(const lvt_conv_geom *g, const float *x, const float *wq, const float *bias,
-                          const float *res, const float *mask, float *y, int flags, void *stream);
+                          const float *res, const float *mask, float *y, int flags, const lvt_amax_io *ax,
+        void *stream);
 /* y = epi( conv(x, wp) ); bias[Co]; res / y are (N,To,Ho,Wo,Co).  flags: BIAS|RESIDUAL|RELU|TANH|MASK */
 int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias,
-                   const float *res, const float *mask, float *y, int flags, void *stream);
+                   const float *res, const float *mask, float *y, int flags, const lvt_amax_io *ax,
+        void *stream);
 /* The same pass for the 4x4 / stride 2 / pad 1 layers between 32x32 and 16x16 frames (Co % 32 == 0, Ci % 128 == 0) on the
  * frame-resident kernel: every output phase (py, px) reads four taps of the ONE staged 18x18 patch of dy.  Weights packed
  * per phase by lvt_conv3d_pack_weight_phases: wph[(py,px)][(a,b)][co][ci] = w[co][ci][3-py-2a][3-px-2b].               */
@@ -167,12 +196,14 @@ int lvt_conv3d_bwd_data_uses_phase_kernel(const lvt_conv_geom *g, int flags);
 int lvt_conv3d_pack_weight_phases(const lvt_conv_geom *g, const float *w, int Ci_real, int Co_real,
                                   float *wph, void *stream);
 int lvt_conv3d_bwd_data_phases(const lvt_conv_geom *g, const float *dy, const float *wph, const float *bias,
-                               const float *res, const float *mask, float *dx, int flags, void *stream);
+                               const float *res, const float *mask, float *dx, int flags, const lvt_amax_io *ax,
+        void *stream);
 /* dx = epi( conv_transpose(dy, wp) ); res / mask / dx are (N,Ti,Hi,Wi,Ci).
  * flags: BIAS (bias[Ci], used when this IS a ConvTranspose forward) | RESIDUAL | RELU | TANH | MASK.
  * Requires Kt % st == 0 etc. and To*st == Ti-ish geometries produced by lvt_conv geometry helpers.  */
 int lvt_conv3d_bwd_data(const lvt_conv_geom *g, const float *dy, const float *wp, const float *bias,
-                        const float *res, const float *mask, float *dx, int flags, void *stream);
+                        const float *res, const float *mask, float *dx, int flags, const lvt_amax_io *ax,
+        void *stream);
 /* dw[Co_real][Ci_real][Kt][Kh][Kw] = sum_pixels x (*) dy, deterministic split-K through workspace.
  * db (nullable, Co_real floats) = sum_pixels dy: the bias gradient, accumulated from the dy tiles the kernel streams
  * anyway (no second pass over dy).                                                                         */
@@ -181,10 +212,12 @@ size_t lvt_conv3d_bwd_weight_workspace_bytes(const lvt_conv_geom *g);
  * channels on one side run on the frame-resident weight-gradient kernel (csrc/conv_wgrad.hip: patch and dy row staged once
  * per frame / image row, taps are row offsets of a transposing LDS read); pass db == NULL there and use lvt_colsum(dy). */
 int lvt_conv3d_bwd_weight_fuses_bias(const lvt_conv_geom *g, int flags);
-/* flags: 0 or LVT_MATH_F32 */
+/* flags: 0, LVT_MATH_F32 or LVT_MATH_F16X2 (ax->a = max |x|, ax->b = max |dy|; ax may be NULL otherwise).  The
+ * frame-resident kernel keeps the fp16 low term UNSCALED in f16x2 mode (one accumulator set for nine taps): full 22-bit
+ * operands within 2^-16 of the operand's max, gradually fewer bits below (csrc/conv_wgrad.hip).                          */
 int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, float *db,
-                          int Ci_real, int Co_real, int flags, void *workspace, size_t workspace_bytes,
-                          void *stream);
+                          int Ci_real, int Co_real, int flags, const lvt_amax_io *ax, void *workspace,
+                          size_t workspace_bytes, void *stream);
 /* Image-side layer (3 channels carried as 4): LDS-tiled fp32 FMA kernel that reads the 128-channel activation exactly
  * once instead of spending MFMA tiles on padding columns.
  * lvt_convt4_fwd: ConvTranspose2d(Ci -> Cr<=3, k4 s2 p1) forward, x (N,Hi,Wi,Ci) -> y (N,2Hi,2Wi,4) (+tanh);
@@ -225,7 +258,9 @@ int lvt_vq_ema_finalize(const float *stats, int num, int D, int KC, float decay,
  * to_channels_last : in [B][C][R] -> out [B][R][ldo] (columns >= C zero); mode 1: (x - a[c]) / s[c]
  * to_channels_first: in [B][R][ldi] -> out [B][C][R];  mode 2: clamp(x * s[c] + a[c], lo, hi)          */
 int lvt_to_channels_last(const float *in, int B, int C, long long R, int ldo, int mode, const float *a,
-                         const float *s, float *out, void *stream);
+                         const float *s, float *out, float *out_amax, void *stream);
+/* (out_amax, here and on lvt_mse_bwd / lvt_tanh_bwd: nullable, max |out| folded into a device scalar as lvt_amax_io.c is --
+ *  these tensors are operands of engine launches.)                                                                        */
 int lvt_to_channels_first(const float *in, int B, int C, long long R, int ldi, int mode, const float *a,
                           const float *s, float lo, float hi, float *out, void *stream);
 
@@ -236,8 +271,8 @@ int lvt_mse_fwd(const float *a, const float *b, long long n, double denom, float
                 void *workspace, size_t workspace_bytes, void *stream);
 /* out = add + gout[0] * (2*scale/denom) * (a-b) [* (1-a^2) if tanh_of_a]; gout/add may be NULL        */
 int lvt_mse_bwd(const float *a, const float *b, long long n, double denom, float scale,
-                const float *gout_dev, const float *add, int tanh_of_a, float *out, void *stream);
-int lvt_tanh_bwd(const float *g, const float *y, long long n, float *out, void *stream);
+                const float *gout_dev, const float *add, int tanh_of_a, float *out, float *out_amax, void *stream);
+int lvt_tanh_bwd(const float *g, const float *y, long long n, float *out, float *out_amax, void *stream);
 /* out = alpha * alpha_dev[0] * x (+ add)                                                              */
 int lvt_axpy(const float *x, const float *add, long long n, const float *alpha_dev, float alpha,
              float *out, void *stream);
@@ -246,12 +281,13 @@ int lvt_add_periodic(float *x, const float *table, long long rows, int P, int d,
 
 /* ---- LayerNorm over the last dim, eps inside the sqrt (F.layer_norm; K19) ---------------------------*/
 int lvt_layernorm_fwd(const float *x, long long rows, int d, float eps, const float *w, const float *b,
-                      float *y, float *mean, float *rstd, void *stream);
+                      float *y, float *mean, float *rstd, float *y_amax, void *stream);
+/* (y_amax / dx_amax, nullable: max |y| resp. max |dx| folded into a device scalar as lvt_amax_io.c is.)                  */
 size_t lvt_layernorm_bwd_workspace_bytes(int d);
 /* dx = LN'(dy) (+ add); dw[d], db[d] reduced in a fixed order                                        */
 int lvt_layernorm_bwd(const float *dy, const float *x, const float *mean, const float *rstd,
                       const float *w, long long rows, int d, const float *add, float *dx, float *dw,
-                      float *db, void *workspace, size_t workspace_bytes, void *stream);
+                      float *db, float *dx_amax, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- attention softmax with learned relative-position bias (vt_attention.py:59-81,142-174; K21,K22) ----
  * scores (B,H,S,S) in place:  softmax_j( s/temper + (dt[h][di_t] + dh[h][di_h]) + dw[h][di_w] ), with the
@@ -287,12 +323,14 @@ int lvt_attn_fwd(const float *q, const float *k, const float *v, int B, int H, i
 int lvt_attn_planes_supported(int S, int da, int bt, int bh, int bw);
 int lvt_attn_fwd_planes(const void *qkv_planes, long long plane_stride, long long operand_stride, int B, int H, int S, int da,
                         float temper, const float *dt, const float *dh, const float *dw, int bt, int bh, int bw, int masked,
-                        float fill, float *P, float *o, void *stream);
+                        float fill, float *P, float *o, float *o_amax, void *stream);
+/* (o_amax / d_amax, nullable: max |o| resp. max over dq, dk, dv folded into a device scalar as lvt_amax_io.c is -- the
+ *  outputs feed engine launches.)                                                                                          */
 size_t lvt_attn_bwd_planes_workspace_bytes(int B, int H, int S, int bt, int bh, int bw);
 int lvt_attn_bwd_planes(const void *qkv_planes, long long plane_stride, long long operand_stride, const void *do_planes,
                         const float *P, const float *o, int B, int H, int S, int da, float temper, int bt, int bh, int bw,
-                        int masked, float *dq, float *dk, float *dv, float *ddt, float *ddh, float *ddw, void *workspace,
-                        size_t workspace_bytes, void *stream);
+                        int masked, float *dq, float *dk, float *dv, float *ddt, float *ddh, float *ddw, float *d_amax,
+                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* single-query attention against a token-major K/V cache (incremental sampling: the reference re-runs the
  * whole causal decoder for every generated pixel, vt.py:121-131).  q (B rows of H*da, row stride ldq), o (B, H*da), caches (B, S, H*da);
@@ -332,7 +370,9 @@ int lvt_embbag_fwd(const long long *idx, long long bstride, int P, long long row
 size_t lvt_onehot_tn_workspace_bytes(int nslots, int V, int N, long long rows);
 int lvt_onehot_tn_gemm(const long long *idx, int nslots, int V, const int *slot_off, long long bstride,
                        long long pstride, int P, long long rows, const float *dout, long long ldb, int N,
-                       float *out, int flags, void *workspace, size_t workspace_bytes, void *stream);
+                       float *out, int flags, const float *dout_amax, void *workspace, size_t workspace_bytes,
+                       void *stream);
+/* (dout_amax: max |dout| as a device scalar, LVT_MATH_F16X2 only; the one-hot operand is exact in fp16 as it is.)     */
 /* out (n0,n1,n2) contiguous <- in[i0*s0 + i1*s1 + i2*s2]  (weight re-layouts)                         */
 int lvt_permute3(const float *in, long long s0, long long s1, long long s2, int n0, int n1, int n2,
                  float *out, void *stream);

@@ -117,7 +117,7 @@ template <int BH, int BW> struct Geo16 {
 };
 
 template <int BT, int BH, int BW, int MASKED, int NCH>
-__device__ __forceinline__ void attn_fwd16_body(const PlaneArgs pa, int H, float inv_temper, const float *__restrict__ dt,
+__device__ __forceinline__ float attn_fwd16_body(const PlaneArgs pa, int H, float inv_temper, const float *__restrict__ dt,
                                                 const float *__restrict__ dh, const float *__restrict__ dw, float fill,
                                                 float *__restrict__ P, float *__restrict__ o, unsigned short *X, int bh_,
                                                 int qhalf) {
@@ -286,20 +286,31 @@ __device__ __forceinline__ void attn_fwd16_body(const PlaneArgs pa, int H, float
 #pragma unroll
         for (int dtile = 0; dtile < AT_D / 16; ++dtile) *reinterpret_cast<f32x4v *>(orow + 16 * dtile) = oacc[dtile];
     }
+    float am = 0.f;          // max |o| of this lane's stores (reported through o_amax for the f16x2 engine launches downstream)
+#pragma unroll
+    for (int dtile = 0; dtile < AT_D / 16; ++dtile)
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(oacc[dtile][0]), fabsf(oacc[dtile][1])), fmaxf(fabsf(oacc[dtile][2]), fabsf(oacc[dtile][3]))));
+    return am;
 }
 
 template <int BT, int BH, int BW, int MASKED>
 __global__ __launch_bounds__(512, 1) void lvt_attn_fwd16_planes_kernel(const PlaneArgs pa, int H, float inv_temper,
                                                                        const float *__restrict__ dt, const float *__restrict__ dh,
                                                                        const float *__restrict__ dw, float fill,
-                                                                       float *__restrict__ P, float *__restrict__ o) {
+                                                                       float *__restrict__ P, float *__restrict__ o,
+                                                                       float *__restrict__ o_amax) {
     __shared__ __attribute__((aligned(16))) unsigned short X[2 * A16_SLOT];
+    float am;
     if (MASKED) {        // one workgroup = both query halves of a (sample, head): 4 + 2 key chunks (see the note at ap_pair)
-        attn_fwd16_body<BT, BH, BW, MASKED, 4>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X, blockIdx.x, 1);
+        am = attn_fwd16_body<BT, BH, BW, MASKED, 4>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X, blockIdx.x, 1);
         __syncthreads();
-        attn_fwd16_body<BT, BH, BW, MASKED, 2>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X, ap_opaque(blockIdx.x), 0);
+        am = fmaxf(am, attn_fwd16_body<BT, BH, BW, MASKED, 2>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X, ap_opaque(blockIdx.x), 0));
     } else {
-        attn_fwd16_body<BT, BH, BW, MASKED, 4>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X, ap_pair(blockIdx.x), ap_half(blockIdx.x));
+        am = attn_fwd16_body<BT, BH, BW, MASKED, 4>(pa, H, inv_temper, dt, dh, dw, fill, P, o, X, ap_pair(blockIdx.x), ap_half(blockIdx.x));
+    }
+    if (o_amax) {
+        __syncthreads();
+        lvt_block_amax_commit(am, o_amax, reinterpret_cast<float *>(X));
     }
 }
 
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(512, 1) void lvt_attn_fwd16_planes_kernel(const Pla
 // backward on 16-wide tiles (eight waves per workgroup, two per SIMD): A16 = dS, dQ, bank sums; B16 = dV, dK.  BW == 16.
 // =====================================================================================================================
 template <int BT, int BH, int BW, int MASKED, int NCH>
-__device__ __forceinline__ void attn_bwd_a16_body(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
+__device__ __forceinline__ float attn_bwd_a16_body(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
                                                   float inv_temper, const float *__restrict__ P, const float *__restrict__ o,
                                                   float *__restrict__ dS, float *__restrict__ dq, float *__restrict__ bank_partial,
                                                   unsigned short *X, int bh_, int qhalf) {
@@ -457,6 +468,10 @@ __device__ __forceinline__ void attn_bwd_a16_body(const PlaneArgs pa, const unsi
 #pragma unroll
         for (int dtile = 0; dtile < AT_D / 16; ++dtile) *reinterpret_cast<f32x4v *>(qrow + 16 * dtile) = oacc[dtile];
     }
+    float am = 0.f;          // max |dq| of this lane's stores
+#pragma unroll
+    for (int dtile = 0; dtile < AT_D / 16; ++dtile)
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(oacc[dtile][0]), fabsf(oacc[dtile][1])), fmaxf(fabsf(oacc[dtile][2]), fabsf(oacc[dtile][3]))));
     // ---- bias-bank gradient of this (sample, head, query half): two fixed-order stages through LDS ----
     float *R = reinterpret_cast<float *>(X);                          // [128 queries][4 kg][NR]
     float *R2 = R + 128 * 4 * NR;                                     // [8 parts][NB]
@@ -502,26 +517,34 @@ __device__ __forceinline__ void attn_bwd_a16_body(const PlaneArgs pa, const unsi
         for (int part = 0; part < 8; ++part) acc += R2[part * BI::NB + tid];
         bank_partial[((long long)bh_ * 2 + qhalf) * BI::NB + tid] = acc;
     }
+    return am;
 }
 
 template <int BT, int BH, int BW, int MASKED>
 __global__ __launch_bounds__(512, 1) void lvt_attn_bwd_a16_kernel(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
                                                                   float inv_temper, const float *__restrict__ P,
                                                                   const float *__restrict__ o, float *__restrict__ dS,
-                                                                  float *__restrict__ dq, float *__restrict__ bank_partial) {
+                                                                  float *__restrict__ dq, float *__restrict__ bank_partial,
+                                                                  float *__restrict__ d_amax) {
     __shared__ __attribute__((aligned(16))) unsigned short X[2 * A16_SLOT];
+    float am;
     if (MASKED) {
-        attn_bwd_a16_body<BT, BH, BW, MASKED, 4>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X, blockIdx.x, 1);
+        am = attn_bwd_a16_body<BT, BH, BW, MASKED, 4>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X, blockIdx.x, 1);
         __syncthreads();
-        attn_bwd_a16_body<BT, BH, BW, MASKED, 2>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X, ap_opaque(blockIdx.x), 0);
+        am = fmaxf(am, attn_bwd_a16_body<BT, BH, BW, MASKED, 2>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X,
+                                                                ap_opaque(blockIdx.x), 0));
     } else {
-        attn_bwd_a16_body<BT, BH, BW, MASKED, 4>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X, ap_pair(blockIdx.x),
-                                                 ap_half(blockIdx.x));
+        am = attn_bwd_a16_body<BT, BH, BW, MASKED, 4>(pa, dop, H, inv_temper, P, o, dS, dq, bank_partial, X, ap_pair(blockIdx.x),
+                                                      ap_half(blockIdx.x));
+    }
+    if (d_amax) {
+        __syncthreads();
+        lvt_block_amax_commit(am, d_amax, reinterpret_cast<float *>(X));
     }
 }
 
 template <int C0, int NCH>
-__device__ __forceinline__ void attn_bwd_b16_body(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
+__device__ __forceinline__ float attn_bwd_b16_body(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
                                                   const float *__restrict__ P, const float *__restrict__ dS,
                                                   float *__restrict__ dk, float *__restrict__ dv, unsigned short *X, int bh_,
                                                   int khalf) {
@@ -605,19 +628,31 @@ __device__ __forceinline__ void attn_bwd_b16_body(const PlaneArgs pa, const unsi
             *reinterpret_cast<f32x4v *>(krow + 16 * dtile) = acck[dtile];
         }
     }
+    float am = 0.f;          // max |dk|, |dv| of this lane's stores
+#pragma unroll
+    for (int dtile = 0; dtile < AT_D / 16; ++dtile)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) am = fmaxf(am, fmaxf(fabsf(accv[dtile][e]), fabsf(acck[dtile][e])));
+    return am;
 }
 
 template <int MASKED>
 __global__ __launch_bounds__(512, 1) void lvt_attn_bwd_b16_kernel(const PlaneArgs pa, const unsigned short *__restrict__ dop, int H,
                                                                   const float *__restrict__ P, const float *__restrict__ dS,
-                                                                  float *__restrict__ dk, float *__restrict__ dv) {
+                                                                  float *__restrict__ dk, float *__restrict__ dv,
+                                                                  float *__restrict__ d_amax) {
     __shared__ __attribute__((aligned(16))) unsigned short X[2 * A16_SLOT];
+    float am;
     if (MASKED) {        // key half 0 meets all four query chunks, key half 1 the last two
-        attn_bwd_b16_body<0, 4>(pa, dop, H, P, dS, dk, dv, X, blockIdx.x, 0);
+        am = attn_bwd_b16_body<0, 4>(pa, dop, H, P, dS, dk, dv, X, blockIdx.x, 0);
         __syncthreads();
-        attn_bwd_b16_body<2, 2>(pa, dop, H, P, dS, dk, dv, X, ap_opaque(blockIdx.x), 1);
+        am = fmaxf(am, attn_bwd_b16_body<2, 2>(pa, dop, H, P, dS, dk, dv, X, ap_opaque(blockIdx.x), 1));
     } else {
-        attn_bwd_b16_body<0, 4>(pa, dop, H, P, dS, dk, dv, X, ap_pair(blockIdx.x), ap_half(blockIdx.x));
+        am = attn_bwd_b16_body<0, 4>(pa, dop, H, P, dS, dk, dv, X, ap_pair(blockIdx.x), ap_half(blockIdx.x));
+    }
+    if (d_amax) {
+        __syncthreads();
+        lvt_block_amax_commit(am, d_amax, reinterpret_cast<float *>(X));
     }
 }
 
@@ -649,7 +684,7 @@ extern "C" int lvt_attn_planes_supported(int S, int da, int bt, int bh, int bw) 
 
 extern "C" int lvt_attn_fwd_planes(const void *qkv_planes, long long plane_stride, long long operand_stride, int B, int H, int S,
                                    int da, float temper, const float *dt, const float *dh, const float *dw, int bt, int bh,
-                                   int bw, int masked, float fill, float *P, float *o, void *stream) {
+                                   int bw, int masked, float fill, float *P, float *o, float *o_amax, void *stream) {
     LVT_REQUIRE(qkv_planes && dt && dh && dw && P && o && B > 0 && H > 0, "attn_fwd_planes: bad args");
     LVT_REQUIRE((B * H) % 8 == 0, "attn_fwd_planes: B * H = %d must be a multiple of 8 (workgroup pairing per XCD)", B * H);
     LVT_REQUIRE(lvt_attn_planes_supported(S, da, bt, bh, bw), "attn_fwd_planes: S=%d da=%d block (%d,%d,%d) has no instantiation", S, da, bt, bh, bw);
@@ -662,8 +697,8 @@ extern "C" int lvt_attn_fwd_planes(const void *qkv_planes, long long plane_strid
     const float it = 1.f / temper;
 #define LVT_X(BT, BH, BW)                                                                                                            \
     if (bt == BT && bh == BH && bw == BW) {                                                                                          \
-        if (masked) hipLaunchKernelGGL((lvt_attn_fwd16_planes_kernel<BT, BH, BW, 1>), grid, blk, 0, s, pa, H, it, dt, dh, dw, fill, P, o); \
-        else hipLaunchKernelGGL((lvt_attn_fwd16_planes_kernel<BT, BH, BW, 0>), grid, blk, 0, s, pa, H, it, dt, dh, dw, fill, P, o);        \
+        if (masked) hipLaunchKernelGGL((lvt_attn_fwd16_planes_kernel<BT, BH, BW, 1>), grid, blk, 0, s, pa, H, it, dt, dh, dw, fill, P, o, o_amax); \
+        else hipLaunchKernelGGL((lvt_attn_fwd16_planes_kernel<BT, BH, BW, 0>), grid, blk, 0, s, pa, H, it, dt, dh, dw, fill, P, o, o_amax); \
     }
     LVT_AP_GEOMS(LVT_X)
 #undef LVT_X
@@ -679,7 +714,7 @@ extern "C" size_t lvt_attn_bwd_planes_workspace_bytes(int B, int H, int S, int b
 extern "C" int lvt_attn_bwd_planes(const void *qkv_planes, long long plane_stride, long long operand_stride, const void *do_planes,
                                    const float *P, const float *o, int B, int H, int S, int da, float temper, int bt, int bh,
                                    int bw, int masked, float *dq, float *dk, float *dv, float *ddt, float *ddh, float *ddw,
-                                   void *workspace, size_t workspace_bytes, void *stream) {
+                                   float *d_amax, void *workspace, size_t workspace_bytes, void *stream) {
     LVT_REQUIRE(qkv_planes && do_planes && P && o && dq && dk && dv && ddt && ddh && ddw && B > 0 && H > 0, "attn_bwd_planes: bad args");
     LVT_REQUIRE((B * H) % 8 == 0, "attn_bwd_planes: B * H = %d must be a multiple of 8 (workgroup pairing per XCD)", B * H);
     LVT_REQUIRE(lvt_attn_planes_supported(S, da, bt, bh, bw), "attn_bwd_planes: S=%d da=%d block (%d,%d,%d) has no instantiation", S, da, bt, bh, bw);
@@ -698,14 +733,14 @@ extern "C" int lvt_attn_bwd_planes(const void *qkv_planes, long long plane_strid
     const float it = 1.f / temper;
 #define LVT_X(BT, BH, BW)                                                                                                            \
     if (bt == BT && bh == BH && bw == BW) {                                                                                          \
-        if (masked) hipLaunchKernelGGL((lvt_attn_bwd_a16_kernel<BT, BH, BW, 1>), grid, blk, 0, s, pa, dop, H, it, P, o, dS, dq, partial);  \
-        else hipLaunchKernelGGL((lvt_attn_bwd_a16_kernel<BT, BH, BW, 0>), grid, blk, 0, s, pa, dop, H, it, P, o, dS, dq, partial);         \
+        if (masked) hipLaunchKernelGGL((lvt_attn_bwd_a16_kernel<BT, BH, BW, 1>), grid, blk, 0, s, pa, dop, H, it, P, o, dS, dq, partial, d_amax);  \
+        else hipLaunchKernelGGL((lvt_attn_bwd_a16_kernel<BT, BH, BW, 0>), grid, blk, 0, s, pa, dop, H, it, P, o, dS, dq, partial, d_amax);  \
     }
     LVT_AP_GEOMS(LVT_X)
 #undef LVT_X
     LVT_CHECK_LAUNCH("lvt_attn_bwd_a16_kernel");
-    if (masked) hipLaunchKernelGGL((lvt_attn_bwd_b16_kernel<1>), grid, blk, 0, s, pa, dop, H, P, dS, dk, dv);
-    else hipLaunchKernelGGL((lvt_attn_bwd_b16_kernel<0>), grid, blk, 0, s, pa, dop, H, P, dS, dk, dv);
+    if (masked) hipLaunchKernelGGL((lvt_attn_bwd_b16_kernel<1>), grid, blk, 0, s, pa, dop, H, P, dS, dk, dv, d_amax);
+    else hipLaunchKernelGGL((lvt_attn_bwd_b16_kernel<0>), grid, blk, 0, s, pa, dop, H, P, dS, dk, dv, d_amax);
     LVT_CHECK_LAUNCH("lvt_attn_bwd_b16_kernel");
     hipLaunchKernelGGL(lvt_attn_bank_reduce_kernel, dim3((unsigned)lvt_cdiv((long long)H * nb, 4)), dim3(256), 0, s, partial, B, H, nb,
                        nt, nh, ddt, ddh, ddw);

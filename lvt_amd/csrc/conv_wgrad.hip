@@ -36,6 +36,7 @@ struct WgParams {
     const float *P, *Q;
     int Cp, N, frames_per_split, nchunks;
     float *partial; long long partial_stride;
+    const float *p_amax, *q_amax;        // MATH == 2: max |P|, max |Q| (device scalars)
 };
 // MODE 0: 3x3 / stride 1 / pad 1 on 16x16 frames: nine taps over the 18x18 patch, as described above.
 // MODE 1: 4x4 / stride 2 / pad 1 between a 32x32 frame (patch operand, Cp channels) and a 16x16 frame (slab operand, 256
@@ -57,6 +58,39 @@ __device__ __forceinline__ void wg_split4(const float4 v, uint2 &p1, uint2 &p2, 
     const float s2 = r2 - __uint_as_float(p2.y << 16), s3 = r3 - __uint_as_float(p2.y & 0xffff0000u);
     p3.x = wg_cvt_pk(s0, s1); p3.y = wg_cvt_pk(s2, s3);
 }
+// f16x2 arithmetic (LVT_MATH_F16X2; gemm_engine.hip describes the split): a * s = hi + lo with lo = RN16(a s - hi) kept
+// UNSCALED here, so that hi hi + hi lo + lo hi accumulate into ONE register set -- nine taps x two sets would not fit.
+// lo then resolves down to 2^-24: all 22 + sign bits for the elements within 2^-16 of the operand's max, fewer below
+// (absolute error <= 2^-40 max |a| per element: invisible in a reduction over 131072 pixels of mixed magnitudes).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned wg_f16_pair(float a, float b, float s) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0\n\tv_fma_mixhi_f16 %0, %3, %2, 0" : "=&v"(r) : "v"(a), "v"(s), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float wg_resid_lo(float a, float s, unsigned h) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(s), "v"(h));
+    return r;
+}
+__device__ __forceinline__ float wg_resid_hi(float a, float s, unsigned h) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(s), "v"(h));
+    return r;
+}
+__device__ __forceinline__ void wg_split2(const float4 v, const float s, uint2 &ph, uint2 &pl) {
+    ph.x = wg_f16_pair(v.x, v.y, s); ph.y = wg_f16_pair(v.z, v.w, s);
+    pl.x = wg_f16_pair(wg_resid_lo(v.x, s, ph.x), wg_resid_hi(v.y, s, ph.x), 1.f);
+    pl.y = wg_f16_pair(wg_resid_lo(v.z, s, ph.y), wg_resid_hi(v.w, s, ph.y), 1.f);
+}
+__device__ __forceinline__ float wg_f16_scale(const float *amax, int &unscale) {     // = lvt_f16_scale (gemm_engine.hip)
+    if (!amax) return 1.f;
+    const int eb = (int)((__float_as_uint(*amax) >> 23) & 0xffu);
+    int se = 268 - eb;
+    se = se < 2 ? 2 : (se > 252 ? 252 : se);
+    unscale -= se - 127;
+    return __uint_as_float((unsigned)se << 23);
+}
 // 8 reduction rows (4 + 4) of the lane's column: two transposing reads, `pitch4` = 4 rows further (bf16 elements)
 __device__ __forceinline__ bf16x8 wg_frag(const unsigned short *p, int pitch4) {
     typedef __attribute__((address_space(3))) s16x4 lds_v4;
@@ -67,11 +101,15 @@ __device__ __forceinline__ bf16x8 wg_frag(const unsigned short *p, int pitch4) {
     return u.v;
 }
 
-template <int MODE>
+template <int MODE, int MATH>
 __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const WgParams p) {
     constexpr int NTAPS = MODE == 0 ? 9 : 4;
-    __shared__ __attribute__((aligned(16))) unsigned short lds[3 * WG_PPL + 2 * 3 * WG_QPL];
-    unsigned short *patch = lds, *slab0 = lds + 3 * WG_PPL;
+    constexpr int NP = MATH == 2 ? 2 : 3;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[NP * WG_PPL + 2 * NP * WG_QPL];
+    unsigned short *patch = lds, *slab0 = lds + NP * WG_PPL;
+    int unscale = 0;
+    float sp = 1.f, sq = 1.f;
+    if (MATH == 2) { sp = wg_f16_scale(p.p_amax, unscale); sq = wg_f16_scale(p.q_amax, unscale); }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // workgroup b runs on XCD b % 8 and every XCD has its own L2: the chunks of one split read the same frames (all of
     // the slab operand, the same patch pixels), so the split index is the fast one -- its low bits pick the XCD
@@ -106,12 +144,19 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
         for (int j = 0; j < PPASS; ++j) {
             const int u = tid + WG_THREADS * j;
             if (u < PUNITS) {
-                uint2 p1, p2, p3;
-                wg_split4(pv[j], p1, p2, p3);
                 unsigned short *d = patch + (u >> 3) * WG_PP + (u & 7) * 4;
-                *reinterpret_cast<uint2 *>(d) = p1;
-                *reinterpret_cast<uint2 *>(d + WG_PPL) = p2;
-                *reinterpret_cast<uint2 *>(d + 2 * WG_PPL) = p3;
+                if (MATH == 2) {
+                    uint2 ph, pl;
+                    wg_split2(pv[j], sp, ph, pl);
+                    *reinterpret_cast<uint2 *>(d) = ph;
+                    *reinterpret_cast<uint2 *>(d + WG_PPL) = pl;
+                } else {
+                    uint2 p1, p2, p3;
+                    wg_split4(pv[j], p1, p2, p3);
+                    *reinterpret_cast<uint2 *>(d) = p1;
+                    *reinterpret_cast<uint2 *>(d + WG_PPL) = p2;
+                    *reinterpret_cast<uint2 *>(d + 2 * WG_PPL) = p3;
+                }
             }
         }
     };
@@ -124,12 +169,19 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int u = tid + WG_THREADS * j;
-            uint2 p1, p2, p3;
-            wg_split4(qv[j], p1, p2, p3);
             unsigned short *d = slab + (u >> 6) * WG_QP + (u & 63) * 4;
-            *reinterpret_cast<uint2 *>(d) = p1;
-            *reinterpret_cast<uint2 *>(d + WG_QPL) = p2;
-            *reinterpret_cast<uint2 *>(d + 2 * WG_QPL) = p3;
+            if (MATH == 2) {
+                uint2 ph, pl;
+                wg_split2(qv[j], sq, ph, pl);
+                *reinterpret_cast<uint2 *>(d) = ph;
+                *reinterpret_cast<uint2 *>(d + WG_QPL) = pl;
+            } else {
+                uint2 p1, p2, p3;
+                wg_split4(qv[j], p1, p2, p3);
+                *reinterpret_cast<uint2 *>(d) = p1;
+                *reinterpret_cast<uint2 *>(d + WG_QPL) = p2;
+                *reinterpret_cast<uint2 *>(d + 2 * WG_QPL) = p3;
+            }
         }
     };
 
@@ -166,17 +218,35 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
             const bool last_row = y == 15;
             const int r = f * 16 + y;
             if (early) {
-                if (r + 1 < r_end) slab_store(slab0 + (buf ^ 1) * (3 * WG_QPL));
+                if (r + 1 < r_end) slab_store(slab0 + (buf ^ 1) * (NP * WG_QPL));
                 slab_fetch_row(r + 2);
             } else {
                 slab_fetch_row(r + 1);
             }
             if (last_row && next_frame) patch_fetch(f + 1);
-            const unsigned short *slab = slab0 + buf * (3 * WG_QPL);
-            bf16x8 b[3];
+            const unsigned short *slab = slab0 + buf * (NP * WG_QPL);
+            bf16x8 b[NP];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) b[q] = wg_frag(slab + boff + q * WG_QPL, 4 * WG_QP);
+            for (int q = 0; q < NP; ++q) b[q] = wg_frag(slab + boff + q * WG_QPL, 4 * WG_QP);
             constexpr int TD = MODE == 0 ? 3 : 2;                                         // taps per dimension
+            if constexpr (MATH == 2) {
+#pragma unroll
+                for (int dy = 0; dy < TD; ++dy) {
+                    bf16x8 a[TD][2];
+#pragma unroll
+                    for (int dx = 0; dx < TD; ++dx)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+                            a[dx][q] = wg_frag(patch + ((y + dy) * WG_PW + dx) * WG_PP + aoff + q * WG_PPL, 4 * WG_PP);
+                    constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};                    // lo hi, hi lo, hi hi
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int dx = 0; dx < TD; ++dx)
+                            acc[dy * TD + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                __builtin_bit_cast(f16x8, a[dx][TA[t]]), __builtin_bit_cast(f16x8, b[TB[t]]), acc[dy * TD + dx], 0, 0, 0);
+                }
+            } else {
 #pragma unroll
             for (int dy = 0; dy < TD; ++dy) {
                 // one tap row at a time: consecutive MFMAs go to different accumulators
@@ -193,7 +263,8 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
                     for (int dx = 0; dx < TD; ++dx)
                         acc[dy * TD + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dx][TA[t]], b[TB[t]], acc[dy * TD + dx], 0, 0, 0);
             }
-            if (!early && r + 1 < r_end) slab_store(slab0 + (buf ^ 1) * (3 * WG_QPL));
+            }
+            if (!early && r + 1 < r_end) slab_store(slab0 + (buf ^ 1) * (NP * WG_QPL));
             if (last_row && next_frame) {
                 __syncthreads();             // every wave is done with this frame's patch
                 patch_store();
@@ -211,7 +282,7 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-            out[((long long)trow * Cp + m) * WG_CQ] = acc[t][r];
+            out[((long long)trow * Cp + m) * WG_CQ] = MATH == 2 ? ldexpf(acc[t][r], unscale) : acc[t][r];
         }
     }
 }
@@ -239,7 +310,7 @@ __global__ void lvt_unpack_wgrad_swapped_kernel(const float *__restrict__ partia
 static int wg_role(const lvt_conv_geom *g, int flags = 0) {
     static const int off = getenv("LVT_NO_FRAME_WGRAD") ? 1 : 0;
     static const int off2 = getenv("LVT_NO_FRAME_WGRAD_S2") ? 1 : 0;
-    if (off || (flags & LVT_MATH_F32)) return 0;
+    if (off || (flags & LVT_MATH_F32)) return 0;                // (bf16x3 and f16x2 are both served)
     if (g->Kt != 1 || g->pt != 0 || g->Ti != 1 || g->To != 1 || g->st != 1 || g->Ho != 16 || g->Wo != 16) return 0;
     if (g->Kh == 3 && g->Kw == 3 && g->sh == 1 && g->sw == 1 && g->ph == 1 && g->pw == 1 && g->Hi == 16 && g->Wi == 16) {
         if (g->Co == WG_CQ && g->Ci % 32 == 0) return 1;
@@ -264,18 +335,25 @@ size_t lvt_wgrad_frames_workspace_bytes(const lvt_conv_geom *g) {
 }
 int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, int Ci_real, int Co_real,
                             void *workspace, hipStream_t s, void (*unpack_plain)(const float *, long long, int, float *,
-                                                                                 const lvt_conv_geom *, int, int, hipStream_t)) {
+                                                                                 const lvt_conv_geom *, int, int, hipStream_t),
+                            const float *x_amax, const float *dy_amax) {
     const int role = wg_role(g);
+    const bool f16 = x_amax && dy_amax;                  // LVT_MATH_F16X2 (checked by the caller)
     WgParams p;
     p.P = role == 2 ? dy : x; p.Q = role == 2 ? x : dy;
+    p.p_amax = role == 2 ? dy_amax : x_amax; p.q_amax = role == 2 ? x_amax : dy_amax;
     p.Cp = role == 2 ? g->Co : g->Ci; p.N = g->N; p.nchunks = p.Cp / 32;
     const int splits = wg_splits(g, role);
     p.frames_per_split = (g->N + splits - 1) / splits;
     p.partial = (float *)workspace; p.partial_stride = (long long)g->Kh * g->Kw * g->Ci * g->Co;
-    if (role == 3)
-        hipLaunchKernelGGL(lvt_conv_wgrad_frames_kernel<1>, dim3((unsigned)(4 * p.nchunks * splits)), dim3(WG_THREADS), 0, s, p);
+    if (role == 3 && f16)
+        hipLaunchKernelGGL((lvt_conv_wgrad_frames_kernel<1, 2>), dim3((unsigned)(4 * p.nchunks * splits)), dim3(WG_THREADS), 0, s, p);
+    else if (role == 3)
+        hipLaunchKernelGGL((lvt_conv_wgrad_frames_kernel<1, 1>), dim3((unsigned)(4 * p.nchunks * splits)), dim3(WG_THREADS), 0, s, p);
+    else if (f16)
+        hipLaunchKernelGGL((lvt_conv_wgrad_frames_kernel<0, 2>), dim3((unsigned)(p.nchunks * splits)), dim3(WG_THREADS), 0, s, p);
     else
-        hipLaunchKernelGGL(lvt_conv_wgrad_frames_kernel<0>, dim3((unsigned)(p.nchunks * splits)), dim3(WG_THREADS), 0, s, p);
+        hipLaunchKernelGGL((lvt_conv_wgrad_frames_kernel<0, 1>), dim3((unsigned)(p.nchunks * splits)), dim3(WG_THREADS), 0, s, p);
     LVT_CHECK_LAUNCH("lvt_conv_wgrad_frames_kernel");
     if (role != 2) {
         unpack_plain(p.partial, p.partial_stride, splits, dw, g, Ci_real, Co_real, s);

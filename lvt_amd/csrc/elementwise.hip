@@ -31,7 +31,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // ------------------------------------------------------------------------------------------------
 __global__ void lvt_to_channels_last_kernel(const float *__restrict__ in, int B, int C, long long R, int ldo,
                                             int mode, const float *__restrict__ a, const float *__restrict__ s,
-                                            float *__restrict__ out) {
+                                            float *__restrict__ out, float *__restrict__ out_amax) {
+    __shared__ float amax_scratch[4];
+    float am = 0.f;
     const long long total = (long long)B * R * ldo;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -43,7 +45,9 @@ __global__ void lvt_to_channels_last_kernel(const float *__restrict__ in, int B,
             if (mode == 1) v = (v - a[c]) / s[c];
         }
         out[i] = v;
+        am = fmaxf(am, fabsf(v));
     }
+    if (out_amax) lvt_block_amax_commit(am, out_amax, amax_scratch);
 }
 __global__ void lvt_to_channels_first_kernel(const float *__restrict__ in, int B, int C, long long R, int ldi,
                                              int mode, const float *__restrict__ a, const float *__restrict__ s,
@@ -60,11 +64,11 @@ __global__ void lvt_to_channels_first_kernel(const float *__restrict__ in, int B
 }
 
 extern "C" int lvt_to_channels_last(const float *in, int B, int C, long long R, int ldo, int mode, const float *a,
-                                    const float *s, float *out, void *stream) {
+                                    const float *s, float *out, float *out_amax, void *stream) {
     LVT_REQUIRE(in && out && B > 0 && C > 0 && R > 0 && ldo >= C, "to_channels_last: bad args");
     LVT_REQUIRE(mode == 0 || (a && s), "to_channels_last: affine tables missing");
-    hipLaunchKernelGGL(lvt_to_channels_last_kernel, dim3(grid_for((long long)B * R * ldo, 256)), dim3(256), 0,
-                       (hipStream_t)stream, in, B, C, R, ldo, mode, a, s, out);
+    hipLaunchKernelGGL(lvt_to_channels_last_kernel, dim3(grid_for((long long)B * R * ldo, 256, out_amax ? 2048 : 8192)), dim3(256), 0,
+                       (hipStream_t)stream, in, B, C, R, ldo, mode, a, s, out, out_amax);
     LVT_CHECK_LAUNCH("lvt_to_channels_last_kernel");
     return LVT_OK;
 }
@@ -138,7 +142,9 @@ extern "C" int lvt_mse_fwd(const float *a, const float *b, long long n, double d
 // out = add + g * (2*scale/denom) * (a - b) [* (1 - a^2)]      g = gout_dev[0] (or 1)
 __global__ void lvt_mse_bwd_kernel(const float *__restrict__ a, const float *__restrict__ b, long long n4, float c,
                                    const float *__restrict__ gout, const float *__restrict__ add, int tanh_of_a,
-                                   float *__restrict__ out) {
+                                   float *__restrict__ out, float *__restrict__ out_amax) {
+    __shared__ float amax_scratch[4];
+    float am = 0.f;
     const float g = (gout ? gout[0] : 1.0f) * c;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
@@ -153,13 +159,15 @@ __global__ void lvt_mse_bwd_kernel(const float *__restrict__ a, const float *__r
             r.x += z.x; r.y += z.y; r.z += z.z; r.w += z.w;
         }
         reinterpret_cast<float4 *>(out)[i] = r;
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
     }
+    if (out_amax) lvt_block_amax_commit(am, out_amax, amax_scratch);
 }
 extern "C" int lvt_mse_bwd(const float *a, const float *b, long long n, double denom, float scale,
-                           const float *gout_dev, const float *add, int tanh_of_a, float *out, void *stream) {
+                           const float *gout_dev, const float *add, int tanh_of_a, float *out, float *out_amax, void *stream) {
     LVT_REQUIRE(a && b && out && n > 0 && n % 4 == 0 && denom > 0, "mse_bwd: bad args");
-    hipLaunchKernelGGL(lvt_mse_bwd_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b,
-                       n / 4, (float)(2.0 * (double)scale / denom), gout_dev, add, tanh_of_a, out);
+    hipLaunchKernelGGL(lvt_mse_bwd_kernel, dim3(grid_for(n / 4, 256, out_amax ? 2048 : 8192)), dim3(256), 0, (hipStream_t)stream, a, b,
+                       n / 4, (float)(2.0 * (double)scale / denom), gout_dev, add, tanh_of_a, out, out_amax);
     LVT_CHECK_LAUNCH("lvt_mse_bwd_kernel");
     return LVT_OK;
 }
@@ -183,19 +191,23 @@ extern "C" int lvt_axpy(const float *x, const float *add, long long n, const flo
 
 // out = g * (1 - y^2)   (tanh backward at the end of the decoder chain)
 __global__ void lvt_tanh_bwd_kernel(const float *__restrict__ g, const float *__restrict__ y, long long n4,
-                                    float *__restrict__ out) {
+                                    float *__restrict__ out, float *__restrict__ out_amax) {
+    __shared__ float amax_scratch[4];
+    float am = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         const float4 a = reinterpret_cast<const float4 *>(g)[i];
         const float4 t = reinterpret_cast<const float4 *>(y)[i];
-        reinterpret_cast<float4 *>(out)[i] = make_float4(a.x * (1.f - t.x * t.x), a.y * (1.f - t.y * t.y),
-                                                         a.z * (1.f - t.z * t.z), a.w * (1.f - t.w * t.w));
+        const float4 r = make_float4(a.x * (1.f - t.x * t.x), a.y * (1.f - t.y * t.y), a.z * (1.f - t.z * t.z), a.w * (1.f - t.w * t.w));
+        reinterpret_cast<float4 *>(out)[i] = r;
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
     }
+    if (out_amax) lvt_block_amax_commit(am, out_amax, amax_scratch);
 }
-extern "C" int lvt_tanh_bwd(const float *g, const float *y, long long n, float *out, void *stream) {
+extern "C" int lvt_tanh_bwd(const float *g, const float *y, long long n, float *out, float *out_amax, void *stream) {
     LVT_REQUIRE(g && y && out && n > 0 && n % 4 == 0, "tanh_bwd: bad args");
-    hipLaunchKernelGGL(lvt_tanh_bwd_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, g, y,
-                       n / 4, out);
+    hipLaunchKernelGGL(lvt_tanh_bwd_kernel, dim3(grid_for(n / 4, 256, out_amax ? 2048 : 8192)), dim3(256), 0, (hipStream_t)stream, g, y,
+                       n / 4, out, out_amax);
     LVT_CHECK_LAUNCH("lvt_tanh_bwd_kernel");
     return LVT_OK;
 }
@@ -229,9 +241,11 @@ extern "C" int lvt_add_periodic(float *x, const float *table, long long rows, in
 __global__ void lvt_layernorm_fwd_kernel(const float *__restrict__ x, long long rows, int d, float eps,
                                          const float *__restrict__ w, const float *__restrict__ b,
                                          float *__restrict__ y, float *__restrict__ mean_out,
-                                         float *__restrict__ rstd_out) {
+                                         float *__restrict__ rstd_out, float *__restrict__ y_amax) {
+    __shared__ float amax_scratch[4];
     const int lane = threadIdx.x & 63;
     const int d4 = d / 4;
+    float am = 0.f;
     for (long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < rows;
          row += ((long long)gridDim.x * blockDim.x) >> 6) {
         const float4 *xp = reinterpret_cast<const float4 *>(x + row * d);
@@ -264,16 +278,18 @@ __global__ void lvt_layernorm_fwd_kernel(const float *__restrict__ x, long long 
                 o.x = (v[i].x - mean) * rstd * ww.x + bb.x; o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
                 o.z = (v[i].z - mean) * rstd * ww.z + bb.z; o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
                 yp[c] = o;
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
             }
         }
         if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
     }
+    if (y_amax) lvt_block_amax_commit(am, y_amax, amax_scratch);
 }
 extern "C" int lvt_layernorm_fwd(const float *x, long long rows, int d, float eps, const float *w, const float *b,
-                                 float *y, float *mean, float *rstd, void *stream) {
+                                 float *y, float *mean, float *rstd, float *y_amax, void *stream) {
     LVT_REQUIRE(x && w && b && y && rows > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "layernorm_fwd: bad args (d=%d)", d);
-    hipLaunchKernelGGL(lvt_layernorm_fwd_kernel, dim3(grid_for(rows, 4, 16384)), dim3(256), 0, (hipStream_t)stream,
-                       x, rows, d, eps, w, b, y, mean, rstd);
+    hipLaunchKernelGGL(lvt_layernorm_fwd_kernel, dim3(grid_for(rows, 4, y_amax ? 2048 : 16384)), dim3(256), 0, (hipStream_t)stream,
+                       x, rows, d, eps, w, b, y, mean, rstd, y_amax);
     LVT_CHECK_LAUNCH("lvt_layernorm_fwd_kernel");
     return LVT_OK;
 }
@@ -283,7 +299,9 @@ extern "C" int lvt_layernorm_fwd(const float *x, long long rows, int d, float ep
 __global__ __launch_bounds__(256) void lvt_layernorm_bwd_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ mean,
     const float *__restrict__ rstd, const float *__restrict__ w, long long rows, int d, const float *__restrict__ add,
-    float *__restrict__ dx, float *__restrict__ pdw, float *__restrict__ pdb) {
+    float *__restrict__ dx, float *__restrict__ pdw, float *__restrict__ pdb, float *__restrict__ dx_amax) {
+    __shared__ float amax_scratch[4];
+    float am = 0.f;
     __shared__ float sdw[4][256 * LN_MAXV];   // per-wave column partials, combined in wave order
     __shared__ float sdb[4][256 * LN_MAXV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -327,9 +345,11 @@ __global__ __launch_bounds__(256) void lvt_layernorm_bwd_kernel(
                     o.x += z.x; o.y += z.y; o.z += z.z; o.w += z.w;
                 }
                 op[c] = o;
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
             }
         }
     }
+    if (dx_amax) lvt_block_amax_commit(am, dx_amax, amax_scratch);
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
         const int c = lane + 64 * i;
@@ -375,7 +395,7 @@ __global__ __launch_bounds__(256) void lvt_rowsum_partials_kernel(const float *_
 extern "C" size_t lvt_layernorm_bwd_workspace_bytes(int d) { return (size_t)2 * LN_BWD_BLOCKS * d * sizeof(float); }
 extern "C" int lvt_layernorm_bwd(const float *dy, const float *x, const float *mean, const float *rstd,
                                  const float *w, long long rows, int d, const float *add, float *dx, float *dw,
-                                 float *db, void *workspace, size_t workspace_bytes, void *stream) {
+                                 float *db, float *dx_amax, void *workspace, size_t workspace_bytes, void *stream) {
     LVT_REQUIRE(dy && x && mean && rstd && w && dx && dw && db && rows > 0 && d % 4 == 0 && d <= 256 * LN_MAXV,
                 "layernorm_bwd: bad args");
     LVT_REQUIRE(workspace && workspace_bytes >= lvt_layernorm_bwd_workspace_bytes(d), "layernorm_bwd: workspace");
@@ -385,7 +405,7 @@ extern "C" int lvt_layernorm_bwd(const float *dy, const float *x, const float *m
     blocks = (int)lvt_cdiv(rows, rpb);
     float *pdw = (float *)workspace, *pdb = pdw + (size_t)LN_BWD_BLOCKS * d;
     hipLaunchKernelGGL(lvt_layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, s, dy, x, mean, rstd, w, rows, d, add,
-                       dx, pdw, pdb);
+                       dx, pdw, pdb, dx_amax);
     LVT_CHECK_LAUNCH("lvt_layernorm_bwd_kernel");
     hipLaunchKernelGGL(lvt_rowsum_partials_kernel, dim3((d + 7) / 8, 2), dim3(256), 0, s, (const float *)pdw, (const float *)pdb,
                        blocks, d, dw, db);
@@ -487,5 +507,87 @@ extern "C" int lvt_row_gather(const float *x, const long long *perm, long long B
     const int blocks = (int)(lvt_cdiv(total, 256) < 8192 ? lvt_cdiv(total, 256) : 8192);
     hipLaunchKernelGGL(lvt_row_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, perm, B, S, d / 4, out);
     LVT_CHECK_LAUNCH("lvt_row_gather_kernel");
+    return LVT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// max |x| of a tensor into a device scalar (LVT_MATH_F16X2 operand scales for tensors that no engine launch
+// produced): *out = max(*out, max |x|).  Non-negative floats order like their bit patterns, so the cross-workgroup
+// step is an INTEGER atomic max -- exact and order-independent (the library has no floating-point atomics).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lvt_amax_kernel(const float *__restrict__ x, long long n, float *__restrict__ out) {
+    __shared__ float scratch[4];
+    const long long n4 = n >> 2;
+    float m = 0.f;
+    if ((((uintptr_t)x) & 15) == 0) {
+        float m1 = 0.f;                  // two independent chains: the loads of a thread do not wait on one fmax
+        long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const long long step = (long long)gridDim.x * blockDim.x;
+        for (; i + step < n4; i += 2 * step) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + i * 4), u = *reinterpret_cast<const float4 *>(x + (i + step) * 4);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fmaxf(fabsf(u.z), fabsf(u.w))));
+        }
+        if (i < n4) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + i * 4);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        m = fmaxf(m, m1);
+        for (long long t = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += step) m = fmaxf(m, fabsf(x[t]));
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+            m = fmaxf(m, fabsf(x[i]));
+    }
+    // (fmaxf drops a NaN; that is fine here: a NaN element poisons the product through its own hi plane)
+    lvt_block_amax_commit(m, out, scratch);
+}
+// the same for up to 64 tensors per launch (the weights of a model, once per pass): blockIdx.y = tensor
+struct AmaxTable { const float *x[64]; long long n[64]; float *out[64]; };
+__global__ __launch_bounds__(256) void lvt_amax_multi_kernel(const AmaxTable t) {
+    __shared__ float scratch[4];
+    const float *x = t.x[blockIdx.y];
+    const long long n = t.n[blockIdx.y], n4 = (((uintptr_t)x) & 15) == 0 ? n >> 2 : 0;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = *reinterpret_cast<const float4 *>(x + i * 4);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(x[i]));
+    lvt_block_amax_commit(m, t.out[blockIdx.y], scratch);
+}
+extern "C" int lvt_amax_multi(const lvt_amax_entry *entries, int n, void *stream) {
+    LVT_REQUIRE(entries && n > 0, "amax_multi: bad args");
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = n - base < 64 ? n - base : 64;
+        AmaxTable t;
+        long long biggest = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const lvt_amax_entry &e = entries[base + i];
+            LVT_REQUIRE(e.x && e.out && e.n > 0, "amax_multi: bad entry %d", base + i);
+            t.x[i] = e.x; t.n[i] = e.n; t.out[i] = e.out;
+            if (e.n > biggest) biggest = e.n;
+        }
+        hipLaunchKernelGGL(lvt_amax_multi_kernel, dim3(grid_for(biggest / 4 + 1, 256 * 4, 64), cnt), dim3(256), 0, (hipStream_t)stream, t);
+        LVT_CHECK_LAUNCH("lvt_amax_multi_kernel");
+    }
+    return LVT_OK;
+}
+// *out = max(*out, *a, *b): the bound of a launch whose operand spans two tensors (b may be NULL)
+__global__ void lvt_amax_merge_kernel(const float *a, const float *b, float *out) {
+    float m = fmaxf(*out, *a);
+    if (b) m = fmaxf(m, *b);
+    *out = m;
+}
+extern "C" int lvt_amax_merge(const float *a, const float *b, float *out, void *stream) {
+    LVT_REQUIRE(a && out, "amax_merge: bad args");
+    hipLaunchKernelGGL(lvt_amax_merge_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a, b, out);
+    LVT_CHECK_LAUNCH("lvt_amax_merge_kernel");
+    return LVT_OK;
+}
+extern "C" int lvt_amax(const float *x, long long n, float *out, void *stream) {
+    LVT_REQUIRE(x && out && n > 0, "amax: bad args");
+    hipLaunchKernelGGL(lvt_amax_kernel, dim3(grid_for(n / 4 + 1, 256 * 8, 1024)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    LVT_CHECK_LAUNCH("lvt_amax_kernel");
     return LVT_OK;
 }

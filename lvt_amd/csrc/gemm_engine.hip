@@ -49,6 +49,8 @@ struct KParams {
     int splits; int k_per_split; float *partial; long long partial_stride;
     int vec_epi;             // C / res / mask / partial rows are 16-byte aligned and N % 4 == 0: float4 epilogue
     float *colsum_partial;   // bwd-weight: [splits][N] column sums of B (= bias gradient), written by the m0 == 0 tiles
+    const float *a_amax, *b_amax;   // f16x2 arithmetic: device scalars >= max |A|, max |B| (NULL: the operand is used unscaled)
+    float *c_amax;                  // any arithmetic: when non-NULL, max |C| is folded in (integer atomic max on the bit pattern)
     lvt_conv_geom g;
     int Tq, Hq, Wq;          // A_CONVT_K: per-phase output extents
     int jT, jH, jW;          // A_CONVT_K: taps per phase and dimension
@@ -119,6 +121,67 @@ template <int ROWS> __device__ __forceinline__ void store_split_block(unsigned s
 }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// ---- f16x2 split (LVT_MATH_F16X2): a * s = hi + 2^-11 * lo with two fp16 terms.  s is an exact power of two taken from the
+// operand's max |a| (lvt_f16_scale: max |a| * s in [2^14, 2^15), so hi never overflows), hi = RN16(a s), the residual
+// a s - hi is exact in fp32 and lo = RN16(2^11 (a s - hi)) keeps it to 2^-23 |a| -- both planes live in the same binades,
+// so the full 22 + sign bits hold for every element down to 2^-27 max |a| and degrade gradually below that.  A block is
+// three v_mfma_f32_32x32x16_f16: hi hi into one accumulator, hi lo + lo hi into a second one that is added with weight 2^-11
+// at the end (dropped: lo lo <= 2^-22 |a||b| worst case, 2^-24.6 rms -- the size of one fp32 rounding).
+// v_fma_mix{lo,hi}_f16 round (x * y + z) ONCE to fp16 into one half of the destination; v_fma_mix_f32 reads an fp16 half.
+__device__ __forceinline__ unsigned f16_pair(float a, float b, float s) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0\n\tv_fma_mixhi_f16 %0, %3, %2, 0" : "=&v"(r) : "v"(a), "v"(s), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float f16_resid_lo(float a, float s, unsigned h) {      // a * s - half(h.lo), exact
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(s), "v"(h));
+    return r;
+}
+__device__ __forceinline__ float f16_resid_hi(float a, float s, unsigned h) {      // a * s - half(h.hi), exact
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(s), "v"(h));
+    return r;
+}
+__device__ __forceinline__ void split2(const float4 v, const float s, uint2 &ph, uint2 &pl) {
+    ph.x = f16_pair(v.x, v.y, s); ph.y = f16_pair(v.z, v.w, s);
+    pl.x = f16_pair(f16_resid_lo(v.x, s, ph.x), f16_resid_hi(v.y, s, ph.x), 2048.f);
+    pl.y = f16_pair(f16_resid_lo(v.z, s, ph.y), f16_resid_hi(v.w, s, ph.y), 2048.f);
+}
+// power-of-two scale of an operand from its max |a| (a device scalar; any upper bound works, a loose one costs range):
+// returns s = 2^e with max * s in [2^14, 2^15) and adds -e to `unscale` (the exponent that undoes it on the result).
+__device__ __forceinline__ float lvt_f16_scale(const float *amax, int &unscale) {
+    if (!amax) return 1.f;
+    const int eb = (int)((__float_as_uint(*amax) >> 23) & 0xffu);                    // biased exponent (255: inf / nan propagate)
+    int se = 268 - eb;                                                               // 127 + 14 - (eb - 127)
+    se = se < 2 ? 2 : (se > 252 ? 252 : se);
+    unscale -= se - 127;
+    return __uint_as_float((unsigned)se << 23);
+}
+template <int ROWS> __device__ __forceinline__ void store_split2_k(unsigned short *lds, int row, int k4, const float4 v, float s) {
+    uint2 ph, pl;
+    split2(v, s, ph, pl);
+    unsigned short *d = lds + hrow<ROWS>(row) + k4;
+    *reinterpret_cast<uint2 *>(d) = ph;
+    *reinterpret_cast<uint2 *>(d + HPlane<ROWS>::SIZE) = pl;
+}
+template <int ROWS> __device__ __forceinline__ void store_split2_m(unsigned short *lds, int row4, int k, const float4 v, float s) {
+    uint2 p[2];
+    split2(v, s, p[0], p[1]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        unsigned short *d = lds + q * HPlane<ROWS>::SIZE + k;
+        d[hrow<ROWS>(row4)] = (unsigned short)(p[q].x & 0xffffu); d[hrow<ROWS>(row4 + 1)] = (unsigned short)(p[q].x >> 16);
+        d[hrow<ROWS>(row4 + 2)] = (unsigned short)(p[q].y & 0xffffu); d[hrow<ROWS>(row4 + 3)] = (unsigned short)(p[q].y >> 16);
+    }
+}
+template <int ROWS> __device__ __forceinline__ void store_split2_block(unsigned short *lds, int row4, int k4, const float4 *v, float s) {
+    store_split2_k<ROWS>(lds, row4 + 0, k4, make_float4(v[0].x, v[1].x, v[2].x, v[3].x), s);
+    store_split2_k<ROWS>(lds, row4 + 1, k4, make_float4(v[0].y, v[1].y, v[2].y, v[3].y), s);
+    store_split2_k<ROWS>(lds, row4 + 2, k4, make_float4(v[0].z, v[1].z, v[2].z, v[3].z), s);
+    store_split2_k<ROWS>(lds, row4 + 3, k4, make_float4(v[0].w, v[1].w, v[2].w, v[3].w), s);
+}
+
 // Mixed-radix digits of a running GEMM-k index, k = ((t*nH + h)*nW + w)*nC + c.  Every loader decodes its
 // k position ONCE (seek, with integer divisions) and then steps it tile by tile with compares only: the main
 // loop is issue-bound (measured 10.6 VALU instructions per MFMA before this), and the three signed divisions
@@ -167,6 +230,10 @@ template <int MODE, int BM> struct AKLoaderBase {
     __device__ __forceinline__ void store_split(unsigned short *lds) const {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) store_split_k<BM>(lds, r0 + RPP * i, kq * 4, v[i]);
+    }
+    __device__ __forceinline__ void store_split2(unsigned short *lds, float s) const {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) store_split2_k<BM>(lds, r0 + RPP * i, kq * 4, v[i], s);
     }
 };
 
@@ -313,6 +380,11 @@ template <int BM, int MATH> struct AMLoaderBase {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) store_split_m<BM>(lds, mq * 4, kk0 * KMUL + KSTEP * i, v[i]);
     }
+    __device__ __forceinline__ void store_split2(unsigned short *lds, float s) const {
+        if (ITERS == 4) { store_split2_block<BM>(lds, mq * 4, kk0 * 4, v, s); return; }
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) store_split2_m<BM>(lds, mq * 4, kk0 * KMUL + KSTEP * i, v[i], s);
+    }
 };
 
 template <int BM, int MATH> struct ALoader<A_MPLAIN, BM, MATH> : AMLoaderBase<BM, MATH> {
@@ -448,6 +520,11 @@ template <int BN> struct BKLoaderBase {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) store_split_k<BN>(lds, r0 + RPP * i, kq * 4, v[i]);
     }
+    __device__ __forceinline__ void store_split2(unsigned short *lds, float s) const {
+        if (r0 >= BN) return;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) store_split2_k<BN>(lds, r0 + RPP * i, kq * 4, v[i], s);
+    }
 };
 
 template <int BN, int MATH> struct BLoader<B_KPLAIN, BN, MATH> : BKLoaderBase<BN> {
@@ -567,12 +644,19 @@ template <int BN, int MATH> struct BLoader<B_NPLAIN, BN, MATH> {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) store_split_m<BN>(lds, nq * 4, kk0 * KMUL + KSTEP * i, v[i]);
     }
+    __device__ __forceinline__ void store_split2(unsigned short *lds, float s) const {
+        if (!active) return;
+        if (ITERS == 4) { store_split2_block<BN>(lds, nq * 4, kk0 * 4, v, s); return; }
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) store_split2_m<BN>(lds, nq * 4, kk0 * KMUL + KSTEP * i, v[i], s);
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // A_PATCH (frame-resident 3x3 convolution, below): GEMM row r of a 256-row frame tile is NOT pixel r.  The 32 rows of an
 // MFMA tile t32 are the pixels of image rows 2*t32 and 2*t32+1, lane quad q (4 consecutive lanes) holding 4 consecutive
@@ -610,6 +694,7 @@ __device__ __forceinline__ void lvt_epilogue(const KParams &p, f32x16 (&acc)[BM 
         rw = ((fw - g.pw) % g.sw + g.sw) % g.sw;
     }
     const int flags = p.flags;
+    float am = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -646,8 +731,13 @@ __device__ __forceinline__ void lvt_epilogue(const KParams &p, f32x16 (&acc)[BM 
                 float *cp = p.C + coff + orow * p.ldc + col;
                 if (flags & LVT_EPI_ACCUM) v += *cp;
                 *cp = v;
+                am = fmaxf(am, fabsf(v));
             }
         }
+    }
+    if (p.c_amax && p.splits <= 1) {
+        __shared__ float amax_scratch[NTHREADS / 64];
+        lvt_block_amax_commit(am, p.c_amax, amax_scratch);
     }
 }
 
@@ -726,6 +816,7 @@ __device__ __forceinline__ void lvt_epilogue_vec(const KParams &p, f32x16 (&acc)
         rw = ((fw - g.pw) % g.sw + g.sw) % g.sw;
     }
     const int flags = p.flags;
+    float am = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -764,6 +855,7 @@ __device__ __forceinline__ void lvt_epilogue_vec(const KParams &p, f32x16 (&acc)
                         const float4 mk = ldg4(p.mask + coff + orow * p.ldm + col);
                         v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
                     }
+                    if (!(flags & LVT_EPI_ACCUM)) am = fmaxf(am, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
                     if (flags & LVT_EPI_PLANES) {
                         // C is a bf16 image: the result leaves as its exact 3-way bf16 split, one plane c_plane elements
                         // after the other (the operand format of the fused attention kernels, attention_pipe.hip)
@@ -775,7 +867,10 @@ __device__ __forceinline__ void lvt_epilogue_vec(const KParams &p, f32x16 (&acc)
                         *reinterpret_cast<uint2 *>(cp + 2 * p.c_plane) = p3;
                     } else {
                         float4 *cp = reinterpret_cast<float4 *>(p.C + coff + orow * p.ldc + col);
-                        if (flags & LVT_EPI_ACCUM) { const float4 c = *cp; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+                        if (flags & LVT_EPI_ACCUM) {
+                            const float4 c = *cp; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
+                            am = fmaxf(am, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                        }
                         *cp = v;
                     }
                 }
@@ -783,27 +878,31 @@ __device__ __forceinline__ void lvt_epilogue_vec(const KParams &p, f32x16 (&acc)
         }
         __syncthreads();
     }
+    if (p.c_amax && p.splits <= 1) lvt_block_amax_commit(am, p.c_amax, lds);      // (the turn-table is free again)
 }
 
 // MATH == 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
 // MATH == 1: bf16x3 split -- every fp32 operand is staged as three bf16 planes and each 32x32x16 block is six
 //            v_mfma_f32_32x32x16_bf16 (a1b1, a1b2, a2b1, a1b3, a3b1, a2b2: all product terms above 2^-24 |ab|,
 //            each bf16 x bf16 product exact in the fp32 accumulator).  fp32-class accuracy at ~2.7x the rate.
+// MATH == 2: f16x2 split -- two fp16 planes per operand after an exact power-of-two scale from the operand's max |.|
+//            (split2 above), three v_mfma_f32_32x32x16_f16 per block into two accumulators.  Half the MFMAs of MATH == 1.
 template <int AMODE, int BMODE, int BM, int BN, int WM, int WN, int MATH>
-__global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const KParams p) {
+__global__ __launch_bounds__(NTHREADS, (MATH == 2 ? 2 : LVT_MINWAVES)) void lvt_gemm_kernel(const KParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     using AL = ALoader<AMODE, BM, MATH>;
     using BL = BLoader<BMODE, BN, MATH>;
     constexpr int LDA = AL::LD, LDB = BL::LD;
     constexpr int PSA = HPlane<BM>::SIZE, PSB = HPlane<BN>::SIZE;                       // bf16 plane strides (MATH == 1)
-    constexpr int STAGE_FLOATS = MATH == 0 ? (BK * LDA + BK * LDB + 8) : (3 * (PSA + PSB) / 2 + 8);
+    constexpr int NP = MATH == 2 ? 2 : 3;                                               // 16-bit planes per operand
+    constexpr int STAGE_FLOATS = MATH == 0 ? (BK * LDA + BK * LDB + 8) : (NP * (PSA + PSB) / 2 + 8);
     constexpr int TURN_FLOATS = WM * WN * 32 * (TN * 32);             // epilogue turn-table: 32 rows of every wave's sub-tile
     constexpr int LDS_FLOATS = STAGE_FLOATS > TURN_FLOATS ? STAGE_FLOATS : TURN_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float *As = lds;
     float *Bs = lds + ((BK * LDA + 3) & ~3);
     unsigned short *Ah = reinterpret_cast<unsigned short *>(lds);
-    unsigned short *Bh = Ah + 3 * PSA;
+    unsigned short *Bh = Ah + NP * PSA;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -820,12 +919,19 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
     bl.init(p, tid, n0, B, cls);
 
     f32x16 acc[TM][TN];
+    f32x16 acx[MATH == 2 ? TM : 1][MATH == 2 ? TN : 1];      // f16x2: the hi lo + lo hi terms (weight 2^-11)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if (MATH == 2) acx[i][j][r] = 0.f;
+            }
+    int unscale = 0;
+    float sa = 1.f, sb = 1.f;
+    if (MATH == 2) { sa = lvt_f16_scale(p.a_amax, unscale); sb = lvt_f16_scale(p.b_amax, unscale); }
 
     constexpr bool COLSUM = (AMODE == A_CONV_M && BMODE == B_NPLAIN);
     constexpr bool COLSUM_A = (AMODE == A_MPLAIN);
@@ -835,7 +941,8 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
         al.seek(kbeg); bl.seek(kbeg);
         al.fetch(kend); bl.fetch(kend);
         if (MATH == 0) { al.store(As); bl.store(Bs); }
-        else { al.store_split(Ah); bl.store_split(Bh); }
+        else if (MATH == 1) { al.store_split(Ah); bl.store_split(Bh); }
+        else { al.store_split2(Ah, sa); bl.store_split2(Bh, sb); }
     }
     __syncthreads();
 
@@ -872,6 +979,39 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
                 __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);   // DS reads
                 __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                       // MFMAs
             }
+        } else if (MATH == 2) {
+            const unsigned short *Arh[TM], *Brh[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) Arh[i] = Ah + hrow<BM>(wm * (TM * 32) + i * 32 + l31) + 8 * half;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) Brh[j] = Bh + hrow<BN>(wn * (TN * 32) + j * 32 + l31) + 8 * half;
+#pragma unroll
+            for (int ks = 0; ks < BK; ks += 16) {
+                f16x8 a[2][TM], b[2][TN];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const f16x8 *>(Arh[i] + q * PSA + ks);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const f16x8 *>(Brh[j] + q * PSB + ks);
+                }
+                // three passes over the TM x TN accumulator pairs: consecutive MFMAs never share an accumulator
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1][j], acx[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0][j], acx[i][j], 0, 0, 0);
+            }
         } else {
             // lane l feeds row (l & 31) and the 8 consecutive k starting at 8 * (l >> 5) of each 16-wide k step
             const unsigned short *Arh[TM], *Brh[TN];
@@ -906,9 +1046,19 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
         __syncthreads();
         if (has_next) {
             if (MATH == 0) { al.store(As); bl.store(Bs); }
-            else { al.store_split(Ah); bl.store_split(Bh); }
+            else if (MATH == 1) { al.store_split(Ah); bl.store_split(Bh); }
+            else { al.store_split2(Ah, sa); bl.store_split2(Bh, sb); }
         }
         __syncthreads();
+    }
+    if constexpr (MATH == 2) {
+        // result = (hi hi + 2^-11 (hi lo + lo hi)) / (sa sb): one fma and one exact exponent shift per element
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = ldexpf(fmaf(acx[i][j][r], 1.f / 2048.f, acc[i][j][r]), unscale);
     }
 
     if constexpr (COLSUM) {
@@ -945,18 +1095,23 @@ __global__ __launch_bounds__(NTHREADS, LVT_MINWAVES) void lvt_gemm_kernel(const 
 //         a 17x17 sub-image on which the class is a 2x2 / stride 1 convolution.  The "patch" is that sub-image, re-staged per
 //         (chunk, class): one staging per four tap steps.  Weights packed [class][tap][Cin][Cout]
 //         (lvt_conv3d_pack_weight_parity).
-template <int MODE>
+// MATH: 1 = bf16x3 planes (six MFMAs per block), 2 = f16x2 planes (three, two accumulators; lvt_gemm_kernel above).
+template <int MODE, int MATH>
 __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParams p) {
     constexpr int BM = 256, BN = 128, WM = 4, WN = 2, TM = 2, TN = 2;
     constexpr int NTAPS = MODE == 0 ? 9 : 4;
+    constexpr int NP = MATH == 2 ? 2 : 3;
     constexpr int PSB = HPlane<BN>::SIZE;
-    constexpr int A_BYTES = 3 * PT_PLANE * 2, B_BYTES = 3 * PSB * 2;
+    constexpr int A_BYTES = NP * PT_PLANE * 2, B_BYTES = NP * PSB * 2;
     constexpr int STAGE_FLOATS = (A_BYTES + 2 * B_BYTES) / 4 + 8;
     constexpr int TURN_FLOATS = WM * WN * 32 * (TN * 32);
     constexpr int LDS_FLOATS = STAGE_FLOATS > TURN_FLOATS ? STAGE_FLOATS : TURN_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     unsigned short *Ah = reinterpret_cast<unsigned short *>(lds);
-    unsigned short *Bh0 = Ah + 3 * PT_PLANE;
+    unsigned short *Bh0 = Ah + NP * PT_PLANE;
+    int unscale = 0;
+    float sa = 1.f, sb = 1.f;
+    if (MATH == 2) { sa = lvt_f16_scale(p.a_amax, unscale); sb = lvt_f16_scale(p.b_amax, unscale); }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -999,12 +1154,19 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
         for (int j = 0; j < PPASS; ++j) {
             const int u = tid + PT_THREADS * j;
             if (u < PUNITS) {
-                uint2 p1, p2, p3;
-                split3(pv[j], p1, p2, p3);
                 unsigned short *d = Ah + (u >> 3) * HLD + (u & 7) * 4;
-                *reinterpret_cast<uint2 *>(d) = p1;
-                *reinterpret_cast<uint2 *>(d + PT_PLANE) = p2;
-                *reinterpret_cast<uint2 *>(d + 2 * PT_PLANE) = p3;
+                if (MATH == 2) {
+                    uint2 ph, pl;
+                    split2(pv[j], sa, ph, pl);
+                    *reinterpret_cast<uint2 *>(d) = ph;
+                    *reinterpret_cast<uint2 *>(d + PT_PLANE) = pl;
+                } else {
+                    uint2 p1, p2, p3;
+                    split3(pv[j], p1, p2, p3);
+                    *reinterpret_cast<uint2 *>(d) = p1;
+                    *reinterpret_cast<uint2 *>(d + PT_PLANE) = p2;
+                    *reinterpret_cast<uint2 *>(d + 2 * PT_PLANE) = p3;
+                }
             }
         }
     };
@@ -1024,12 +1186,20 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
     };
 
     f32x16 acc[TM][TN];
+    f32x16 acx[MATH == 2 ? TM : 1][MATH == 2 ? TN : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if (MATH == 2) acx[i][j][r] = 0.f;
+            }
+    auto b_store = [&](unsigned short *dst) {
+        if (MATH == 2) store_split2_block<BN>(dst, bnq * 4, bkk0 * 4, bv, sb);
+        else store_split_block<BN>(dst, bnq * 4, bkk0 * 4, bv);
+    };
 
     // A operand rows of this lane: MFMA tile i of the wave covers image rows 2*(2*wm + i) + {0, 1}
     int arow[TM];
@@ -1047,7 +1217,7 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
     patch_fetch(0);
     if (bact) b_fetch(0);
     patch_store();
-    if (bact) store_split_block<BN>(Bh0, bnq * 4, bkk0 * 4, bv);
+    if (bact) b_store(Bh0);
     __syncthreads();
 
     for (int step = 0; step < nsteps; ++step) {
@@ -1056,35 +1226,72 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
         const bool new_chunk = has_next && tap == NTAPS - 1;
         if (has_next && bact) b_fetch(step + 1);
         if (new_chunk) patch_fetch(cc + 1);
-        const unsigned short *Bh = Bh0 + (step & 1) * (3 * PSB);
+        const unsigned short *Bh = Bh0 + (step & 1) * (NP * PSB);
         const unsigned short *Ap = MODE == 0 ? Ah + ((tap / 3) * PT_PW + (tap % 3)) * HLD
                                              : Ah + (((phase >> 1) + (tap >> 1)) * PT_PW + (phase & 1) + (tap & 1)) * HLD;   // (phase 0 in MODE 2)
+        if constexpr (MATH == 2) {
 #pragma unroll
-        for (int ks = 0; ks < BK; ks += 16) {
-            bf16x8 a[3][TM], b[3][TN];
+            for (int ks = 0; ks < BK; ks += 16) {
+                f16x8 a[2][TM], b[2][TN];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < 2; ++q) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const bf16x8 *>(Ap + arow[i] + q * PT_PLANE + ks);
+                    for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const f16x8 *>(Ap + arow[i] + q * PT_PLANE + ks);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const bf16x8 *>(Bh + brow[j] + q * PSB + ks);
-            }
-            constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
+                    for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const f16x8 *>(Bh + brow[j] + q * PSB + ks);
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]][i], b[TB[t]][j], acc[i][j], 0, 0, 0);
+                        acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1][j], acx[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0][j], acx[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < BK; ks += 16) {
+                bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const bf16x8 *>(Ap + arow[i] + q * PT_PLANE + ks);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const bf16x8 *>(Bh + brow[j] + q * PSB + ks);
+                }
+                constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]][i], b[TB[t]][j], acc[i][j], 0, 0, 0);
+            }
         }
         // the other weight buffer was last read in the previous step, which every wave has left (barrier below)
-        if (has_next && bact) store_split_block<BN>(Bh0 + ((step + 1) & 1) * (3 * PSB), bnq * 4, bkk0 * 4, bv);
+        if (has_next && bact) b_store(Bh0 + ((step + 1) & 1) * (NP * PSB));
         if (new_chunk) {
             __syncthreads();              // every wave is done with the old patch
             patch_store();
         }
         __syncthreads();
+    }
+    if constexpr (MATH == 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = ldexpf(fmaf(acx[i][j][r], 1.f / 2048.f, acc[i][j][r]), unscale);
     }
     if (MODE != 1) lvt_epilogue_vec<A_PATCH, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, 0, 0, 0, 0);
     else lvt_epilogue_vec<A_PATCHT, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, phase, 0, 0, 0);
@@ -1291,7 +1498,14 @@ __global__ __launch_bounds__(CS_THREADS) void lvt_colsum_kernel(const float *__r
 // The arithmetic of a launch is chosen PER CALL by LVT_MATH_F32 in its `flags` (clear: bf16x3, the default; set: plain
 // fp32 MFMA): the library keeps no mutable state, so concurrent callers (the autograd thread runs the backward launches
 // of a forward issued from another thread) cannot influence each other.
-static inline int math_of(int flags) { return (flags & LVT_MATH_F32) ? 0 : 1; }
+static inline int math_of(int flags) { return (flags & LVT_MATH_F32) ? 0 : ((flags & LVT_MATH_F16X2) ? 2 : 1); }
+// f16x2 needs the operands' max |.| (device scalars, lvt_amax_io); outputs may report theirs in any mode
+static inline void set_amax(KParams &p, const lvt_amax_io *ax) {
+    if (ax) { p.a_amax = ax->a; p.b_amax = ax->b; p.c_amax = ax->c; }
+}
+#define LVT_REQUIRE_AMAX(flags, ax, who)                                                                              \
+    LVT_REQUIRE(math_of(flags) != 2 || ((ax) && (ax)->a && (ax)->b), "%s: LVT_MATH_F16X2 needs the operands' max |.| " \
+                "(lvt_amax_io.a / .b: device scalars, see lvt_amax)", who)
 
 template <int AMODE, int BMODE, int BM, int BN, int WM, int WN>
 static int launch_tile(const KParams &p, int zcount, hipStream_t s) {
@@ -1314,7 +1528,9 @@ static int launch_tile(const KParams &p, int zcount, hipStream_t s) {
         }
         pv.vec_epi = ok ? 1 : 0;
     }
-    if (math_of(p.flags) == 1 && BK == 32)
+    if (math_of(p.flags) == 2 && BK == 32)
+        hipLaunchKernelGGL((lvt_gemm_kernel<AMODE, BMODE, BM, BN, WM, WN, 2>), grid, dim3(NTHREADS), 0, s, pv);
+    else if (math_of(p.flags) == 1 && BK == 32)
         hipLaunchKernelGGL((lvt_gemm_kernel<AMODE, BMODE, BM, BN, WM, WN, 1>), grid, dim3(NTHREADS), 0, s, pv);
     else
         hipLaunchKernelGGL((lvt_gemm_kernel<AMODE, BMODE, BM, BN, WM, WN, 0>), grid, dim3(NTHREADS), 0, s, pv);
@@ -1346,6 +1562,7 @@ static void kparams_from_desc(const lvt_gemm_desc *d, KParams &p) {
     p.alpha = d->alpha; p.flags = d->flags; p.bias = d->bias; p.res = d->res; p.ldr = d->ldr;
     p.mask = d->mask; p.ldm = d->ldm;
     p.splits = d->splits > 1 ? d->splits : 1;
+    p.a_amax = d->a_amax; p.b_amax = d->b_amax; p.c_amax = d->c_amax;
 }
 
 static int gemm_batch(const lvt_gemm_desc *d) {
@@ -1371,6 +1588,8 @@ extern "C" int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t work
     LVT_REQUIRE(!(d->flags & LVT_EPI_BIAS) || d->bias, "gemm: BIAS flag without bias");
     LVT_REQUIRE(!(d->flags & LVT_EPI_RESIDUAL) || d->res, "gemm: RESIDUAL flag without res");
     LVT_REQUIRE(!(d->flags & LVT_EPI_MASK) || d->mask, "gemm: MASK flag without mask");
+    LVT_REQUIRE(math_of(d->flags) != 2 || (d->a_amax && d->b_amax), "gemm: LVT_MATH_F16X2 needs a_amax and b_amax");
+    LVT_REQUIRE(!d->c_amax || d->splits <= 1, "gemm: c_amax is not produced by split-K launches");
     if (d->flags & LVT_EPI_PLANES)
         LVT_REQUIRE(d->splits <= 1 && !(d->flags & LVT_EPI_ACCUM) && d->N % 4 == 0 && d->ldc % 4 == 0 && d->c_plane % 4 == 0 &&
                     d->sC_o % 4 == 0 && d->sC_i % 4 == 0 && lvt_aligned16(d->C) && !(d->flags & LVT_MATH_F32),
@@ -1379,7 +1598,7 @@ extern "C" int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t work
     KParams p; kparams_from_desc(d, p);
     const int zc = gemm_batch(d);
     if (p.splits > 1) {
-        LVT_REQUIRE((d->flags & ~(LVT_EPI_ACCUM | LVT_MATH_F32)) == 0 && d->alpha == 1.0f, "gemm: split-K allows only ACCUM");
+        LVT_REQUIRE((d->flags & ~(LVT_EPI_ACCUM | LVT_MATH_F32 | LVT_MATH_F16X2)) == 0 && d->alpha == 1.0f, "gemm: split-K allows only ACCUM");
         LVT_REQUIRE(d->ldc == d->N && (zc == 1 || (d->sC_i == (long long)d->M * d->N)),
                     "gemm: split-K needs a dense C (ldc == N)");
         LVT_REQUIRE(((long long)d->M * d->N) % 4 == 0 && lvt_aligned16(d->C), "gemm: split-K C alignment");
@@ -1462,7 +1681,7 @@ extern "C" int lvt_conv3d_pack_weight_t(const lvt_conv_geom *g, const float *w, 
 // the frame-resident kernel serves 3x3 / stride 1 / pad 1 convolutions of 16x16 frames with Ci % 32 == 0, Co % 128 == 0
 static bool patch_conv_eligible(const lvt_conv_geom *g, int flags) {
     static const int off = getenv("LVT_NO_PATCH_CONV") ? 1 : 0;
-    return !off && math_of(flags) == 1 && BK == 32 && g->Kt == 1 && g->Kh == 3 && g->Kw == 3 && g->st == 1 && g->sh == 1 &&
+    return !off && math_of(flags) >= 1 && BK == 32 && g->Kt == 1 && g->Kh == 3 && g->Kw == 3 && g->st == 1 && g->sh == 1 &&
            g->sw == 1 && g->pt == 0 && g->ph == 1 && g->pw == 1 && g->Ti == 1 && g->Hi == 16 && g->Wi == 16 && g->To == 1 &&
            g->Ho == 16 && g->Wo == 16 && g->Ci % 32 == 0 && g->Co % 128 == 0;
 }
@@ -1471,7 +1690,7 @@ extern "C" int lvt_conv3d_uses_patch_kernel(const lvt_conv_geom *g, int flags) {
 // 4x4 / stride 2 / pad 1 convolution 32x32 -> 16x16 on the frame-resident kernel (parity classes)
 static bool conv2x_eligible(const lvt_conv_geom *g, int flags) {
     static const int off = (getenv("LVT_NO_PATCH_CONV") || getenv("LVT_NO_PARITY_CONV")) ? 1 : 0;
-    return !off && math_of(flags) == 1 && BK == 32 && g->Kt == 1 && g->Kh == 4 && g->Kw == 4 && g->st == 1 && g->sh == 2 &&
+    return !off && math_of(flags) >= 1 && BK == 32 && g->Kt == 1 && g->Kh == 4 && g->Kw == 4 && g->st == 1 && g->sh == 2 &&
            g->sw == 2 && g->pt == 0 && g->ph == 1 && g->pw == 1 && g->Ti == 1 && g->Hi == 32 && g->Wi == 32 && g->To == 1 &&
            g->Ho == 16 && g->Wo == 16 && g->Ci % 32 == 0 && g->Co % 128 == 0;
 }
@@ -1488,7 +1707,8 @@ extern "C" int lvt_conv3d_pack_weight_parity(const lvt_conv_geom *g, const float
     return LVT_OK;
 }
 extern "C" int lvt_conv3d_fwd_parity(const lvt_conv_geom *g, const float *x, const float *wq, const float *bias,
-                                     const float *res, const float *mask, float *y, int flags, void *stream) {
+                                     const float *res, const float *mask, float *y, int flags, const lvt_amax_io *ax,
+                                     void *stream) {
     int rc = check_geom(g, "conv3d_fwd_parity"); if (rc) return rc;
     LVT_REQUIRE(x && wq && y, "conv3d_fwd_parity: null pointer");
     LVT_REQUIRE(conv2x_eligible(g, flags), "conv3d_fwd_parity: geometry not served (see lvt_conv3d_fwd_uses_parity_kernel)");
@@ -1503,14 +1723,19 @@ extern "C" int lvt_conv3d_fwd_parity(const lvt_conv_geom *g, const float *x, con
     p.A = x; p.B = wq; p.ldb = g->Co; p.C = y; p.ldc = g->Co; p.batch_inner = 1;
     p.alpha = 1.f; p.flags = flags; p.bias = bias; p.res = res; p.ldr = g->Co; p.mask = mask; p.ldm = g->Co;
     p.splits = 1; p.vec_epi = 1; p.g = *g;
-    hipLaunchKernelGGL(lvt_conv_patch_kernel<2>, dim3((unsigned)(g->N * (g->Co / 128))), dim3(PT_THREADS), 0,
-                       (hipStream_t)stream, p);
+    LVT_REQUIRE_AMAX(flags, ax, "conv3d_fwd_parity"); set_amax(p, ax);
+    if (math_of(flags) == 2)
+        hipLaunchKernelGGL((lvt_conv_patch_kernel<2, 2>), dim3((unsigned)(g->N * (g->Co / 128))), dim3(PT_THREADS), 0,
+                           (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((lvt_conv_patch_kernel<2, 1>), dim3((unsigned)(g->N * (g->Co / 128))), dim3(PT_THREADS), 0,
+                           (hipStream_t)stream, p);
     LVT_CHECK_LAUNCH("lvt_conv_patch_kernel<2>");
     return LVT_OK;
 }
 
 extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias,
-                              const float *res, const float *mask, float *y, int flags, void *stream) {
+                              const float *res, const float *mask, float *y, int flags, const lvt_amax_io *ax, void *stream) {
     int rc = check_geom(g, "conv3d_fwd"); if (rc) return rc;
     LVT_REQUIRE(x && wp && y, "conv3d_fwd: null pointer");
     LVT_REQUIRE(!(flags & LVT_EPI_BIAS) || bias, "conv3d_fwd: BIAS without bias");
@@ -1524,6 +1749,7 @@ extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const floa
     p.A = x; p.B = wp; p.ldb = g->Co; p.C = y; p.ldc = g->Co; p.batch_inner = 1;
     p.alpha = 1.f; p.flags = flags; p.bias = bias; p.res = res; p.ldr = g->Co; p.mask = mask; p.ldm = g->Co;
     p.splits = 1; p.g = *g;
+    LVT_REQUIRE_AMAX(flags, ax, "conv3d_fwd"); set_amax(p, ax);
     {
         auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
         bool ok = patch_conv_eligible(g, flags) && al16(x) && al16(wp) && al16(y);
@@ -1532,8 +1758,12 @@ extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const floa
         if (flags & LVT_EPI_MASK) ok = ok && al16(mask);
         if (ok) {
             p.vec_epi = 1;
-            hipLaunchKernelGGL(lvt_conv_patch_kernel<0>, dim3((unsigned)(g->N * (g->Co / 128))), dim3(PT_THREADS), 0,
-                               (hipStream_t)stream, p);
+            if (math_of(flags) == 2)
+                hipLaunchKernelGGL((lvt_conv_patch_kernel<0, 2>), dim3((unsigned)(g->N * (g->Co / 128))), dim3(PT_THREADS), 0,
+                                   (hipStream_t)stream, p);
+            else
+                hipLaunchKernelGGL((lvt_conv_patch_kernel<0, 1>), dim3((unsigned)(g->N * (g->Co / 128))), dim3(PT_THREADS), 0,
+                                   (hipStream_t)stream, p);
             LVT_CHECK_LAUNCH("lvt_conv_patch_kernel");
             return LVT_OK;
         }
@@ -1546,7 +1776,7 @@ extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const floa
 static bool convt2x_eligible(const lvt_conv_geom *g, int flags) {
     static const int off = (getenv("LVT_NO_PATCH_CONV") || getenv("LVT_NO_PHASE_CONV")) ? 1 : 0;
     // g is the geometry of the FORWARD strided convolution (Ci -> Co, 32x32 -> 16x16); the transposed pass maps Co -> Ci
-    return !off && math_of(flags) == 1 && BK == 32 && g->Kt == 1 && g->Kh == 4 && g->Kw == 4 && g->st == 1 && g->sh == 2 &&
+    return !off && math_of(flags) >= 1 && BK == 32 && g->Kt == 1 && g->Kh == 4 && g->Kw == 4 && g->st == 1 && g->sh == 2 &&
            g->sw == 2 && g->pt == 0 && g->ph == 1 && g->pw == 1 && g->Ti == 1 && g->Hi == 32 && g->Wi == 32 && g->To == 1 &&
            g->Ho == 16 && g->Wo == 16 && g->Co % 32 == 0 && g->Ci % 128 == 0;
 }
@@ -1563,7 +1793,8 @@ extern "C" int lvt_conv3d_pack_weight_phases(const lvt_conv_geom *g, const float
     return LVT_OK;
 }
 extern "C" int lvt_conv3d_bwd_data_phases(const lvt_conv_geom *g, const float *dy, const float *wph, const float *bias,
-                                          const float *res, const float *mask, float *dx, int flags, void *stream) {
+                                          const float *res, const float *mask, float *dx, int flags, const lvt_amax_io *ax,
+                                          void *stream) {
     int rc = check_geom(g, "conv3d_bwd_data_phases"); if (rc) return rc;
     LVT_REQUIRE(dy && wph && dx, "conv3d_bwd_data_phases: null pointer");
     LVT_REQUIRE(convt2x_eligible(g, flags), "conv3d_bwd_data_phases: geometry not served (see lvt_conv3d_bwd_data_uses_phase_kernel)");
@@ -1579,14 +1810,20 @@ extern "C" int lvt_conv3d_bwd_data_phases(const lvt_conv_geom *g, const float *d
     p.alpha = 1.f; p.flags = flags; p.bias = bias; p.res = res; p.ldr = g->Ci; p.mask = mask; p.ldm = g->Ci;
     p.splits = 1; p.vec_epi = 1;
     p.g = *g; p.g.Ci = g->Co;                                   // the kernel's input channel count
-    hipLaunchKernelGGL(lvt_conv_patch_kernel<1>, dim3((unsigned)(g->N * 4 * (g->Ci / 128))), dim3(PT_THREADS), 0,
-                       (hipStream_t)stream, p);
+    LVT_REQUIRE_AMAX(flags, ax, "conv3d_bwd_data_phases"); set_amax(p, ax);
+    if (math_of(flags) == 2)
+        hipLaunchKernelGGL((lvt_conv_patch_kernel<1, 2>), dim3((unsigned)(g->N * 4 * (g->Ci / 128))), dim3(PT_THREADS), 0,
+                           (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((lvt_conv_patch_kernel<1, 1>), dim3((unsigned)(g->N * 4 * (g->Ci / 128))), dim3(PT_THREADS), 0,
+                           (hipStream_t)stream, p);
     LVT_CHECK_LAUNCH("lvt_conv_patch_kernel<1>");
     return LVT_OK;
 }
 
 extern "C" int lvt_conv3d_bwd_data(const lvt_conv_geom *g, const float *dy, const float *wp, const float *bias,
-                                   const float *res, const float *mask, float *dx, int flags, void *stream) {
+                                   const float *res, const float *mask, float *dx, int flags, const lvt_amax_io *ax,
+                                   void *stream) {
     int rc = check_geom(g, "conv3d_bwd_data"); if (rc) return rc;
     LVT_REQUIRE(dy && wp && dx, "conv3d_bwd_data: null pointer");
     LVT_REQUIRE(g->Kt % g->st == 0 && g->Kh % g->sh == 0 && g->Kw % g->sw == 0,
@@ -1606,6 +1843,7 @@ extern "C" int lvt_conv3d_bwd_data(const lvt_conv_geom *g, const float *dy, cons
     p.A = dy; p.B = wp; p.C = dx; p.ldc = g->Ci; p.batch_inner = 1;
     p.alpha = 1.f; p.flags = flags; p.bias = bias; p.res = res; p.ldr = g->Ci; p.mask = mask; p.ldm = g->Ci;
     p.splits = 1; p.g = *g;
+    LVT_REQUIRE_AMAX(flags, ax, "conv3d_bwd_data"); set_amax(p, ax);
     const int ncls = g->st * g->sh * g->sw;
     if (g->Ci <= 32) return launch_tile<A_CONVT_K, B_CONVT_W, 128, 32, 4, 1>(p, ncls, (hipStream_t)stream);
     return launch_tile<A_CONVT_K, B_CONVT_W, 128, 128, 2, 2>(p, ncls, (hipStream_t)stream);
@@ -1616,12 +1854,19 @@ int lvt_wgrad_frames_role(const lvt_conv_geom *g, int flags);
 size_t lvt_wgrad_frames_workspace_bytes(const lvt_conv_geom *g);
 int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, int Ci_real, int Co_real,
                             void *workspace, hipStream_t s, void (*unpack_plain)(const float *, long long, int, float *,
-                                                                                 const lvt_conv_geom *, int, int, hipStream_t));
+                                                                                 const lvt_conv_geom *, int, int, hipStream_t),
+                            const float *x_amax, const float *dy_amax);
+// the tiled unpack kernel turns a [64 co][4 ci x taps] tile through dynamic LDS: served while that tile fits in 64 KB
+static bool unpack_tiled_ok(const lvt_conv_geom *g, int Ci_real, int Co_real) {
+    const int taps = g->Kt * g->Kh * g->Kw;
+    return g->Co % UW_CO == 0 && g->Ci % UW_CI == 0 && Ci_real == g->Ci && Co_real == g->Co &&
+           (size_t)UW_CO * (UW_CI * taps + 1) * sizeof(float) <= 64 * 1024;
+}
 static void unpack_plain_wgrad(const float *partial, long long stride, int splits, float *dw, const lvt_conv_geom *g,
                                int Ci_real, int Co_real, hipStream_t s) {
     const int taps = g->Kt * g->Kh * g->Kw;
     const long long total = (long long)taps * g->Ci * g->Co;
-    if (g->Co % UW_CO == 0 && g->Ci % UW_CI == 0 && Ci_real == g->Ci && Co_real == g->Co) {
+    if (unpack_tiled_ok(g, Ci_real, Co_real)) {
         hipLaunchKernelGGL(lvt_unpack_wgrad_tiled_kernel, dim3((unsigned)((g->Co / UW_CO) * (g->Ci / UW_CI))), dim3(256),
                            (size_t)UW_CO * (UW_CI * taps + 1) * sizeof(float), s, partial, stride, splits, dw, taps, g->Ci, g->Co);
         return;
@@ -1653,8 +1898,8 @@ extern "C" size_t lvt_conv3d_bwd_weight_workspace_bytes(const lvt_conv_geom *g) 
 }
 
 extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, float *db,
-                                     int Ci_real, int Co_real, int flags, void *workspace, size_t workspace_bytes,
-                                     void *stream) {
+                                     int Ci_real, int Co_real, int flags, const lvt_amax_io *ax, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
     int rc = check_geom(g, "conv3d_bwd_weight"); if (rc) return rc;
     LVT_REQUIRE(x && dy && dw && Ci_real <= g->Ci && Co_real <= g->Co, "conv3d_bwd_weight: bad args");
     const size_t need = lvt_conv3d_bwd_weight_workspace_bytes(g);
@@ -1664,16 +1909,23 @@ extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, con
     }
     const long long pix = (long long)g->N * g->To * g->Ho * g->Wo;
     LVT_REQUIRE(pix < 0x7fffffffLL, "conv3d_bwd_weight: too many positions");
-    LVT_REQUIRE((flags & ~LVT_MATH_F32) == 0, "conv3d_bwd_weight: only LVT_MATH_F32 is accepted in flags");
+    LVT_REQUIRE((flags & ~(LVT_MATH_F32 | LVT_MATH_F16X2)) == 0, "conv3d_bwd_weight: only LVT_MATH_* is accepted in flags");
+    LVT_REQUIRE_AMAX(flags, ax, "conv3d_bwd_weight");
+    const bool f16 = math_of(flags) == 2;
     if (lvt_wgrad_frames_role(g, flags) && lvt_aligned16(x) && lvt_aligned16(dy)) {
         LVT_REQUIRE(!db, "conv3d_bwd_weight: this geometry runs on the frame-resident kernel, which leaves the bias gradient "
                          "to lvt_colsum (see lvt_conv3d_bwd_weight_fuses_bias)");
-        return lvt_wgrad_frames_launch(g, x, dy, dw, Ci_real, Co_real, workspace, (hipStream_t)stream, unpack_plain_wgrad);
+        rc = lvt_wgrad_frames_launch(g, x, dy, dw, Ci_real, Co_real, workspace, (hipStream_t)stream, unpack_plain_wgrad,
+                                     f16 ? ax->a : nullptr, f16 ? ax->b : nullptr);
+        if (rc) return rc;
+        LVT_CHECK_LAUNCH("conv3d_bwd_weight (frame-resident)");
+        return LVT_OK;
     }
     const int taps = g->Kt * g->Kh * g->Kw;
     KParams p; memset(&p, 0, sizeof(p));
     p.M = taps * g->Ci; p.N = g->Co; p.K = (int)pix;
     p.A = x; p.B = dy; p.ldb = g->Co; p.batch_inner = 1; p.alpha = 1.f; p.g = *g; p.flags = flags;
+    if (f16) { p.a_amax = ax->a; p.b_amax = ax->b; }
     p.splits = bwd_weight_splits(g);
     p.k_per_split = (int)(lvt_cdiv(lvt_cdiv(p.K, p.splits), BK) * BK);
     p.partial = (float *)workspace;
@@ -1686,7 +1938,7 @@ extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, con
     const long long total = (long long)taps * g->Ci * g->Co;
     int L = 1;
     while (L < 64 && L * 4 <= p.splits) L <<= 1;                     // ~4 splits per lane
-    if (g->Co % UW_CO == 0 && g->Ci % UW_CI == 0 && Ci_real == g->Ci && Co_real == g->Co) {
+    if (unpack_tiled_ok(g, Ci_real, Co_real)) {
         // the weight part on the tiled kernel; the generic kernel then only reduces the bias gradient (taps = 0: no elements)
         hipLaunchKernelGGL(lvt_unpack_wgrad_tiled_kernel, dim3((unsigned)((g->Co / UW_CO) * (g->Ci / UW_CI))), dim3(256),
                            (size_t)UW_CO * (UW_CI * taps + 1) * sizeof(float), s, (const float *)p.partial, p.partial_stride, p.splits,
@@ -1717,7 +1969,8 @@ extern "C" size_t lvt_onehot_tn_workspace_bytes(int nslots, int V, int N, long l
 }
 extern "C" int lvt_onehot_tn_gemm(const long long *idx, int nslots, int V, const int *slot_off, long long bstride,
                                   long long pstride, int P, long long rows, const float *dout, long long ldb, int N,
-                                  float *out, int flags, void *workspace, size_t workspace_bytes, void *stream) {
+                                  float *out, int flags, const float *dout_amax, void *workspace, size_t workspace_bytes,
+                                  void *stream) {
     LVT_REQUIRE(idx && slot_off && dout && out && nslots > 0 && nslots <= 32 && V > 0 && V % 4 == 0,
                 "onehot_tn_gemm: bad args");
     LVT_REQUIRE(rows > 0 && rows < 0x7fffffffLL && P > 0 && rows % P == 0 && N % 4 == 0 && ldb % 4 == 0,
@@ -1729,7 +1982,9 @@ extern "C" int lvt_onehot_tn_gemm(const long long *idx, int nslots, int V, const
     }
     KParams p; memset(&p, 0, sizeof(p));
     p.M = nslots * V; p.N = N; p.K = (int)rows;
-    p.B = dout; p.ldb = ldb; p.batch_inner = 1; p.alpha = 1.f; p.flags = flags & LVT_MATH_F32;
+    LVT_REQUIRE(math_of(flags) != 2 || dout_amax, "onehot_tn_gemm: LVT_MATH_F16X2 needs dout_amax");
+    p.B = dout; p.ldb = ldb; p.batch_inner = 1; p.alpha = 1.f; p.flags = flags & (LVT_MATH_F32 | LVT_MATH_F16X2);
+    p.b_amax = dout_amax;             // (the one-hot operand is exact in fp16 unscaled: a_amax stays NULL)
     p.oh_idx = idx; p.oh_bstride = bstride; p.oh_pstride = pstride; p.oh_P = P; p.oh_V = V;
     for (int i = 0; i < nslots; ++i) p.oh_off[i] = slot_off[i];
     p.splits = onehot_splits(p.M, N, rows);

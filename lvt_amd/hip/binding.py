@@ -14,8 +14,9 @@ _LIB_PATH = os.environ.get("LVT_HIP_LIB") or os.path.join(os.path.dirname(_HERE)
 
 EPI_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_TANH, EPI_MASK, EPI_ACCUM, EPI_PLANES = 1, 2, 4, 8, 16, 32, 64
 CAUSAL_KMAX, CAUSAL_KMIN, CAUSAL_TILE = 1 << 8, 1 << 9, 1 << 10      # causal attention products (include/lvt_hip.h)
-ABI_VERSION = 300           # lvt_version() of the library this module binds (argument lists below)
-MATH_F32 = 1 << 16          # per-call arithmetic selector of the engine entry points (include/lvt_hip.h)
+ABI_VERSION = 400           # lvt_version() of the library this module binds (argument lists below)
+MATH_F32 = 1 << 16          # per-call arithmetic selectors of the engine entry points (include/lvt_hip.h)
+MATH_F16X2 = 1 << 18
 
 
 class LvtError(RuntimeError):
@@ -35,7 +36,17 @@ class GemmDesc(C.Structure):
         ("bias", C.c_void_p), ("res", C.c_void_p), ("ldr", C.c_longlong),
         ("mask", C.c_void_p), ("ldm", C.c_longlong), ("splits", C.c_int),
         ("a_colsum", C.c_void_p), ("c_plane", C.c_longlong),
+        ("a_amax", C.c_void_p), ("b_amax", C.c_void_p), ("c_amax", C.c_void_p),
     ]
+
+
+class AmaxEntry(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("n", C.c_longlong), ("out", C.c_void_p)]
+
+
+class AmaxIO(C.Structure):
+    """lvt_amax_io: device scalars with max |.| of the two operands (f16x2 mode) and of the result (optional)."""
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p)]
 
 
 class OptEntry(C.Structure):
@@ -74,15 +85,18 @@ def _declare(lib):
         "lvt_conv3d_uses_patch_kernel": (ci, [P(ConvGeom), ci]),
         "lvt_conv3d_fwd_uses_parity_kernel": (ci, [P(ConvGeom), ci]),
         "lvt_conv3d_pack_weight_parity": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
-        "lvt_conv3d_fwd_parity": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
-        "lvt_conv3d_fwd": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
+        "lvt_amax": (ci, [vp, cll, vp, vp]),
+        "lvt_amax_multi": (ci, [P(AmaxEntry), ci, vp]),
+        "lvt_amax_merge": (ci, [vp, vp, vp, vp]),
+        "lvt_conv3d_fwd_parity": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, P(AmaxIO), vp]),
+        "lvt_conv3d_fwd": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, P(AmaxIO), vp]),
         "lvt_conv3d_bwd_data_uses_phase_kernel": (ci, [P(ConvGeom), ci]),
         "lvt_conv3d_pack_weight_phases": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
-        "lvt_conv3d_bwd_data_phases": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
-        "lvt_conv3d_bwd_data": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, vp]),
+        "lvt_conv3d_bwd_data_phases": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, P(AmaxIO), vp]),
+        "lvt_conv3d_bwd_data": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, P(AmaxIO), vp]),
         "lvt_conv3d_bwd_weight_workspace_bytes": (sz, [P(ConvGeom)]),
         "lvt_conv3d_bwd_weight_fuses_bias": (ci, [P(ConvGeom), ci]),
-        "lvt_conv3d_bwd_weight": (ci, [P(ConvGeom), vp, vp, vp, vp, ci, ci, ci, vp, sz, vp]),
+        "lvt_conv3d_bwd_weight": (ci, [P(ConvGeom), vp, vp, vp, vp, ci, ci, ci, P(AmaxIO), vp, sz, vp]),
         "lvt_convt4_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]),
         "lvt_colsum_workspace_bytes": (sz, [cll, ci]),
         "lvt_colsum": (ci, [vp, cll, ci, cll, vp, vp, sz, vp]),
@@ -92,31 +106,31 @@ def _declare(lib):
         "lvt_vq_ema_workspace_bytes": (sz, [cll, ci, ci, ci]),
         "lvt_vq_ema_accumulate": (ci, [vp, vp, cll, ci, ci, ci, ci, ci, vp, vp, sz, vp]),
         "lvt_vq_ema_finalize": (ci, [vp, ci, ci, ci, cf, cf, vp, vp, vp, vp]),
-        "lvt_to_channels_last": (ci, [vp, ci, ci, cll, ci, ci, vp, vp, vp, vp]),
+        "lvt_to_channels_last": (ci, [vp, ci, ci, cll, ci, ci, vp, vp, vp, vp, vp]),
         "lvt_to_channels_first": (ci, [vp, ci, ci, cll, ci, ci, vp, vp, cf, cf, vp, vp]),
         "lvt_reduce_workspace_bytes": (sz, []),
         "lvt_mse_fwd": (ci, [vp, vp, cll, C.c_double, cf, vp, vp, sz, vp]),
-        "lvt_mse_bwd": (ci, [vp, vp, cll, C.c_double, cf, vp, vp, ci, vp, vp]),
-        "lvt_tanh_bwd": (ci, [vp, vp, cll, vp, vp]),
+        "lvt_mse_bwd": (ci, [vp, vp, cll, C.c_double, cf, vp, vp, ci, vp, vp, vp]),
+        "lvt_tanh_bwd": (ci, [vp, vp, cll, vp, vp, vp]),
         "lvt_axpy": (ci, [vp, vp, cll, vp, cf, vp, vp]),
         "lvt_add_periodic": (ci, [vp, vp, cll, ci, ci, vp]),
-        "lvt_layernorm_fwd": (ci, [vp, cll, ci, cf, vp, vp, vp, vp, vp, vp]),
+        "lvt_layernorm_fwd": (ci, [vp, cll, ci, cf, vp, vp, vp, vp, vp, vp, vp]),
         "lvt_layernorm_bwd_workspace_bytes": (sz, [ci]),
-        "lvt_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, cll, ci, vp, vp, vp, vp, vp, sz, vp]),
+        "lvt_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, cll, ci, vp, vp, vp, vp, vp, vp, sz, vp]),
         "lvt_attn_softmax_fwd": (ci, [vp, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp]),
         "lvt_attn_softmax_bwd": (ci, [vp, vp, ci, ci, ci, cf, ci, ci, ci, vp, vp, vp, vp, vp]),
         "lvt_attn_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp]),
         "lvt_attn_planes_supported": (ci, [ci, ci, ci, ci, ci]),
-        "lvt_attn_fwd_planes": (ci, [vp, cll, cll, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp]),
+        "lvt_attn_fwd_planes": (ci, [vp, cll, cll, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp, vp]),
         "lvt_attn_bwd_planes_workspace_bytes": (sz, [ci, ci, ci, ci, ci, ci]),
-        "lvt_attn_bwd_planes": (ci, [vp, cll, cll, vp, vp, vp, ci, ci, ci, ci, cf, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+        "lvt_attn_bwd_planes": (ci, [vp, cll, cll, vp, vp, vp, ci, ci, ci, ci, cf, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
         "lvt_attn_decode": (ci, [vp, cll, vp, vp, ci, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, vp, vp, cll, vp]),
         "lvt_decode_gather_codes": (ci, [vp, vp, vp, ci, ci, ci, vp, vp]),
         "lvt_decode_commit": (ci, [vp, ci, ci, vp, vp, vp]),
         "lvt_sample_categorical": (ci, [vp, cll, ci, cf, vp, vp, cll, vp, vp, cll, vp]),
         "lvt_embbag_fwd": (ci, [vp, cll, ci, cll, ci, P(ci), P(ci), vp, ci, vp, vp, vp, vp, vp]),
         "lvt_onehot_tn_workspace_bytes": (sz, [ci, ci, ci, cll]),
-        "lvt_onehot_tn_gemm": (ci, [vp, ci, ci, P(ci), cll, cll, ci, cll, vp, cll, ci, vp, ci, vp, sz, vp]),
+        "lvt_onehot_tn_gemm": (ci, [vp, ci, ci, P(ci), cll, cll, ci, cll, vp, cll, ci, vp, ci, vp, vp, sz, vp]),
         "lvt_permute3": (ci, [vp, cll, cll, cll, ci, ci, ci, vp, vp]),
         "lvt_row_gather": (ci, [vp, vp, cll, ci, ci, vp, vp]),
         "lvt_slice_context": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci, cll, vp, vp, vp, vp, vp]),
@@ -154,19 +168,23 @@ def lib():
     return _lib
 
 
-# The library itself is stateless: every engine call carries its arithmetic in `flags` (MATH_F32 or not).  The default the
-# Python wrappers pass is a host-side setting of this module (LVT_MATH environment variable, or set_math_mode()).
+# The library itself is stateless: every engine call carries its arithmetic in `flags`.  The default the Python wrappers
+# pass is a host-side setting of this module (LVT_MATH environment variable, or set_math_mode()).
+MATH_MODES = ("f32", "bf16x3", "f16x2")
 _math_mode = os.environ.get("LVT_MATH", "bf16x3")
-if _math_mode not in ("f32", "bf16x3"):
-    raise LvtError("LVT_MATH must be 'f32' or 'bf16x3' (got %r)" % _math_mode)
+if _math_mode not in MATH_MODES:
+    raise LvtError("LVT_MATH must be one of %s (got %r)" % (MATH_MODES, _math_mode))
 
 
 def set_math_mode(mode):
-    """'bf16x3' (default: exact 3-way bf16 split of fp32 operands on the bf16 matrix cores, fp32 accumulation) or
-    'f32' (plain fp32 MFMA): what the wrappers of lvt_amd.hip put into the `flags` of the calls they issue from now on."""
+    """What the wrappers of lvt_amd.hip put into the `flags` of the engine calls they issue from now on:
+    'bf16x3' (default) exact 3-way bf16 split of the fp32 operands, six bf16 MFMAs per block;
+    'f16x2'  2-way fp16 split after an exact power-of-two scale from the operand's max |.|, three fp16 MFMAs per block
+             (the wrappers carry the max |.| of every engine operand along: `amax_of`, `new_amax`);
+    'f32'    plain fp32 MFMA.  All three are fp32 in / fp32 out with fp32 accumulation."""
     global _math_mode
-    if mode not in ("f32", "bf16x3"):
-        raise LvtError("math mode must be 'f32' or 'bf16x3' (got %r)" % (mode,))
+    if mode not in MATH_MODES:
+        raise LvtError("math mode must be one of %s (got %r)" % (MATH_MODES, mode))
     _math_mode = mode
 
 
@@ -175,7 +193,162 @@ def get_math_mode():
 
 
 def math_flag():
-    return MATH_F32 if _math_mode == "f32" else 0
+    return MATH_F32 if _math_mode == "f32" else (MATH_F16X2 if _math_mode == "f16x2" else 0)
+
+
+def f16x2():
+    return _math_mode == "f16x2"
+
+
+# ---- max |.| bookkeeping of the f16x2 arithmetic -------------------------------------------------------------------
+# Every operand of an f16x2 engine launch needs a device scalar >= max |operand|.  Engine launches report the max of what
+# they write (c_amax), the helper kernels that produce engine operands do the same, and anything else falls back to one
+# lvt_amax pass.  The scalar rides on the tensor object as `_lvt_amax = (slot, version, epoch, data_ptr)`: a torch in-place
+# op bumps `_version`, `p.data = ...` changes the pointer, and whatever rewrites tensors behind torch's back bumps the epoch
+# (the fused optimizers after a step; the meta-architectures at the start of every forward, which also covers parameters
+# edited through `.data` between passes) -- any of them invalidates the record.
+_amax_pool, _amax_pos, _epoch = None, 0, 0
+
+
+def bump_epoch():
+    """Called by whatever rewrites tensors behind torch's back (the fused optimizers): forget every cached max |.|."""
+    global _epoch
+    _epoch += 1
+
+
+def amax_slot(device):
+    """A fresh zeroed float32 device scalar (a 1-element view of a pool that is zero-filled 4096 slots at a time)."""
+    global _amax_pool, _amax_pos
+    if _amax_pool is None or _amax_pos >= _amax_pool.numel() or _amax_pool.device != device:
+        _amax_pool, _amax_pos = torch.zeros(4096, dtype=torch.float32, device=device), 0
+    s = _amax_pool[_amax_pos:_amax_pos + 1]
+    _amax_pos += 1
+    return s
+
+
+def set_amax(t, slot):
+    t._lvt_amax = (slot, t._version, _epoch, t.data_ptr())
+    return t
+
+
+def drop_amax(t):
+    if getattr(t, "_lvt_amax", None) is not None:
+        t._lvt_amax = None
+
+
+def _valid_amax(t):
+    rec = getattr(t, "_lvt_amax", None)
+    if rec is not None and rec[1] == t._version and rec[2] == _epoch and rec[3] == t.data_ptr():
+        return rec[0]
+    return None
+
+
+def new_amax(t):
+    """Attach a fresh zeroed slot to `t` (about to be written by a launch that reports max |t| into it) and return it."""
+    slot = amax_slot(t.device)
+    set_amax(t, slot)
+    return slot
+
+
+def amax_of(t):
+    """Device scalar >= max |t|: the record on `t`, or on the tensor it is a view of (the max of the whole is a bound for
+    the part), else one lvt_amax pass whose result is cached on `t`."""
+    slot = _valid_amax(t)
+    if slot is not None:
+        return slot
+    base = t._base
+    if base is not None:
+        slot = _valid_amax(base)
+        if slot is not None:
+            return slot
+    src = t
+    if not t.is_contiguous():
+        if base is None or not base.is_contiguous():
+            raise LvtError("amax_of: non-contiguous tensor without a contiguous base")
+        src = base                    # strided view: scan (and cache on) the whole it was cut from
+    require(src)
+    slot = amax_slot(src.device)
+    check(lib().lvt_amax(ptr(src), src.numel(), ptr(slot), stream_ptr()), "lvt_amax")
+    AMAX_FALLBACKS[0] += 1
+    if AMAX_TRACE is not None:          # diagnostic: who needed a stand-alone pass (call sites that should carry a record)
+        import traceback
+        fr = [f for f in traceback.extract_stack()[:-1] if "binding.py" not in f.filename][-3:]
+        key = " < ".join("%s:%d" % (os.path.basename(f.filename), f.lineno) for f in reversed(fr)) + " %s" % (tuple(src.shape),)
+        AMAX_TRACE[key] = AMAX_TRACE.get(key, 0) + 1
+    set_amax(src, slot)
+    return slot
+
+
+def out_amax(t):
+    """Pointer argument for a helper kernel that can report max |t| of the tensor it is about to write: a fresh slot
+    attached to `t` in f16x2 mode, NULL otherwise."""
+    return ptr(new_amax(t)) if _math_mode == "f16x2" else None
+
+
+def amax_prefetch(tensors):
+    """max |.| of many tensors (the weights of a model at the start of a pass) in ONE launch per 64 instead of one
+    lvt_amax pass each; tensors that still hold a valid record are skipped.  No-op outside f16x2 mode."""
+    if _math_mode != "f16x2":
+        return
+    todo = [t for t in tensors if t is not None and t.is_cuda and _valid_amax(t) is None and t.is_contiguous() and t.numel() > 0]
+    if not todo:
+        return
+    arr = (AmaxEntry * len(todo))()
+    for e, t in zip(arr, todo):
+        slot = amax_slot(t.device)
+        e.x, e.n, e.out = t.data_ptr(), t.numel(), slot.data_ptr()
+        set_amax(t, slot)
+    check(lib().lvt_amax_multi(arr, len(todo), stream_ptr()), "lvt_amax_multi")
+
+
+def prefetch_module_weights(module):
+    """max |.| of every matrix-shaped parameter of `module` (the operands its engine launches will read) in one launch
+    per 64 tensors: what a meta-architecture calls at the start of a pass, right after bump_epoch().  Attention modules
+    contribute their packed (3, na, d, da) q/k/v buffer, which is what the launches address."""
+    if _math_mode != "f16x2":
+        return
+    todo = []
+    for m in module.modules():
+        packed = getattr(m, "packed_qkv", None)
+        skip = ()
+        if packed is not None:
+            todo.append(packed())
+            skip = ("w_q", "w_k", "w_v")
+        for name, p in m.named_parameters(recurse=False):
+            if p.dim() >= 2 and name not in skip:
+                todo.append(p)
+    amax_prefetch(todo)
+
+
+def amax_merged(*tensors):
+    """A slot holding the max over the records of several tensors (an operand that spans them: batched launches whose
+    batch strides are address differences)."""
+    slots = [amax_of(t) for t in tensors]
+    out = amax_slot(tensors[0].device)
+    for i in range(0, len(slots), 2):
+        check(lib().lvt_amax_merge(ptr(slots[i]), ptr(slots[i + 1]) if i + 1 < len(slots) else None, ptr(out), stream_ptr()),
+              "lvt_amax_merge")
+    return out
+
+
+AMAX_TRACE = {} if os.environ.get("LVT_AMAX_TRACE") else None
+AMAX_FALLBACKS = [0]        # diagnostic: stand-alone lvt_amax passes issued so far (bench.py reports them per step)
+
+
+def amax_io(a=None, b=None, c=None):
+    """lvt_amax_io for an engine call: operands a, b (tensors; looked up only in f16x2 mode), result c (tensor that the
+    launch is about to write).  Returns None outside f16x2 mode (the entry points take a NULL pointer)."""
+    if _math_mode != "f16x2":
+        return None
+    io = AmaxIO()
+    io.a = amax_of(a).data_ptr() if a is not None else None
+    io.b = amax_of(b).data_ptr() if b is not None else None
+    io.c = new_amax(c).data_ptr() if c is not None else None
+    return io
+
+
+def io_ref(io):
+    return C.byref(io) if io is not None else None
 
 
 def declared_symbols():

@@ -16,7 +16,7 @@ def to_channels_last(x_bcr, ldo, mode=0, a=None, s=None):
     B, Cc, R = x_bcr.shape
     out = _f32(B, R, ldo, like=x_bcr)
     L.check(L.lib().lvt_to_channels_last(L.ptr(x_bcr), B, Cc, R, ldo, mode, L.ptr(a), L.ptr(s), L.ptr(out),
-                                         L.stream_ptr()), "lvt_to_channels_last")
+                                         L.out_amax(out), L.stream_ptr()), "lvt_to_channels_last")
     return out
 
 
@@ -48,14 +48,14 @@ def mse_bwd(a, b, denom, scale=1.0, gout=None, add=None, tanh_of_a=False):
     L.require(a, b, gout, add)
     out = torch.empty_like(a)
     L.check(L.lib().lvt_mse_bwd(L.ptr(a), L.ptr(b), a.numel(), float(denom), scale, L.ptr(gout), L.ptr(add),
-                                1 if tanh_of_a else 0, L.ptr(out), L.stream_ptr()), "lvt_mse_bwd")
+                                1 if tanh_of_a else 0, L.ptr(out), L.out_amax(out), L.stream_ptr()), "lvt_mse_bwd")
     return out
 
 
 def tanh_bwd(g, y):
     L.require(g, y)
     out = torch.empty_like(g)
-    L.check(L.lib().lvt_tanh_bwd(L.ptr(g), L.ptr(y), g.numel(), L.ptr(out), L.stream_ptr()), "lvt_tanh_bwd")
+    L.check(L.lib().lvt_tanh_bwd(L.ptr(g), L.ptr(y), g.numel(), L.ptr(out), L.out_amax(out), L.stream_ptr()), "lvt_tanh_bwd")
     return out
 
 
@@ -72,6 +72,7 @@ def add_periodic_(x, table, P):
     d = x.shape[-1]
     L.check(L.lib().lvt_add_periodic(L.ptr(x), L.ptr(table), x.numel() // d, P, d, L.stream_ptr()),
             "lvt_add_periodic")
+    L.drop_amax(x)          # rewritten in place behind torch's back
     return x
 
 
@@ -83,7 +84,7 @@ def layernorm_fwd(x, w, b, eps=1e-5, save_stats=True):
     mean = _f32(rows, like=x) if save_stats else None
     rstd = _f32(rows, like=x) if save_stats else None
     L.check(L.lib().lvt_layernorm_fwd(L.ptr(x), rows, d, eps, L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(mean),
-                                      L.ptr(rstd), L.stream_ptr()), "lvt_layernorm_fwd")
+                                      L.ptr(rstd), L.out_amax(y), L.stream_ptr()), "lvt_layernorm_fwd")
     return y, mean, rstd
 
 
@@ -96,7 +97,7 @@ def layernorm_bwd(dy, x, mean, rstd, w, add=None):
     n = L.lib().lvt_layernorm_bwd_workspace_bytes(d)
     ws = L.workspace(n, x.device, "ln")
     L.check(L.lib().lvt_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(w), rows, d, L.ptr(add),
-                                      L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws), n, L.stream_ptr()),
+                                      L.ptr(dx), L.ptr(dw), L.ptr(db), L.out_amax(dx), L.ptr(ws), n, L.stream_ptr()),
             "lvt_layernorm_bwd")
     return dx, dw, db
 
@@ -108,4 +109,6 @@ def row_gather(x, perm, S):
     out = torch.empty_like(x)
     L.check(L.lib().lvt_row_gather(L.ptr(x), L.ptr(perm), x.numel() // (S * d), S, d, L.ptr(out), L.stream_ptr()),
             "lvt_row_gather")
+    if L.f16x2() and L._valid_amax(x) is not None:
+        L.set_amax(out, L._valid_amax(x))        # a permutation of the rows: same max |.|
     return out

@@ -30,6 +30,11 @@ def gemm(A, B, C_out, M, N, K, ta=0, tb=0, lda=None, ldb=None, ldc=None, a_kb=0,
     d.splits = splits
     d.a_colsum = a_colsum.data_ptr() if a_colsum is not None else None
     d.c_plane = c_plane
+    if L.f16x2():
+        # operand scales of the f16x2 arithmetic; the launch reports max |C| unless it is a split-K one (weight gradients)
+        d.a_amax, d.b_amax = L.amax_of(A).data_ptr(), L.amax_of(B).data_ptr()
+        if splits <= 1 and C_out.dtype == torch.float32:
+            d.c_amax = L.new_amax(C_out).data_ptr()
     lib = L.lib()
     ws, nws = None, 0
     if splits > 1:
@@ -133,12 +138,19 @@ def conv_flops(g):
     return 2.0 * g.N * g.To * g.Ho * g.Wo * g.Co * g.Ci * g.Kt * g.Kh * g.Kw
 
 
+def _same_amax(packed, w):
+    """A re-layout (plus zero padding) of `w` has the same max |.|: hand the record on (f16x2 mode only)."""
+    if L.f16x2():
+        L.set_amax(packed, L.amax_of(w))
+    return packed
+
+
 def pack_weight(g, w, Ci_real, Co_real):
     L.require(w)
     wp = torch.empty(g.Kt * g.Kh * g.Kw, g.Ci, g.Co, dtype=torch.float32, device=w.device)
     L.check(L.lib().lvt_conv3d_pack_weight(C.byref(g), L.ptr(w), Ci_real, Co_real, L.ptr(wp), L.stream_ptr()),
             "lvt_conv3d_pack_weight")
-    return wp
+    return _same_amax(wp, w)
 
 
 def pack_weight_t(g, w, Ci_real, Co_real):
@@ -147,7 +159,7 @@ def pack_weight_t(g, w, Ci_real, Co_real):
     wt = torch.empty(g.Kt * g.Kh * g.Kw, g.Co, g.Ci, dtype=torch.float32, device=w.device)
     L.check(L.lib().lvt_conv3d_pack_weight_t(C.byref(g), L.ptr(w), Ci_real, Co_real, L.ptr(wt), L.stream_ptr()),
             "lvt_conv3d_pack_weight_t")
-    return wt
+    return _same_amax(wt, w)
 
 
 def swapped_geom(g):
@@ -170,7 +182,7 @@ def pack_weight_parity(g, w, Ci_real, Co_real):
     wq = torch.empty(4, 4, g.Ci, g.Co, dtype=torch.float32, device=w.device)
     L.check(L.lib().lvt_conv3d_pack_weight_parity(C.byref(g), L.ptr(w), Ci_real, Co_real, L.ptr(wq), L.stream_ptr()),
             "lvt_conv3d_pack_weight_parity")
-    return wq
+    return _same_amax(wq, w)
 
 
 def fwd_by_parity(g):
@@ -187,13 +199,14 @@ def conv_fwd(g, x, wp, bias=None, res=None, mask=None, flags=0, timer_key="conv_
         flags |= L.EPI_RESIDUAL
     if mask is not None:
         flags |= L.EPI_MASK
+    io = L.amax_io(x, wp if wq is None else wq, y)
     t0 = L.TIMER.begin() if L.TIMER is not None else None
     if wq is not None:
         L.check(L.lib().lvt_conv3d_fwd_parity(C.byref(g), L.ptr(x), L.ptr(wq), L.ptr(bias), L.ptr(res), L.ptr(mask), L.ptr(y),
-                                              flags | L.math_flag(), L.stream_ptr()), "lvt_conv3d_fwd_parity")
+                                              flags | L.math_flag(), L.io_ref(io), L.stream_ptr()), "lvt_conv3d_fwd_parity")
     else:
         L.check(L.lib().lvt_conv3d_fwd(C.byref(g), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(mask), L.ptr(y),
-                                       flags | L.math_flag(), L.stream_ptr()), "lvt_conv3d_fwd")
+                                       flags | L.math_flag(), L.io_ref(io), L.stream_ptr()), "lvt_conv3d_fwd")
     if t0 is not None:
         L.TIMER.end(timer_key, conv_flops(g), t0)
     return y
@@ -205,7 +218,7 @@ def pack_weight_phases(g, w, Ci_real, Co_real):
     wph = torch.empty(4, 4, g.Co, g.Ci, dtype=torch.float32, device=w.device)
     L.check(L.lib().lvt_conv3d_pack_weight_phases(C.byref(g), L.ptr(w), Ci_real, Co_real, L.ptr(wph), L.stream_ptr()),
             "lvt_conv3d_pack_weight_phases")
-    return wph
+    return _same_amax(wph, w)
 
 
 def bwd_data_by_phases(g):
@@ -224,9 +237,10 @@ def conv_bwd_data(g, dy, wp, bias=None, res=None, mask=None, flags=0, wt=None, w
         dx = torch.empty(g.N, g.Ti, g.Hi, g.Wi, g.Ci, dtype=torch.float32, device=dy.device)
         flags |= (L.EPI_BIAS if bias is not None else 0) | (L.EPI_RESIDUAL if res is not None else 0) | \
             (L.EPI_MASK if mask is not None else 0)
+        io = L.amax_io(dy, wph, dx)
         t0 = L.TIMER.begin() if L.TIMER is not None else None
         L.check(L.lib().lvt_conv3d_bwd_data_phases(C.byref(g), L.ptr(dy), L.ptr(wph), L.ptr(bias), L.ptr(res), L.ptr(mask),
-                                                   L.ptr(dx), flags | L.math_flag(), L.stream_ptr()),
+                                                   L.ptr(dx), flags | L.math_flag(), L.io_ref(io), L.stream_ptr()),
                 "lvt_conv3d_bwd_data_phases")
         if t0 is not None:
             L.TIMER.end("conv_bwd_data", conv_flops(g), t0)
@@ -239,9 +253,10 @@ def conv_bwd_data(g, dy, wp, bias=None, res=None, mask=None, flags=0, wt=None, w
         flags |= L.EPI_RESIDUAL
     if mask is not None:
         flags |= L.EPI_MASK
+    io = L.amax_io(dy, wp, dx)
     t0 = L.TIMER.begin() if L.TIMER is not None else None
     L.check(L.lib().lvt_conv3d_bwd_data(C.byref(g), L.ptr(dy), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(mask),
-                                        L.ptr(dx), flags | L.math_flag(), L.stream_ptr()), "lvt_conv3d_bwd_data")
+                                        L.ptr(dx), flags | L.math_flag(), L.io_ref(io), L.stream_ptr()), "lvt_conv3d_bwd_data")
     if t0 is not None:
         L.TIMER.end("conv_bwd_data", conv_flops(g), t0)
     return dx
@@ -272,9 +287,10 @@ def conv_bwd_weight(g, x, dy, Ci_real, Co_real, want_bias=False):
     # (the frame-resident kernel of the 3x3 layers leaves the bias gradient to a column-sum launch: db stays None)
     fused_bias = want_bias and bool(lib.lvt_conv3d_bwd_weight_fuses_bias(C.byref(g), L.math_flag()))
     db = torch.empty(Co_real, dtype=torch.float32, device=x.device) if fused_bias else None
+    io = L.amax_io(x, dy)
     t0 = L.TIMER.begin() if L.TIMER is not None else None
     L.check(lib.lvt_conv3d_bwd_weight(C.byref(g), L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), Ci_real, Co_real,
-                                      L.math_flag(), L.ptr(ws), nws, L.stream_ptr()), "lvt_conv3d_bwd_weight")
+                                      L.math_flag(), L.io_ref(io), L.ptr(ws), nws, L.stream_ptr()), "lvt_conv3d_bwd_weight")
     if t0 is not None:
         L.TIMER.end("conv_bwd_weight", conv_flops(g), t0)
     return (dw, db) if want_bias else dw

@@ -40,7 +40,7 @@ def attn_fwd(q, k, v, B, H, S, da, temper, dt, dh, dw, block, masked, fill=-1e4)
 
 def attn_planes_supported(S, da, block, bh_pairs=8):
     """bh_pairs = batch x heads (the pipelined kernels pair their workgroups per XCD: a multiple of 8)."""
-    return bh_pairs % 8 == 0 and bool(L.lib().lvt_attn_planes_supported(S, da, block[0], block[1], block[2])) and L.get_math_mode() == "bf16x3"
+    return bh_pairs % 8 == 0 and bool(L.lib().lvt_attn_planes_supported(S, da, block[0], block[1], block[2])) and L.get_math_mode() != "f32"
 
 
 def attn_fwd_planes(qkvp, B, H, S, da, temper, dt, dh, dw, block, masked, fill=-1e4):
@@ -53,7 +53,7 @@ def attn_fwd_planes(qkvp, B, H, S, da, temper, dt, dh, dw, block, masked, fill=-
     t0 = L.TIMER.begin() if L.TIMER is not None else None
     L.check(L.lib().lvt_attn_fwd_planes(L.ptr(qkvp), M * hd, 3 * M * hd, B, H, S, da, temper, L.ptr(dt), L.ptr(dh), L.ptr(dw),
                                         block[0], block[1], block[2], 1 if masked else 0, fill, L.ptr(P), L.ptr(o),
-                                        L.stream_ptr()), "lvt_attn_fwd_planes")
+                                        L.out_amax(o), L.stream_ptr()), "lvt_attn_fwd_planes")
     if t0 is not None:
         L.TIMER.end("attn_fwd", 4.0 * B * H * S * S * da, t0)
     return P, o
@@ -74,7 +74,8 @@ def attn_bwd_planes(qkvp, dop, P, o, B, H, S, da, temper, block, masked):
     t0 = L.TIMER.begin() if L.TIMER is not None else None
     L.check(lib.lvt_attn_bwd_planes(L.ptr(qkvp), M * hd, 3 * M * hd, L.ptr(dop), L.ptr(P), L.ptr(o), B, H, S, da, temper,
                                     block[0], block[1], block[2], 1 if masked else 0, L.ptr(dqkv[0]), L.ptr(dqkv[1]),
-                                    L.ptr(dqkv[2]), L.ptr(ddt), L.ptr(ddh), L.ptr(ddw), L.ptr(ws), nws, L.stream_ptr()),
+                                    L.ptr(dqkv[2]), L.ptr(ddt), L.ptr(ddh), L.ptr(ddw), L.out_amax(dqkv), L.ptr(ws), nws,
+                                    L.stream_ptr()),
             "lvt_attn_bwd_planes")
     if t0 is not None:
         L.TIMER.end("attn_bwd", 8.0 * B * H * S * S * da, t0)
@@ -125,7 +126,8 @@ def _onehot_once(idx, V, slot_off, bstride, pstride, P, rows, dout, N, ldb):
     ws = L.workspace(nws, dout.device, "onehot")
     t0 = L.TIMER.begin() if L.TIMER is not None else None
     L.check(lib.lvt_onehot_tn_gemm(L.ptr(idx), ns, V, _iarr(slot_off), bstride, pstride, P, rows, L.ptr(dout),
-                                   ldb if ldb is not None else N, N, L.ptr(out), L.math_flag(), L.ptr(ws), nws, L.stream_ptr()),
+                                   ldb if ldb is not None else N, N, L.ptr(out), L.math_flag(),
+                                   L.ptr(L.amax_of(dout)) if L.f16x2() else None, L.ptr(ws), nws, L.stream_ptr()),
             "lvt_onehot_tn_gemm")
     if t0 is not None:
         L.TIMER.end("gemm_onehot_tn", 2.0 * ns * V * N * rows, t0)

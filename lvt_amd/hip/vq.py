@@ -33,6 +33,8 @@ def gather(idx, codebooks):
     out = torch.empty(n * P, num * D, dtype=torch.float32, device=idx.device)
     L.check(L.lib().lvt_vq_gather(L.ptr(idx), L.ptr(codebooks), n * P, num, D, K, P, L.ptr(out), num * D,
                                   L.stream_ptr()), "lvt_vq_gather")
+    if L.f16x2():
+        L.set_amax(out, L.amax_of(codebooks))        # rows of the codebooks: their max |.| bounds the selection
     return out
 
 
@@ -56,3 +58,4 @@ def ema_finalize(stats, running_size, running_sum, weight, decay=0.99, eps=1e-5)
     num, K, D = weight.shape
     L.check(L.lib().lvt_vq_ema_finalize(L.ptr(stats), num, D, K, decay, eps, L.ptr(running_size),
                                         L.ptr(running_sum), L.ptr(weight), L.stream_ptr()), "lvt_vq_ema_finalize")
+    L.drop_amax(weight)         # rewritten in place behind torch's back

@@ -108,6 +108,8 @@ class AutoEncoderModel(nn.Module):
 
     # ---- forward modes (ae.py:101-149) ------------------------------------------------------------
     def forward(self, data, mode="inference"):
+        L.bump_epoch()                       # f16x2 arithmetic: max |.| records of parameters are per pass (hip/binding.py)
+        L.prefetch_module_weights(self)
         if mode in ("generator", "supervised"):
             self.finish_gradient_sync()      # accumulation: the previous micro-step's all-reduce owns the buckets
             x, _ = self._preprocess_cl(data)

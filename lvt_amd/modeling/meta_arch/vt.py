@@ -137,7 +137,14 @@ class VideoTransformerModel(nn.Module):
             return None
         return stack_to_device([torch.as_tensor(x["class"]).long() for x in data], self.device)
 
+    def _begin_pass(self):
+        """f16x2 arithmetic: the max |.| records of the parameters are per pass (hip/binding.py) -- forget the old ones and
+        scan every weight matrix in one launch.  A no-op in the other math modes."""
+        L.bump_epoch()
+        L.prefetch_module_weights(self)
+
     def compute_supervised_loss(self, context, slice, slice_idx, ignore_mask, iter=0, class_idx=None):
+        self._begin_pass()
         ignore = self.cfg.MODEL.IGNORE_INDEX
         b, nc = slice.shape[:2]
         target = torch.masked_fill(slice, ignore_mask, ignore).reshape(b, nc, -1).contiguous()
@@ -148,6 +155,8 @@ class VideoTransformerModel(nn.Module):
         return {"loss_cross_entropy": loss}
 
     def forward(self, data, mode="inference"):
+        if mode != "supervised":
+            self._begin_pass()                   # (compute_supervised_loss begins its own)
         if mode == "supervised":
             self.finish_gradient_sync()      # accumulation: the previous micro-step's all-reduce owns the buckets
             context, slice, slice_idx, ignore_mask, class_idx = self.preprocess_data(data)

@@ -90,6 +90,7 @@ class FusedAdam(_FusedBase):
                 arr = _entries(ents)
                 L.check(L.lib().lvt_adam_step(arr, len(ents), betas[0], betas[1], eps, step, L.stream_ptr()),
                         "lvt_adam_step")
+        L.bump_epoch()          # parameters were rewritten through raw pointers: cached max |.| records are stale
         return loss
 
 
@@ -116,4 +117,5 @@ class FusedRMSprop(_FusedBase):
             for (alpha, eps, mom), ents in batches.items():
                 arr = _entries(ents)
                 L.check(L.lib().lvt_rmsprop_step(arr, len(ents), alpha, eps, mom, L.stream_ptr()), "lvt_rmsprop_step")
+        L.bump_epoch()
         return loss

@@ -1,7 +1,7 @@
 """GPU parity of the MFMA tile engine (GEMM / conv fwd / bwd-data / bwd-weight) against plain
 torch-CPU fp32 ops (the ops the oracle is made of).  Tolerances: fp32 accumulate in a different
 order -> max-abs error relative to the output scale < 2e-5 (stated per test).  Every test runs in both
-arithmetic modes of the engine ('bf16x3', the default, and 'f32') at the SAME tolerance."""
+arithmetic modes of the engine ('bf16x3', 'f16x2' and 'f32') at the SAME tolerance."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
-@pytest.fixture(autouse=True, params=["bf16x3", "f32"])
+@pytest.fixture(autouse=True, params=["bf16x3", "f16x2", "f32"])
 def math_mode(request):
     from lvt_amd.hip import binding as L
     before = L.get_math_mode()
@@ -209,7 +209,7 @@ def test_frame_resident_conv_forward_and_backward_data(Ci, Co, N, math_mode):
     y = torch.relu(F.conv2d(x, w, b, padding=1) + res)
     dev = _dev()
     g = G.conv_geom(N, 1, H, H, Ci, Co, (1, 3, 3), (1, 1, 1), (0, 1, 1))
-    if math_mode == "bf16x3":
+    if math_mode != "f32":
         assert L.lib().lvt_conv3d_uses_patch_kernel(__import__("ctypes").byref(g), L.math_flag()) == 1
     wd = w.to(dev)
     yd = G.conv_fwd(g, _nhwc(x).to(dev), G.pack_weight(g, wd, Ci, Co), bias=b.to(dev), res=_nhwc(res).to(dev), flags=L.EPI_RELU)
@@ -217,7 +217,7 @@ def test_frame_resident_conv_forward_and_backward_data(Ci, Co, N, math_mode):
     gy, rx, msrc = _rand(N, Co, H, H, seed=5), _rand(N, Ci, H, H, seed=6), _rand(N, Ci, H, H, seed=7)
     ref = (F.conv_transpose2d(gy, w, stride=1, padding=1) + rx) * (msrc > 0)
     if Co % 32 == 0 and Ci % 128 == 0:
-        assert G.bwd_data_as_conv(g) == (math_mode == "bf16x3")
+        assert G.bwd_data_as_conv(g) == (math_mode != "f32")
     wt = G.pack_weight_t(g, wd, Ci, Co)
     dx = G.conv_bwd_data(g, _nhwc(gy).to(dev), None, res=_nhwc(rx).to(dev), mask=_nhwc(msrc).to(dev), wt=wt)
     assert rel_err(_nchw(dx), ref) < TOL
@@ -242,7 +242,7 @@ def test_frame_resident_weight_gradient(Ci, Co, N, math_mode):
     dev = _dev()
     g = G.conv_geom(N, 1, H, H, Ci, Co, (1, 3, 3), (1, 1, 1), (0, 1, 1))
     fused = L.lib().lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g), L.math_flag())
-    assert fused == (0 if math_mode == "bf16x3" else 1)
+    assert fused == (0 if math_mode != "f32" else 1)
     dw, db = G.conv_bwd_weight(g, _nhwc(x.detach()).to(dev), _nhwc(gy).to(dev), Ci, Co, want_bias=True)
     assert (db is None) == (fused == 0)
     assert rel_err(dw.squeeze(2), w.grad) < 5e-5
@@ -260,11 +260,11 @@ def test_transposed_conv_by_phases(Cin, Cout, N, math_mode):
     ref = (F.conv_transpose2d(x, w, b, stride=2, padding=1) + res) * (msrc > 0)
     dev = _dev()
     g = G.conv_geom(N, 1, 2 * H, 2 * H, Cout, Cin, (1, 4, 4), (1, 2, 2), (0, 1, 1))
-    assert G.bwd_data_by_phases(g) == (math_mode == "bf16x3")
+    assert G.bwd_data_by_phases(g) == (math_mode != "f32")
     args = dict(bias=b.to(dev), res=_nhwc(res).to(dev), mask=_nhwc(msrc).to(dev))
     y2 = G.conv_bwd_data(g, _nhwc(x).to(dev), G.pack_weight(g, w.to(dev), Cout, Cin), **args)
     assert rel_err(_nchw(y2), ref) < TOL
-    if math_mode == "bf16x3":
+    if math_mode != "f32":
         y1 = G.conv_bwd_data(g, _nhwc(x).to(dev), None, wph=G.pack_weight_phases(g, w.to(dev), Cout, Cin), **args)
         assert rel_err(_nchw(y1), ref) < TOL
         assert rel_err(y1, y2) < TOL
@@ -280,11 +280,11 @@ def test_strided_conv_by_parity_classes(Ci, Co, N, math_mode):
     ref = torch.relu(F.conv2d(x, w, b, stride=2, padding=1) + res)
     dev = _dev()
     g = G.conv_geom(N, 1, 32, 32, Ci, Co, (1, 4, 4), (1, 2, 2), (0, 1, 1))
-    assert G.fwd_by_parity(g) == (math_mode == "bf16x3")
+    assert G.fwd_by_parity(g) == (math_mode != "f32")
     args = dict(bias=b.to(dev), res=_nhwc(res).to(dev), flags=L.EPI_RELU)
     y2 = G.conv_fwd(g, _nhwc(x).to(dev), G.pack_weight(g, w.to(dev), Ci, Co), **args)
     assert rel_err(_nchw(y2), ref) < TOL
-    if math_mode == "bf16x3":
+    if math_mode != "f32":
         y1 = G.conv_fwd(g, _nhwc(x).to(dev), None, wq=G.pack_weight_parity(g, w.to(dev), Ci, Co), **args)
         assert rel_err(_nchw(y1), ref) < TOL
         assert rel_err(y1, y2) < TOL
@@ -304,7 +304,7 @@ def test_frame_resident_weight_gradient_stride2(Ci, N, math_mode):
     y.backward(gy)
     dev = _dev()
     g = G.conv_geom(N, 1, 32, 32, Ci, Co, (1, 4, 4), (1, 2, 2), (0, 1, 1))
-    assert L.lib().lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g), L.math_flag()) == (0 if math_mode == "bf16x3" else 1)
+    assert L.lib().lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g), L.math_flag()) == (0 if math_mode != "f32" else 1)
     dw = G.conv_bwd_weight(g, _nhwc(x.detach()).to(dev), _nhwc(gy).to(dev), Ci, Co)
     assert rel_err(dw.squeeze(2), w.grad) < 5e-5
 
@@ -332,34 +332,75 @@ def test_conv3d_causal_geometry():
 
 
 def test_math_modes_accuracy(math_mode):
-    """The split-bf16 mode is an fp32 computation: against an fp64 product its error (scaled by sum |a||b|, the
-    natural error unit of a dot product) must not exceed the plain fp32 MFMA path's by more than 25%, on normal,
-    all-positive, tiny and heavy-tailed operands; and both stay within 4 ulp-class bounds."""
+    """The split modes are fp32 computations: against an fp64 product their error (scaled by sum |a||b|, the natural error
+    unit of a dot product) must not exceed the plain fp32 MFMA path's by more than 25%, on normal, all-positive, tiny,
+    heavy-tailed and mixed-scale operands; and all stay within 4 ulp-class bounds.  f16x2 additionally meets operands whose
+    max |.| is an outlier 2^20 above everything else (the scale comes from the max) and a per-row scale ladder."""
     from lvt_amd.hip import gemm as G, binding as L
     if math_mode != "bf16x3":
         pytest.skip("comparison test, run once")
     d = _dev()
     g = torch.Generator().manual_seed(5)
+    ladder = torch.exp2(-torch.arange(384).float() / 16).view(-1, 1)           # rows from 1 down to 2^-24
+    outlier = torch.randn(384, 1024, generator=g)
+    outlier[7, 5] = 2.0 ** 20
     cases = {
         "normal": (torch.randn(384, 4096, generator=g), torch.randn(256, 4096, generator=g)),
         "positive": (torch.rand(384, 4096, generator=g), torch.rand(256, 4096, generator=g)),
         "tiny": (torch.randn(384, 1024, generator=g) * 1e-6, torch.randn(256, 1024, generator=g) * 1e-5),
+        "huge": (torch.randn(384, 1024, generator=g) * 1e12, torch.randn(256, 1024, generator=g) * 1e9),
         "heavy_tail": (torch.randn(384, 2048, generator=g) * torch.exp(3 * torch.randn(384, 2048, generator=g)),
                        torch.randn(256, 2048, generator=g) * torch.exp(3 * torch.randn(256, 2048, generator=g))),
+        "row_ladder": (torch.randn(384, 1024, generator=g) * ladder, torch.randn(256, 1024, generator=g)),
+        "outlier": (outlier, torch.randn(256, 1024, generator=g)),
     }
     for name, (a, b) in cases.items():
         ref = a.double() @ b.double().t()
         unit = a.double().abs() @ b.double().abs().t()
         err = {}
-        for mode in ("f32", "bf16x3"):
+        for mode in ("f32", "bf16x3", "f16x2"):
             L.set_math_mode(mode)
             out = torch.empty(a.shape[0], b.shape[0], device=d)
             G.gemm(a.to(d), b.to(d), out, a.shape[0], b.shape[0], a.shape[1])
             e = (out.double().cpu() - ref).abs() / unit
             err[mode] = (float(e.pow(2).mean().sqrt()), float(e.max()))
-        assert err["bf16x3"][0] <= 1.25 * err["f32"][0], (name, err)
-        assert err["bf16x3"][1] <= 1.5 * err["f32"][1] + 1e-7, (name, err)
-        assert err["bf16x3"][1] < 1e-5, (name, err)
+        for mode in ("bf16x3", "f16x2"):
+            assert err[mode][0] <= 1.25 * err["f32"][0], (name, mode, err)
+            assert err[mode][1] <= 1.5 * err["f32"][1] + 1e-7, (name, mode, err)
+            assert err[mode][1] < 1e-5, (name, mode, err)
+
+
+def test_f16x2_amax_bookkeeping(math_mode):
+    """f16x2 operand scales: an engine launch reports max |C| through c_amax (bit-exact), a stale record is not used after
+    an in-place torch op, a view inherits the bound of the tensor it was cut from, and a launch without operand scales is
+    refused by the library."""
+    import ctypes
+    from lvt_amd.hip import gemm as G, binding as L
+    if math_mode != "f16x2":
+        pytest.skip("f16x2 only")
+    d = _dev()
+    a, b = _rand(256, 512).to(d), _rand(128, 512, seed=1).to(d)
+    out = torch.empty(256, 128, device=d)
+    n0 = L.AMAX_FALLBACKS[0]
+    G.gemm(a, b, out, 256, 128, 512)
+    assert L.AMAX_FALLBACKS[0] == n0 + 2                       # a and b were scanned once ...
+    G.gemm(a, b, out, 256, 128, 512)
+    assert L.AMAX_FALLBACKS[0] == n0 + 2                       # ... and the records are reused
+    assert float(L.amax_of(out)) == float(out.abs().max())     # reported by the launch itself
+    assert L.AMAX_FALLBACKS[0] == n0 + 2
+    assert float(L.amax_of(out[3:7])) == float(out.abs().max())
+    a.mul_(4.0)                                                # torch in-place op: the record on `a` is stale now
+    G.gemm(a, b, out, 256, 128, 512)
+    assert L.AMAX_FALLBACKS[0] == n0 + 3
+    assert rel_err(out, (a.double().cpu() @ b.double().cpu().t()).float()) < TOL
+    L.bump_epoch()                                             # what the fused optimizers do after rewriting parameters
+    G.gemm(a, b, out, 256, 128, 512)
+    assert L.AMAX_FALLBACKS[0] == n0 + 5
+    desc = L.GemmDesc()
+    desc.M, desc.N, desc.K, desc.A, desc.lda, desc.B, desc.ldb, desc.C, desc.ldc = 256, 128, 512, a.data_ptr(), 512, b.data_ptr(), 512, out.data_ptr(), 128
+    desc.alpha, desc.flags, desc.batch_outer, desc.batch_inner, desc.splits = 1.0, L.MATH_F16X2, 1, 1, 1
+    assert L.lib().lvt_gemm_f32(ctypes.byref(desc), None, 0, L.stream_ptr()) != 0
+    assert b"a_amax" in L.lib().lvt_last_error()
 
 
 @pytest.mark.parametrize("M,N,K,tb", [(64, 512, 512, 0), (3, 512, 1024, 0), (33, 100, 136, 0), (64, 2048, 512, 0),
