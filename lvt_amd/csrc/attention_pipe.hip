@@ -343,31 +343,12 @@ __device__ __forceinline__ float attn_bwd_a16_body(const PlaneArgs pa, const uns
     load_item(0, g0);
     load_item(1, g1);
     bf16x8 dob[AT_D / 32][3];
-    float delta = 0.f;
     {
         const unsigned short *drow = dop + (row0 + i) * hd + h * AT_D;
-        const float *orow = o + (row0 + i) * hd + h * AT_D + 8 * kg;
 #pragma unroll
-        for (int s = 0; s < AT_D / 32; ++s) {
+        for (int s = 0; s < AT_D / 32; ++s)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) dob[s][pl] = *reinterpret_cast<const bf16x8 *>(drow + pl * pa.ps + 32 * s + 8 * kg);
-            const float4 o0 = *reinterpret_cast<const float4 *>(orow + 32 * s), o1 = *reinterpret_cast<const float4 *>(orow + 32 * s + 4);
-            const float ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
-            uint4 u[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) u[pl] = *reinterpret_cast<const uint4 *>(&dob[s][pl]);
-            const unsigned w[3][4] = {{u[0].x, u[0].y, u[0].z, u[0].w}, {u[1].x, u[1].y, u[1].z, u[1].w}, {u[2].x, u[2].y, u[2].z, u[2].w}};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float d = 0.f;
-#pragma unroll
-                for (int pl = 2; pl >= 0; --pl)
-                    d += (e & 1) ? __uint_as_float(w[pl][e >> 1] & 0xffff0000u) : __uint_as_float(w[pl][e >> 1] << 16);
-                delta = fmaf(d, ov[e], delta);
-            }
-        }
-        delta += __shfl_xor(delta, 16, 64);
-        delta += __shfl_xor(delta, 32, 64);
     }
     a16_park<0, A16_NG>(g0, X, tid);
     __syncthreads();
@@ -378,6 +359,18 @@ __device__ __forceinline__ float attn_bwd_a16_body(const PlaneArgs pa, const uns
     const float *prow = P + (((long long)b * H + h) * AT_S + i) * AT_S + 4 * kg;
     float *dsrow = dS + (((long long)b * H + h) * AT_S + i) * AT_S + 4 * kg;
     f32x4v pv[4];                          // P of a chunk: slot k is consumed by piece k during step c+1 and refilled right after
+    // delta_i = sum_j P_ij dP_ij, from THE dP values that dS is formed with: the row sums of dS then cancel the way the
+    // reference's softmax backward makes them cancel (P o (dP - sum_j P dP)).  (Round 3 took delta_i = sum_d dO_id O_id,
+    // the same number in exact arithmetic; its rounding error is a common offset of a whole row of dP - delta, i.e. an error
+    // of dS along P_i that adds up coherently in dQ / dK: 6x the CPU fp32 oracle's distance from fp64 on the w_q gradient
+    // of a near-uniform attention layer.)  dP of the whole row stays in registers; P is streamed twice (the second pass
+    // hits L2) and O is not read at all.
+    float delta = 0.f;
+    auto delta_piece = [&](auto cc, auto pc, const f32x4v p4) {
+        constexpr int T = 4 * decltype(cc)::value + decltype(pc)::value;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) delta = fmaf(p4[e], st[T][e], delta);
+    };
     auto ds_piece = [&](auto cc, auto pc, const f32x4v p4) {
         constexpr int T = 4 * decltype(cc)::value + decltype(pc)::value;
         f32x4v ds;
@@ -407,12 +400,23 @@ __device__ __forceinline__ float attn_bwd_a16_body(const PlaneArgs pa, const uns
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
                     st[4 * t + kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kt][AT_TA(tm)], dob[s][AT_TB(tm)], st[4 * t + kt], 0, 0, 0);
-            if constexpr (t > 0) ds_piece(IC<t - 1>{}, sc, pv[s]);
+            if constexpr (t > 0) delta_piece(IC<t - 1>{}, sc, pv[s]);
             pv[s] = *reinterpret_cast<const f32x4v *>(prow + 16 * (4 * t + s));
         });
         __syncthreads();
     });
+    static_for<4>([&](auto pc) { delta_piece(IC<NCH - 1>{}, pc, pv[decltype(pc)::value]); });
+    delta += __shfl_xor(delta, 16, 64);          // the four lanes (kg) that share query i hold 64 keys each
+    delta += __shfl_xor(delta, 32, 64);
+    // second pass over P: dS = P o (dP - delta) / temper.  The last chunk's P is still in pv and goes first; the other chunks
+    // are re-read (L2 hits), the four pieces of a chunk in flight together.
     static_for<4>([&](auto pc) { ds_piece(IC<NCH - 1>{}, pc, pv[decltype(pc)::value]); });
+    static_for<NCH - 1>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pv[s] = *reinterpret_cast<const f32x4v *>(prow + 16 * (4 * c + s));
+        static_for<4>([&](auto pc) { ds_piece(cc, pc, pv[decltype(pc)::value]); });
+    });
     if (NCH < AT_S / AT_KC) {
 #pragma unroll
         for (int T = 4 * NCH; T < AT_S / 16; ++T) *reinterpret_cast<f32x4v *>(dsrow + 16 * T) = f32x4v{0.f, 0.f, 0.f, 0.f};

@@ -22,6 +22,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -736,7 +737,7 @@ __device__ __forceinline__ void lvt_epilogue(const KParams &p, f32x16 (&acc)[BM 
         }
     }
     if (p.c_amax && p.splits <= 1) {
-        __shared__ float amax_scratch[NTHREADS / 64];
+        __shared__ float amax_scratch[8];
         lvt_block_amax_commit(am, p.c_amax, amax_scratch);
     }
 }
@@ -1297,6 +1298,214 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
     else lvt_epilogue_vec<A_PATCHT, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, phase, 0, 0, 0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide software-pipelined GEMM for the f16x2 arithmetic (round 4).  With three MFMAs per block instead of six the 128x128
+// kernel above is bound by what surrounds the matrix instructions: per k-tile a wave waits for its global loads, splits,
+// stores and passes two barriers before the next MFMA block can start (matrix pipe 39 % busy on the 16384 x 512 x 3072
+// product).  Here
+//   * one workgroup of 8 waves owns a 256 x 128 tile (wave = 64 x 64 as before): a third less staging per MFMA;
+//   * the two fp16 planes of both operands are DOUBLE-BUFFERED in LDS (2 x 61.5 KB, one workgroup per CU): the split and
+//     the stores of tile k+1 are independent of the MFMA block of tile k and share its issue window, and there is ONE
+//     barrier per k-tile;
+//   * the global loads of tile k+2 are issued as soon as the registers of tile k+1 have been split: a full iteration of
+//     latency cover.
+// Serves the plain forms (NT / NN / TN incl. 2-level k, batches, split-K with column sums); everything else and the other
+// arithmetic modes stay on lvt_gemm_kernel.
+// ------------------------------------------------------------------------------------------------
+#define WIDE_THREADS 512
+template <int TA, int TB>
+__global__ __launch_bounds__(WIDE_THREADS, 2) void lvt_gemm_wide_kernel(const KParams p) {
+    constexpr int BM = 256, BN = 128, WM = 4, WN = 2, TM = 2, TN = 2;
+    constexpr int AMODE = TA ? A_MPLAIN : A_KPLAIN;
+    constexpr int PSA = HPlane<BM>::SIZE, PSB = HPlane<BN>::SIZE;
+    constexpr int STAGE = 2 * (PSA + PSB);                                  // fp16 elements per buffer
+    constexpr int STAGE_FLOATS = (2 * STAGE) / 2 + 8;
+    constexpr int TURN_FLOATS = WM * WN * 32 * (TN * 32);
+    constexpr int LDS_FLOATS = STAGE_FLOATS > TURN_FLOATS ? STAGE_FLOATS : TURN_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    unsigned short *S0 = reinterpret_cast<unsigned short *>(lds);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const TileCtx tc = lvt_tile_ctx<AMODE, BM, BN>(p);
+    const int m0 = tc.m0, n0 = tc.n0, kbeg = tc.kbeg, kend = tc.kend;
+
+    int unscale = 0;
+    const float sa = lvt_f16_scale(p.a_amax, unscale), sb = lvt_f16_scale(p.b_amax, unscale);
+
+    // ---- operand fetch state.  k-contiguous: thread = (row r0 + 64 i, k quad kq); m-contiguous: thread = (4 k rows, 4 columns).
+    // The main loop carries NO bounds checks (one basic block: the split of tile k+1 and the loads of tile k+2 interleave
+    // with the MFMAs of tile k): rows / columns beyond M / N are fetched from a clamped, valid address -- they only feed
+    // output rows / columns that the epilogue does not store -- and the launcher sends K % 32 != 0 to lvt_gemm_kernel.
+    float4 av[4], bv[TB ? 4 : 2];
+    const int r0 = tid >> 3, kq = tid & 7;            // k-contiguous
+    const int kk0 = TA ? tid >> 6 : 0, mq = tid & 63; // A m-contiguous: 8 k groups x 64 m quads
+    const int bkk0 = (tid >> 5) & 7, bnq = tid & 31;  // B n-contiguous: 8 k groups x 32 n quads (threads 0..255)
+    const bool bact = !TB || tid < 256;
+    const float *arow[4];
+    const float *brow[2];
+    const float *akp = nullptr, *bkp = nullptr;
+    int a_kin = 0, b_kin = 0; long long a_kbase = 0, b_kbase = 0;
+    if (!TA) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) arow[i] = tc.A + (long long)min(m0 + r0 + 64 * i, p.M - 1) * p.lda;
+        const int kc = kbeg + kq * 4, blk = kc / p.a_kb;
+        a_kin = kc - blk * p.a_kb; a_kbase = (long long)blk * p.a_skb;
+    } else {
+        const int m = m0 + mq * 4;
+        akp = tc.A + (m < p.M ? m : 0) + (long long)(kbeg + kk0 * 4) * p.lda;
+    }
+    if (!TB) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) brow[i] = tc.B + (long long)min(n0 + r0 + 64 * i, p.N - 1) * p.ldb;
+        const int kc = kbeg + kq * 4, blk = kc / p.b_kb;
+        b_kin = kc - blk * p.b_kb; b_kbase = (long long)blk * p.b_skb;
+    } else {
+        const int n = n0 + bnq * 4;
+        bkp = tc.B + (n < p.N ? n : 0) + (long long)(kbeg + bkk0 * 4) * p.ldb;
+    }
+    const bool sum_on = TA && p.colsum_partial != nullptr && n0 == 0;
+    float4 colacc = zero4();
+    auto fetch = [&]() {
+        if (!TA) {
+            const long long koff = a_kbase + a_kin;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = ldg4(arow[i] + koff);
+            a_kin += BK;
+            const bool wrap = a_kin >= p.a_kb;              // (a_kb is a multiple of BK: at most one wrap per tile)
+            a_kin = wrap ? a_kin - p.a_kb : a_kin; a_kbase = wrap ? a_kbase + p.a_skb : a_kbase;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = ldg4(akp + (long long)i * p.lda);
+            akp += (long long)BK * p.lda;
+            if (sum_on) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { colacc.x += av[i].x; colacc.y += av[i].y; colacc.z += av[i].z; colacc.w += av[i].w; }
+            }
+        }
+        if (!TB) {
+            const long long koff = b_kbase + b_kin;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) bv[i] = ldg4(brow[i] + koff);
+            b_kin += BK;
+            const bool wrap = b_kin >= p.b_kb;
+            b_kin = wrap ? b_kin - p.b_kb : b_kin; b_kbase = wrap ? b_kbase + p.b_skb : b_kbase;
+        } else if (bact) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[i] = ldg4(bkp + (long long)i * p.ldb);
+            bkp += (long long)BK * p.ldb;
+        }
+    };
+    auto store = [&](unsigned short *buf) {
+        unsigned short *Ah = buf, *Bh = buf + 2 * PSA;
+        if (!TA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) store_split2_k<BM>(Ah, r0 + 64 * i, kq * 4, av[i], sa);
+        } else {
+            store_split2_block<BM>(Ah, mq * 4, kk0 * 4, av, sa);
+        }
+        if (!TB) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) store_split2_k<BN>(Bh, r0 + 64 * i, kq * 4, bv[i], sb);
+        } else if (bact) {
+            store_split2_block<BN>(Bh, bnq * 4, bkk0 * 4, bv, sb);
+        }
+    };
+
+    f32x16 acc[TM][TN], acx[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acx[i][j][r] = 0.f; }
+
+    int aoff[TM], boff[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) aoff[i] = hrow<BM>(wm * (TM * 32) + i * 32 + l31) + 8 * half;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) boff[j] = 2 * PSA + hrow<BN>(wn * (TN * 32) + j * 32 + l31) + 8 * half;
+
+    // one k-tile: the MFMA block on buffer `cur`; with STORE the registers (tile kt+1) are split into the other buffer, with
+    // FETCH the loads of tile kt+2 follow -- no dependence on the MFMAs, so the scheduler is free to interleave them
+    auto tile = [&](const unsigned short *cur, unsigned short *nxt, auto do_store, auto do_fetch) {
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 16) {
+            f16x8 a[2][TM], b[2][TN];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const f16x8 *>(cur + aoff[i] + q * PSA + ks);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const f16x8 *>(cur + boff[j] + q * PSB + ks);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1][j], acx[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0][j], acx[i][j], 0, 0, 0);
+            if (ks == 0) {
+                if constexpr (decltype(do_store)::value) store(nxt);
+                if constexpr (decltype(do_fetch)::value) fetch();
+            }
+        }
+    };
+    typedef std::integral_constant<bool, true> yes_t;
+    typedef std::integral_constant<bool, false> no_t;
+
+    const int ntiles = kbeg < kend ? (kend - kbeg) / BK : 0;
+    if (ntiles > 0) {
+        fetch();
+        store(S0);
+        if (ntiles > 1) fetch();
+    }
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 < ntiles; ++kt) {
+        tile(S0 + (kt & 1) * STAGE, S0 + ((kt + 1) & 1) * STAGE, yes_t(), yes_t());
+        __syncthreads();
+    }
+    if (kt + 1 < ntiles) {
+        tile(S0 + (kt & 1) * STAGE, S0 + ((kt + 1) & 1) * STAGE, yes_t(), no_t());
+        __syncthreads();
+        ++kt;
+    }
+    if (kt < ntiles) tile(S0 + (kt & 1) * STAGE, nullptr, no_t(), no_t());
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = ldexpf(fmaf(acx[i][j][r], 1.f / 2048.f, acc[i][j][r]), unscale);
+
+    if (TA && sum_on) {
+        // column sums of everything this workgroup fetched (bias gradient): lanes with the same m quad are added in kk0 order
+        float *scratch = lds;
+        *reinterpret_cast<float4 *>(&scratch[(kk0 * 64 + mq) * 4]) = colacc;
+        __syncthreads();
+        if (tid < BM) {
+            float s_ = 0.f;
+            for (int r = 0; r < 8; ++r) s_ += scratch[(r * 64 + tid / 4) * 4 + (tid & 3)];
+            if (m0 + tid < p.M) p.colsum_partial[((long long)tc.split * gridDim.y + tc.z) * p.M + m0 + tid] = s_;
+        }
+        __syncthreads();
+    }
+    if (p.vec_epi) lvt_epilogue_vec<AMODE, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, 0, tc.coff, tc.z, tc.split);
+    else lvt_epilogue<AMODE, BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, l31, half, 0, tc.coff, tc.z, tc.split);
+}
+
 // deterministic split-K reduction: out[i] (+)= sum_s partial[s][i]
 __global__ void lvt_reduce_splits_kernel(const float *__restrict__ partial, long long n4, long long stride,
                                          int splits, float *__restrict__ out, int accumulate) {
@@ -1528,6 +1737,11 @@ static int launch_tile(const KParams &p, int zcount, hipStream_t s) {
         }
         pv.vec_epi = ok ? 1 : 0;
     }
+    if ((p.flags & LVT_EPI_PLANES) && !pv.vec_epi) {
+        // only the float4 epilogue writes planes: the scalar one would store fp32 into the bf16 image
+        lvt_set_error("gemm: LVT_EPI_PLANES needs 16-byte aligned bias / res / mask and ldr, ldm %% 4 == 0");
+        return LVT_EINVAL;
+    }
     if (math_of(p.flags) == 2 && BK == 32)
         hipLaunchKernelGGL((lvt_gemm_kernel<AMODE, BMODE, BM, BN, WM, WN, 2>), grid, dim3(NTHREADS), 0, s, pv);
     else if (math_of(p.flags) == 1 && BK == 32)
@@ -1535,6 +1749,37 @@ static int launch_tile(const KParams &p, int zcount, hipStream_t s) {
     else
         hipLaunchKernelGGL((lvt_gemm_kernel<AMODE, BMODE, BM, BN, WM, WN, 0>), grid, dim3(NTHREADS), 0, s, pv);
     LVT_CHECK_LAUNCH("lvt_gemm_kernel");
+    return LVT_OK;
+}
+
+template <int TA, int TB>
+static int launch_wide(const KParams &p, int zcount, hipStream_t s) {
+    const long long ntm = lvt_cdiv(p.M, 256), ntn = lvt_cdiv(p.N, 128);
+    if (ntm * ntn > 0x7fffffffLL || zcount > 65535 || p.splits > 65535) {
+        lvt_set_error("gemm: grid too large (%lld tiles, z=%d, splits=%d)", ntm * ntn, zcount, p.splits);
+        return LVT_EINVAL;
+    }
+    dim3 grid((unsigned)(ntm * ntn), (unsigned)zcount, (unsigned)(p.splits > 1 ? p.splits : 1));
+    KParams pv = p;
+    {
+        auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
+        bool ok = p.N % 4 == 0;
+        if (p.splits > 1) ok = ok && al16(p.partial) && p.partial_stride % 4 == 0 && ((long long)p.M * p.N) % 4 == 0;
+        else {
+            ok = ok && al16(p.C) && p.ldc % 4 == 0 && p.sC_o % 4 == 0 && p.sC_i % 4 == 0;
+            if (p.flags & LVT_EPI_BIAS) ok = ok && al16(p.bias);
+            if (p.flags & LVT_EPI_RESIDUAL) ok = ok && al16(p.res) && p.ldr % 4 == 0;
+            if (p.flags & LVT_EPI_MASK) ok = ok && al16(p.mask) && p.ldm % 4 == 0;
+        }
+        pv.vec_epi = ok ? 1 : 0;
+    }
+    if ((p.flags & LVT_EPI_PLANES) && !pv.vec_epi) {
+        // only the float4 epilogue writes planes: the scalar one would store fp32 into the bf16 image
+        lvt_set_error("gemm: LVT_EPI_PLANES needs 16-byte aligned bias / res / mask and ldr, ldm %% 4 == 0");
+        return LVT_EINVAL;
+    }
+    hipLaunchKernelGGL((lvt_gemm_wide_kernel<TA, TB>), grid, dim3(WIDE_THREADS), 0, s, pv);
+    LVT_CHECK_LAUNCH("lvt_gemm_wide_kernel");
     return LVT_OK;
 }
 
@@ -1618,7 +1863,13 @@ extern "C" int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t work
         LVT_REQUIRE(!d->a_colsum, "gemm: a_colsum needs splits > 1");
     }
     int rc;
-    if (d->ta == 0 && d->tb == 0) rc = launch_tile<A_KPLAIN, B_KPLAIN, 128, 128, 2, 2>(p, zc, s);
+    static const int no_wide = getenv("LVT_NO_WIDE_GEMM") ? 1 : 0;
+    const bool wide = !no_wide && math_of(d->flags) == 2 && BK == 32 && d->M > 128 && d->K % BK == 0 && p.a_kb % BK == 0 &&
+                      p.b_kb % BK == 0 && !(d->flags & (LVT_CAUSAL_KMAX | LVT_CAUSAL_KMIN | LVT_CAUSAL_TILE));
+    if (wide && d->ta == 0 && d->tb == 0) rc = launch_wide<0, 0>(p, zc, s);
+    else if (wide && d->ta == 0 && d->tb == 1) rc = launch_wide<0, 1>(p, zc, s);
+    else if (wide) rc = launch_wide<1, 1>(p, zc, s);
+    else if (d->ta == 0 && d->tb == 0) rc = launch_tile<A_KPLAIN, B_KPLAIN, 128, 128, 2, 2>(p, zc, s);
     else if (d->ta == 0 && d->tb == 1) rc = launch_tile<A_KPLAIN, B_NPLAIN, 128, 128, 2, 2>(p, zc, s);
     else rc = launch_tile<A_MPLAIN, B_NPLAIN, 128, 128, 2, 2>(p, zc, s);
     if (rc != LVT_OK) return rc;

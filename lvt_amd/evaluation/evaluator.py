@@ -129,8 +129,10 @@ class BitsEvaluator(_SumEvaluator):
                 P = target[0].numel()
                 rows = tx.permute3(logits.contiguous().float().view(nc, nv, P), (nv * P, 1, P), (nc, P, nv)).view(nc * P, nv)
                 tgt = torch.where(keep, target, torch.full_like(target, -100)).reshape(1, nc * P).contiguous()
-                loss, _, count = tx.xent_fwd(rows, tgt[0], 0, 1, nc * P, -100, 1.0)      # mean over the kept rows
-                self._add(loss.double() * count.double().reshape(()), int(keep.sum()))
+                # the SUM over the kept rows (bits_evaluation.py:36-40), from the per-row terms in fp64: `mean * count` would be
+                # 0/0 = NaN for a sample whose positions are all ignored, and rounds the mean to fp32 first
+                _, _, _, row_loss = tx.xent_fwd(rows, tgt[0], 0, 1, nc * P, -100, 1.0, want_rows=True)
+                self._add(row_loss.double().sum(), int(keep.sum()))
             else:
                 ce = F.cross_entropy(logits.permute(1, 0, 2, 3, 4).unsqueeze(0), target.unsqueeze(0), reduction="none")[0]
                 self._add(ce[keep].sum(), int(keep.sum()))

@@ -171,16 +171,16 @@ def lib():
 # The library itself is stateless: every engine call carries its arithmetic in `flags`.  The default the Python wrappers
 # pass is a host-side setting of this module (LVT_MATH environment variable, or set_math_mode()).
 MATH_MODES = ("f32", "bf16x3", "f16x2")
-_math_mode = os.environ.get("LVT_MATH", "bf16x3")
+_math_mode = os.environ.get("LVT_MATH", "f16x2")
 if _math_mode not in MATH_MODES:
     raise LvtError("LVT_MATH must be one of %s (got %r)" % (MATH_MODES, _math_mode))
 
 
 def set_math_mode(mode):
     """What the wrappers of lvt_amd.hip put into the `flags` of the engine calls they issue from now on:
-    'bf16x3' (default) exact 3-way bf16 split of the fp32 operands, six bf16 MFMAs per block;
-    'f16x2'  2-way fp16 split after an exact power-of-two scale from the operand's max |.|, three fp16 MFMAs per block
-             (the wrappers carry the max |.| of every engine operand along: `amax_of`, `new_amax`);
+    'f16x2'  (default since round 4) 2-way fp16 split after an exact power-of-two scale from the operand's max |.|, three
+             fp16 MFMAs per block (the wrappers carry the max |.| of every engine operand along: `amax_of`, `new_amax`);
+    'bf16x3' exact 3-way bf16 split of the fp32 operands, six bf16 MFMAs per block (the default of rounds 1-3);
     'f32'    plain fp32 MFMA.  All three are fp32 in / fp32 out with fp32 accumulation."""
     global _math_mode
     if mode not in MATH_MODES:
@@ -410,6 +410,8 @@ class KernelTimer:
 
 
 TIMER = None     # set to a KernelTimer() to time every engine launch
+RELU_TRACE = None   # diagnostic (tests/util_relu.py): a list that receives, in execution order, the bool mask (y > 0) of every
+                    # ReLU of the transformer path (FFN hidden of each attention layer, U_k of the channel predictor)
 
 
 _ws = {}

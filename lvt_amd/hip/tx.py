@@ -152,8 +152,10 @@ def permute3(x, strides, shape):
     return out
 
 
-def xent_fwd(logits, target, tstride_b, tstride_pos, P, ignore, scale):
-    """logits (rows, V); target is a view INTO an int64 tensor (its data_ptr is the (b=0,pos=0) element)."""
+def xent_fwd(logits, target, tstride_b, tstride_pos, P, ignore, scale, want_rows=False):
+    """logits (rows, V); target is a view INTO an int64 tensor (its data_ptr is the (b=0,pos=0) element).
+    -> (loss, lse, count) or, with want_rows, (loss, lse, count, row_loss): row_loss[r] = lse - logit[target], 0 where the
+    target is the ignore index (the un-normalised terms of the mean)."""
     L.require(logits)
     rows, V = logits.shape
     dev = logits.device
@@ -167,6 +169,8 @@ def xent_fwd(logits, target, tstride_b, tstride_pos, P, ignore, scale):
     L.check(lib.lvt_xent_fwd(L.ptr(logits), C.c_void_p(target.data_ptr()), tstride_b, tstride_pos, P, rows, V, ignore,
                              scale, L.ptr(row_loss), L.ptr(lse), L.ptr(loss), L.ptr(count), L.ptr(ws), nws,
                              L.stream_ptr()), "lvt_xent_fwd")
+    if want_rows:
+        return loss.view(()), lse, count, row_loss
     return loss.view(()), lse, count
 
 

@@ -15,6 +15,14 @@ def all_reduce_sum_(t, group=None):
     return t
 
 
+def all_reduce_sum_async_(t, group=None):
+    """Start the in-place sum over ranks and return a handle whose .wait() orders the CURRENT stream behind it (RCCL runs
+    the collective on its own stream, behind everything already enqueued on the current one); None when not distributed."""
+    if comm.get_world_size() > 1:
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return None
+
+
 class AllReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input):

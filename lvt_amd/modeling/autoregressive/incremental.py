@@ -223,13 +223,17 @@ class GraphedSliceSampler:
     def _body(self, sample):
         dec = self.dec
         y = dec.step_at_cursor()
-        drawn = self.vt.ch_predictor.sample_from_rows(y, self.temp, uniforms=self.uniforms, pos=dec.pos).reshape(-1) if sample else None     # (b*nc,)
+        drawn = self.vt.ch_predictor.sample_from_rows(y, self.temp, uniforms=self.uniforms, pos=dec.pos,
+                                                      split_ws=dec._split_ws).reshape(-1) if sample else None     # (b*nc,)
         tx.decode_commit(dec.sl_ext.view(dec.b * dec.nc, dec.S + 1), dec.pos, drawn)
 
     def step(self, pos, sample):
         """Decode position `pos` (must be the next one: positions of a slice are visited in order)."""
         if pos != self._next:
             raise L.LvtError("GraphedSliceSampler.step(%d): the device cursor is at %d" % (pos, self._next))
+        if pos >= self.dec.S:
+            raise L.LvtError("GraphedSliceSampler.step(%d): the slice has %d positions (a replay past the end would address "
+                             "beyond the caches)" % (pos, self.dec.S))
         self._next += 1
         g = self.graphs.get(bool(sample))
         if g is not None:

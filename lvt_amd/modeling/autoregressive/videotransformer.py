@@ -273,6 +273,8 @@ class _ChannelPredictorFn(torch.autograd.Function):
             u = torch.empty(rows, d, dtype=torch.float32, device=yl.device)
             G.gemm(y, uw, u, rows, d, d, ldb=fin, flags=L.EPI_BIAS | L.EPI_RELU | (L.EPI_RESIDUAL if k else 0),
                    bias=ub, res=res)
+            if L.RELU_TRACE is not None:
+                L.RELU_TRACE.append(u > 0)
             o = torch.empty(rows, pw.shape[0], dtype=torch.float32, device=yl.device)
             G.gemm(u, pw, o, rows, pw.shape[0], d, flags=L.EPI_BIAS, bias=pb)
             us.append(u)
@@ -362,7 +364,7 @@ class ChannelPredictor(nn.Module):
         for k in range(1, self.nc):
             self._ut[k].copy_(self.U[k].weight.detach()[:, d:d + k * self.nv].t())
 
-    def sample_from_rows(self, rows, temp=1.0, forced_codes=None, return_probs=False, uniforms=None, pos=None):
+    def sample_from_rows(self, rows, temp=1.0, forced_codes=None, return_probs=False, uniforms=None, pos=None, split_ws=None):
         """rows (b, d): decoder hidden state of ONE position per sample -> codes (b, nc).
         `uniforms` (P, nc, b) with the int32 device cursor `pos`: the draws of position pos[0] come from uniforms[pos[0]]
         (a table filled once per slice: the decode graphs contain no random-number generator)."""
@@ -382,10 +384,12 @@ class ChannelPredictor(nn.Module):
                 ut = cached[k] if cached is not None else _permute_cols(uw, d, k * self.nv)
                 res = tx.embbag_fwd(codes, self.nc, 1, b, list(range(k)), [c * self.nv for c in range(k)], ut, d)
             u_ = torch.empty(b, d, dtype=torch.float32, device=y.device)
+            # `split_ws`: the caller's split-K scratch (d >= 1024 takes the split-K form, whose default workspace must not be
+            # recorded into a hipGraph: incremental.GraphedSliceSampler passes the decoder's own)
             G.gemm_small(y, uw, u_, b, d, d, ldb=uw.shape[1], flags=L.EPI_BIAS | L.EPI_RELU | (L.EPI_RESIDUAL if k else 0),
-                         bias=self.U[k].bias, res=res)
+                         bias=self.U[k].bias, res=res, split_ws=split_ws)
             o = torch.empty(b, self.nv, dtype=torch.float32, device=y.device)
-            G.gemm_small(u_, pw, o, b, self.nv, d, flags=L.EPI_BIAS, bias=self.P[k].bias)
+            G.gemm_small(u_, pw, o, b, self.nv, d, flags=L.EPI_BIAS, bias=self.P[k].bias, split_ws=split_ws)
             if forced_codes is None:
                 # writes codes[:, k, 0] (element stride nc between samples)
                 if uniforms is not None:

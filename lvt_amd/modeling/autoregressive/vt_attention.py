@@ -213,6 +213,8 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         fn, mean2, rstd2 = ew.layernorm_fwd(y1, f0w, f0b)
         h1 = torch.empty(M, f1w.shape[0], dtype=torch.float32, device=dev)
         G.gemm(fn, f1w, h1, M, f1w.shape[0], d, flags=L.EPI_BIAS | L.EPI_RELU, bias=f1b)
+        if L.RELU_TRACE is not None:
+            L.RELU_TRACE.append(h1 > 0)
         y2 = torch.empty(M, d, dtype=torch.float32, device=dev)
         G.gemm(h1, f3w, y2, M, d, f3w.shape[1], flags=L.EPI_BIAS | L.EPI_RESIDUAL, bias=f3b, res=y1)
         ctx.save_for_backward(x, mean1, rstd1, xn, qkv, P, o, y1, mean2, rstd2, fn, h1,

@@ -73,8 +73,11 @@ class VQVAEModel(AutoEncoderModel):
 
     def _supervised_loss_cl(self, x, return_x=False):
         z_e = self.encoder.forward_cl(x)
-        z_q_st, z_q_bar = self.codebook.straight_through_cl(z_e)
+        # the decoder needs z_q_st only (pre-update codebook): the all-reduce of the EMA statistics that the quantiser
+        # started runs beside the decoder forward and is joined afterwards (reference order of updates: vq_embedding.py:46-59)
+        z_q_st = self.codebook.straight_through_cl(z_e, defer=True)
         x_tilde = self.generator.forward_cl(z_q_st)
+        z_q_bar = self.codebook.finish_ema()
         c = len(self.cfg.MODEL.PIXEL_MEAN)
         loss = {
             "loss_reconstruction": self.pixel_loss(x_tilde, x, denom=x.numel() // x.shape[-1] * c),

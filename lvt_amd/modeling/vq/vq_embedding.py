@@ -10,13 +10,17 @@ Deliberate, documented deviations:
     aliases the codebook; on a GPU `.to(device)` de-aliases.  GPU semantics are kept.
   * multi-GPU EMA statistics are summed with ONE all-reduce of a packed (num, K, D+1) buffer instead of
     2*num all_gather+sum round trips (vq_embedding.py:46-47, 53-54); the sum is the same.
+  * that all-reduce is OFF the critical path: the decoder only needs z_q_st, which comes from the pre-update codebook, so
+    `straight_through_cl(z, defer=True)` starts the collective asynchronously right after the statistics kernel and returns;
+    `finish_ema()` joins it, applies the EMA update and gathers z_q_bar for the commitment loss -- after the decoder forward
+    has been enqueued (meta_arch/vqvae.py).  Same arithmetic, same order of updates as the reference (vq_embedding.py:46-59).
 """
 import torch
 from torch import nn
 
 from ...hip import binding as L
 from ...hip import ew, vq
-from ...layers import all_reduce_sum_
+from ...layers.all_reduce import all_reduce_sum_async_
 from .. import convstack
 
 
@@ -35,23 +39,24 @@ class VQEmbedding(nn.Module):
 
 
 class _StraightThroughFn(torch.autograd.Function):
-    """vq_st + EMA + z_q_bar gather as one autograd node (vq_utils.py:34-65, vq_embedding.py:35-66)."""
+    """vq_st as an autograd node (vq_utils.py:34-65): nearest code + gather from the PRE-update codebook; with EMA the
+    assignment statistics are accumulated and their all-reduce is STARTED here (joined by DVQEmbedding.finish_ema)."""
 
     @staticmethod
     def forward(ctx, z2d, owner, P):
         w, rsize, rsum = owner._flat()
         idx = vq.nearest(z2d, w, P)
         z_q_st = vq.gather(idx, w)                       # from the PRE-update codebook
+        stats = work = None
         if owner.ema:
             stats = vq.ema_accumulate(idx, z2d, owner.K)
-            all_reduce_sum_(stats)
-            vq.ema_finalize(stats, rsize, rsum, w, owner.decay, owner.eps)
-        z_q_bar = vq.gather(idx, w)                      # from the POST-update codebook
-        ctx.mark_non_differentiable(z_q_bar, idx)
-        return z_q_st, z_q_bar, idx
+            work = all_reduce_sum_async_(stats)
+        owner._pending = (idx, stats, work)
+        ctx.mark_non_differentiable(idx)
+        return z_q_st, idx
 
     @staticmethod
-    def backward(ctx, g_st, g_bar, g_idx):
+    def backward(ctx, g_st, g_idx):
         return g_st, None, None                          # straight-through (vq_utils.py:52-54)
 
 
@@ -98,13 +103,34 @@ class DVQEmbedding(nn.Module):
         idx = vq.nearest(z_cl.view(n * h * w, d), self._flat()[0], h * w)
         return idx.view(n, self.num, h, w)
 
-    def straight_through_cl(self, z_cl):
-        """(N,1,H,W,D) -> (z_q_st, z_q_bar) channels-last; updates the EMA state (vq_embedding.py:35-66)."""
+    def straight_through_cl(self, z_cl, defer=False):
+        """(N,1,H,W,D) -> (z_q_st, z_q_bar) channels-last; updates the EMA state (vq_embedding.py:35-66).
+        defer=True returns z_q_st only and leaves the EMA update + z_q_bar to `finish_ema()`: the statistics all-reduce of a
+        data-parallel run then overlaps whatever the caller enqueues in between (the decoder forward)."""
         n, _, h, w, d = z_cl.shape
         L.require(z_cl)
-        z_q_st, z_q_bar, idx = _StraightThroughFn.apply(z_cl.view(n * h * w, d), self, h * w)
+        if getattr(self, "_pending", None) is not None:
+            raise L.LvtError("DVQEmbedding: the EMA update of the previous pass was never finished (finish_ema)")
+        z_q_st, idx = _StraightThroughFn.apply(z_cl.view(n * h * w, d), self, h * w)
         self.last_indices = idx.view(n, self.num, h, w)      # kept for evaluators / tests
-        return z_q_st.view(n, 1, h, w, d), z_q_bar.view(n, 1, h, w, d)
+        self._pending_shape = (n, 1, h, w, d)
+        z_q_st = z_q_st.view(n, 1, h, w, d)
+        return z_q_st if defer else (z_q_st, self.finish_ema())
+
+    def finish_ema(self):
+        """Join the statistics all-reduce, apply the EMA update (vq_embedding.py:48-59) and return z_q_bar, the codes of this
+        pass gathered from the UPDATED codebook (channels-last)."""
+        pend = getattr(self, "_pending", None)
+        if pend is None:
+            raise L.LvtError("DVQEmbedding.finish_ema without a pending straight_through_cl")
+        idx, stats, work = pend
+        self._pending = None
+        w, rsize, rsum = self._flat()
+        if stats is not None:
+            if work is not None:
+                work.wait()
+            vq.ema_finalize(stats, rsize, rsum, w, self.decay, self.eps)
+        return vq.gather(idx, w).view(*self._pending_shape)      # from the POST-update codebook
 
     def embed_cl(self, latents):
         """(N,num,H,W) int64 -> (N,1,H,W,D) channels-last."""

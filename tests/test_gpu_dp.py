@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _vq_worker(rank, world, port, ret):
+def _vq_worker(rank, world, port, ret, backend="gloo"):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")):
@@ -34,12 +34,13 @@ def _vq_worker(rank, world, port, ret):
     from lvt_amd.utils.events import EventStorage
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = rank if backend == "nccl" else 0               # RCCL: one GPU per rank; gloo: both ranks share cuda:0
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
-        model, _, _, _ = vqvae_seeded(50 + rank, scale=0.05 * (1 + rank))      # ranks start different
+        model, _, _, _ = vqvae_seeded(50 + rank, scale=0.05 * (1 + rank), device="cuda:%d" % dev)      # ranks start different
         model.train()
-        model.wrap_parallel(device_ids=[0], broadcast_buffers=False)
+        model.wrap_parallel(device_ids=[dev], broadcast_buffers=False)
         x = seeded.seeded_input("dp", (8, 3, 64, 64), 9)[4 * rank:4 * rank + 4]
         with EventStorage(0):
             losses = model([{"image": x[i].numpy()} for i in range(4)], mode="supervised")
@@ -57,13 +58,19 @@ def _vq_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_vqvae_two_ranks_equal_one_big_batch():
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_vqvae_two_ranks_equal_one_big_batch(backend):
+    """backend "nccl": two REAL RCCL ranks on two GPUs -- gradient buckets averaged with ReduceOp.AVG on the side stream, the
+    EMA-statistics all-reduce started asynchronously behind the quantiser and joined after the decoder forward, parameter
+    and codebook broadcast -- collected everywhere, skipped on boxes with a single GPU (the first multi-GPU box runs it)."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs for two RCCL ranks (this box has %d)" % torch.cuda.device_count())
     from util_models import vqvae_seeded
     from lvt_amd.utils.events import EventStorage
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_vq_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_vq_worker, args=(r, 2, port, ret, backend)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

@@ -40,7 +40,12 @@ def test_train_net_vqvae_then_dsfvt(tmp_path):
     # --eval-only inference path of the VQ-VAE from the checkpoints just written
     log = _run(["tools/train_net.py", "--config-file", "configs/vqvae/PR-DVQVAE2.yaml", "--synthetic", "--eval-only",
                 "OUTPUT_DIR", out, "SOLVER.IMS_PER_BATCH", "4", "MODEL.ENCODER.WEIGHTS", os.path.join(out, "netE", "model_final.pth")])
-    assert "inference OK" in log
+    assert "evaluation results" in log and "MSE" in log
+    assert os.path.isdir(os.path.join(out, "inference"))                   # CodesExtractor wrote the latent clips
+    # ... and of the transformer: BitsEvaluator through build_evaluator / inference_on_dataset (reference tools/train_net.py:35-57,76-86)
+    log = _run(["tools/train_net.py", "--config-file", "configs/vt/DSFVT.yaml", "--synthetic", "--eval-only", "--eval-batches", "1",
+                "OUTPUT_DIR", out2, "SOLVER.IMS_PER_BATCH", "2", "MODEL.GENERATOR.WEIGHTS", os.path.join(out2, "netG", "model_final.pth")])
+    assert "bits_per_dim" in log
 
 
 def test_generate_videos_on_example_frames(tmp_path, golden):

@@ -156,28 +156,23 @@ def test_g5_supervised_loss_and_grads(golden, tag):
     # The HIP path must be as close to fp64 as the CPU fp32 path is (x4 slack): the differences between
     # two fp32 evaluations of this deep chain are roundoff amplified by cancellation (z_e - z_q) and by
     # ReLU units sitting within an ulp of their threshold, not a fixed relative number.
-    if flips:
-        g32, aux = oracle_grads(torch.float32, mine)
     g64, _ = oracle_grads(torch.float64, mine)
-    worst = 0.0
-    for n, ref in g64.items():
-        got = (G[n[2:]] if n.startswith("G.") else E[n]).grad
-        e_mine, e_cpu = rel_err(got, ref), rel_err(g32[n], ref)
-        worst = max(worst, e_mine)
-        l2_mine = float((got.double().cpu() - ref).norm() / ref.norm())
-        if tag == "frames":
+    got = {n: (G[n[2:]] if n.startswith("G.") else E[n]).grad for n in g64}
+    if tag == "frames":
+        for n, ref in g64.items():
+            e_mine, e_cpu = rel_err(got[n], ref), rel_err(g32[n], ref)
+            l2_mine = float((got[n].double().cpu() - ref).norm() / ref.norm())
             # THE accuracy pin, no fallback: measured 1e-6 .. 2.3e-6 on all 28 tensors in every kernel configuration
-            # (frame-resident / implicit-GEMM convolutions, bf16x3 / f32 products); the CPU fp32 oracle is at 2e-7 .. 7e-7
+            # (frame-resident / implicit-GEMM convolutions, all three arithmetic modes); the CPU fp32 oracle is at 2e-7 .. 7e-7
             assert e_mine < 1e-5 and l2_mine < 1e-5, (n, e_mine, l2_mine, e_cpu)
-        else:
-            # 16 frames = 4 M ReLU units per forward: about one of them sits within an ulp of zero and resolves
-            # differently in two fp32 evaluations, which moves that token's gradient by ~1 % -- measured on MI355X: l2
-            # 1e-4 .. 3e-4 and up to 1.2e-3 of the largest element of ONE resblock weight gradient, in all three kernel
-            # configurations alike; the CPU fp32 oracle showed 9e-4 (l2) on the round-1 clip input.  A systematic error
-            # would show in the 2-frame fixture above, which has no such unit.
-            # Allowance: one such unit (1e-3 in l2) on top of 4x the CPU fp32 oracle's own distance from fp64 on this tensor.
-            l2_cpu = float((g32[n].double() - ref).norm() / ref.norm())
-            assert e_mine < 5e-3 and l2_mine < 1e-3 + 4 * l2_cpu, (n, e_mine, l2_mine, e_cpu, l2_cpu)
+    else:
+        # 16 frames = 4 M ReLU units per forward: about one of them sits within fp32 round-off of zero and resolves
+        # differently in two fp32 evaluations, which moves that token's gradient by ~1 %.  No wider tolerance for that: the
+        # undecided units are identified from an fp64 run, the side this path put them on is determined, and all 28 tensors
+        # are held to max(4 x the CPU fp32 oracle's distance from fp64, 2e-5) against the fp64 run that decides the same way
+        # (tests/util_relu.py).
+        from util_relu import assert_grads_match
+        assert_grads_match(got, lambda dtype: oracle_grads(dtype, mine)[0], sorted(g64))
     # ---- and against the golden vectors captured from the reference (same indices only) ---------------
     for got, key in ((E["layers.0.weight"], "grad_enc_first"), (E["layers.0.bias"], "grad_enc_first_bias"),
                      (E["layers.6.block.3.weight"], "grad_enc_last"), (G["layers.6.weight"], "grad_dec_last"),
@@ -208,15 +203,20 @@ def test_g6_inference_on_example_frames(golden):
     # end-to-end indices: the conv stack's fp32 summation order differs from oneDNN's, so only rows
     # with a margin larger than that perturbation are required to be identical.
     z = g["z_e"]
-    n_flip = 0
+    keep = torch.ones(5, 64, 64, dtype=torch.bool)
     for i in range(4):
         rows = z[:, 64 * i:64 * (i + 1)].permute(0, 2, 3, 1).reshape(-1, 64)
         ok = margin_ok(rows, st0["ve.%d.embedding.weight" % i], rel=1e-4).view(5, 16, 16)
+        # every code that differs from the reference's sits on a row whose two best codes are closer than the perturbation
         assert torch.equal(lat[:, i][ok], g["latent"][:, i][ok]), i
-        n_flip += int((lat[:, i] != g["latent"][:, i]).sum())
-    assert n_flip <= 2, n_flip
-    if n_flip == 0:
-        assert rel_err(rec, g["reconstruction"]) < ATOL
+        for t, y, x in (lat[:, i] != g["latent"][:, i]).nonzero().tolist():
+            # a differing code reaches the pixels of its decoder receptive field (3x3 conv + two 3x3 resblocks at latent
+            # resolution, two 4x4 / stride 2 transposed convs): a window of +-4 latent positions covers it with margin
+            keep[t, max(0, 4 * (y - 4)):4 * (y + 5), max(0, 4 * (x - 4)):4 * (x + 5)] = False
+    # the reconstruction is compared ALWAYS: everywhere outside the receptive fields of sub-margin code differences
+    assert float(keep.float().mean()) > 0.8
+    k3 = keep[:, None].expand_as(rec)
+    assert float((rec - g["reconstruction"]).abs()[k3].max() / g["reconstruction"].abs().max()) < ATOL
     # decode() contract used by generate_videos.py: (T,num,h,w) codes -> (T,3,H,W)
     with torch.no_grad():
         xt = model.decode(g["latent"].to(DEV))

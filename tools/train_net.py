@@ -27,6 +27,7 @@ from lvt_amd.data import DatasetMapper  # noqa: E402
 from lvt_amd.data.latents import list_latent_videos, load_video_codes  # noqa: E402
 from lvt_amd.data.samplers import TrainingSampler  # noqa: E402
 from lvt_amd.engine.trainer import Trainer  # noqa: E402
+from lvt_amd.evaluation import build_evaluator, inference_on_dataset  # noqa: E402
 from lvt_amd.modeling import build_model  # noqa: E402
 from lvt_amd.utils import comm  # noqa: E402
 
@@ -43,6 +44,7 @@ def default_argument_parser():
     p.add_argument("--data-dir", default="")
     p.add_argument("--synthetic", action="store_true")
     p.add_argument("--max-iter", type=int, default=None)
+    p.add_argument("--eval-batches", type=int, default=4, help="--eval-only: batches of the test loader per rank")
     p.add_argument("opts", default=None, nargs=argparse.REMAINDER)
     return p
 
@@ -103,24 +105,58 @@ def data_iterator(cfg, args):
             yield [{key: np.asarray(frames[next(it)], dtype=np.float32)} for _ in range(per_rank)]
 
 
+def test_batches(cfg, args):
+    """Finite test loader of --eval-only: `--eval-batches` batches of IMS_PER_BATCH / world samples per rank, in order (the
+    reference's InferenceSampler shards the dataset the same way), unmapped for the transformer apart from the frame
+    window (DatasetMapper(is_train=False): whole code clips, vidgen/data/dataset_mapper.py:113-149)."""
+    world, rank = comm.get_world_size(), comm.get_rank()
+    per_rank = max(1, cfg.SOLVER.IMS_PER_BATCH // world)
+    seed = cfg.SEED if cfg.SEED >= 0 else 0
+    if cfg.MODEL.META_ARCHITECTURE == "VideoTransformerModel":
+        mapper = DatasetMapper(cfg, False)
+        if args.synthetic or not args.data_dir:
+            v = cfg.MODEL.AUTOREGRESSIVE.VT
+            rng = np.random.default_rng(seed)
+            videos = [rng.integers(0, v.NV, (16, v.NC, 16, 16), dtype=np.int64) for _ in range(world * per_rank * args.eval_batches)]
+            load = lambda i: videos[i]                     # noqa: E731
+            n = len(videos)
+        else:
+            vids = list_latent_videos(args.data_dir)
+            load = lambda i: load_video_codes(vids[i][0], vids[i][1])      # noqa: E731
+            n = len(vids)
+        idx = list(range(rank, n, world))[:per_rank * args.eval_batches]
+        for b in range(0, len(idx), per_rank):
+            batch = [mapper({"image_sequence": load(i), "video_idx": i}) for i in idx[b:b + per_rank]]
+            batch = [d for d in batch if d is not None]
+            if batch:
+                yield batch
+    else:
+        if args.synthetic or not args.data_dir:
+            frames = np.random.default_rng(seed).random((world * per_rank * args.eval_batches, 3, 64, 64), dtype=np.float32)
+        else:
+            frames = np.load(args.data_dir, mmap_mode="r")
+        key = "image_sequence" if frames.ndim == 5 else "image"
+        idx = list(range(rank, len(frames), world))[:per_rank * args.eval_batches]
+        for b in range(0, len(idx), per_rank):
+            yield [{key: np.asarray(frames[i], dtype=np.float32), "video_idx": i} for i in idx[b:b + per_rank]]
+
+
 def main(args):
     logging.basicConfig(level=logging.INFO if comm.is_main_process() else logging.WARNING,
                         format="[%(asctime)s] %(name)s %(levelname)s: %(message)s")
     cfg = setup(args)
     model = build_model(cfg)
     if args.eval_only:
+        # the reference's `MyTrainer.test` (tools/train_net.py:35-57,76-86): load the checkpoints, run the test loader through
+        # the model in inference mode and hand (inputs, outputs) to the evaluators cfg.TEST.EVALUATORS names
         _, checkpointers = model.configure_optimizers_and_checkpointers()
         for item in checkpointers:
             item["checkpointer"].resume_or_load(item["pretrained"], resume=False)
-        model.eval()
-        batch = next(data_iterator(cfg, args))
-        if cfg.MODEL.META_ARCHITECTURE == "VideoTransformerModel":
-            raise SystemExit("--eval-only for the transformer needs the reference's evaluators (out of scope); "
-                             "use VideoTransformerModel.calculate_logits_for_entire_video / sample_videos directly")
-        with torch.no_grad():
-            out = model(batch, mode="inference")
-        logging.getLogger("lvt_amd").info("inference OK: %d outputs, latent %s", len(out), tuple(out[0]["latent"].shape))
-        return out
+        evaluator = build_evaluator(cfg, cfg.DATASETS.TEST[0] if len(cfg.DATASETS.TEST) else "test")
+        res = inference_on_dataset(model, test_batches(cfg, args), evaluator)
+        if comm.is_main_process():
+            logging.getLogger("lvt_amd").info("evaluation results: %s", dict(res))
+        return res
     trainer = Trainer(cfg, model, data_iterator(cfg, args))
     trainer.resume_or_load(resume=args.resume)
     return trainer.train(args.max_iter)
