@@ -120,6 +120,8 @@ typedef struct {
     float *a_colsum;
     long long c_plane;                  /* LVT_EPI_PLANES: distance between the bf16 planes of C (elements)                 */
     const float *a_amax, *b_amax;       /* LVT_MATH_F16X2: device scalars >= max |A|, max |B| (required in that mode)        */
+    const float *a_amax2, *b_amax2;     /* optional second bounds: the operand scale comes from max(*x_amax, *x_amax2) -- for
+                                         * operands that span two tensors (batch strides = address differences)           */
     float *c_amax;                      /* optional, any mode: max |C| is folded into *c_amax (see lvt_amax_io)              */
 } lvt_gemm_desc;
 size_t lvt_gemm_workspace_bytes(const lvt_gemm_desc *d);
@@ -281,8 +283,11 @@ int lvt_add_periodic(float *x, const float *table, long long rows, int P, int d,
 
 /* ---- LayerNorm over the last dim, eps inside the sqrt (F.layer_norm; K19) ---------------------------*/
 int lvt_layernorm_fwd(const float *x, long long rows, int d, float eps, const float *w, const float *b,
-                      float *y, float *mean, float *rstd, float *y_amax, void *stream);
-/* (y_amax / dx_amax, nullable: max |y| resp. max |dx| folded into a device scalar as lvt_amax_io.c is.)                  */
+                      float *y, float *mean, float *rstd, float *y_amax, const float *w_amax, const float *b_amax,
+                      void *stream);
+/* (y_amax / dx_amax, nullable: max |y| resp. max |dx| folded into a device scalar as lvt_amax_io.c is.  With w_amax and
+ *  b_amax -- device scalars >= max |w|, max |b| -- the forward STORES the bound max |w| sqrt(d - 1) + max |b| into *y_amax
+ *  instead of reducing: |(x - mean) rstd| <= sqrt(d - 1) on every row.)                                                   */
 size_t lvt_layernorm_bwd_workspace_bytes(int d);
 /* dx = LN'(dy) (+ add); dw[d], db[d] reduced in a fixed order                                        */
 int lvt_layernorm_bwd(const float *dy, const float *x, const float *mean, const float *rstd,

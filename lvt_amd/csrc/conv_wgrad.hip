@@ -63,25 +63,29 @@ __device__ __forceinline__ void wg_split4(const float4 v, uint2 &p1, uint2 &p2, 
 // lo then resolves down to 2^-24: all 22 + sign bits for the elements within 2^-16 of the operand's max, fewer below
 // (absolute error <= 2^-40 max |a| per element: invisible in a reduction over 131072 pixels of mixed magnitudes).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ unsigned wg_f16_pair(float a, float b, float s) {
-    unsigned r;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0\n\tv_fma_mixhi_f16 %0, %3, %2, 0" : "=&v"(r) : "v"(a), "v"(s), "v"(b));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float wg_mix_lo(unsigned h, float c) {                  // c - half(h.lo), one rounding (exact here)
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(c));
     return r;
 }
-__device__ __forceinline__ float wg_resid_lo(float a, float s, unsigned h) {
+__device__ __forceinline__ float wg_mix_hi(unsigned h, float c) {
     float r;
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(s), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(c));
     return r;
 }
-__device__ __forceinline__ float wg_resid_hi(float a, float s, unsigned h) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(s), "v"(h));
-    return r;
+// per pair: t = v s (v_pk_mul_f32), hi = RN16(t) (v_cvt_pk_f16_f32), r = t - hi exactly (v_fma_mix_f32), lo = RN16(r)
+// (instruction costs: gemm_engine.hip, f16_split_pair)
+__device__ __forceinline__ void wg_split_pair(float a, float b, float s, unsigned &ph, unsigned &pl) {
+    const f32x2 t = f32x2{a, b} * s;
+    ph = __builtin_bit_cast(unsigned, __builtin_convertvector(t, f16x2v));
+    const f32x2 r = {wg_mix_lo(ph, t.x), wg_mix_hi(ph, t.y)};
+    pl = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2v));
 }
 __device__ __forceinline__ void wg_split2(const float4 v, const float s, uint2 &ph, uint2 &pl) {
-    ph.x = wg_f16_pair(v.x, v.y, s); ph.y = wg_f16_pair(v.z, v.w, s);
-    pl.x = wg_f16_pair(wg_resid_lo(v.x, s, ph.x), wg_resid_hi(v.y, s, ph.x), 1.f);
-    pl.y = wg_f16_pair(wg_resid_lo(v.z, s, ph.y), wg_resid_hi(v.w, s, ph.y), 1.f);
+    wg_split_pair(v.x, v.y, s, ph.x, pl.x);
+    wg_split_pair(v.z, v.w, s, ph.y, pl.y);
 }
 __device__ __forceinline__ float wg_f16_scale(const float *amax, int &unscale) {     // = lvt_f16_scale (gemm_engine.hip)
     if (!amax) return 1.f;

@@ -241,11 +241,19 @@ extern "C" int lvt_add_periodic(float *x, const float *table, long long rows, in
 __global__ void lvt_layernorm_fwd_kernel(const float *__restrict__ x, long long rows, int d, float eps,
                                          const float *__restrict__ w, const float *__restrict__ b,
                                          float *__restrict__ y, float *__restrict__ mean_out,
-                                         float *__restrict__ rstd_out, float *__restrict__ y_amax) {
+                                         float *__restrict__ rstd_out, float *__restrict__ y_amax,
+                                         const float *__restrict__ w_amax, const float *__restrict__ b_amax) {
     __shared__ float amax_scratch[4];
     const int lane = threadIdx.x & 63;
     const int d4 = d / 4;
     float am = 0.f;
+    if (y_amax && w_amax) {
+        // a-priori bound instead of a reduction: |(x - mean) rstd| <= sqrt(d - 1) on every row, so
+        // max |y| <= max |w| sqrt(d - 1) + max |b| -- ~4x above the actual maximum of a 16384 x 512 output (2 of the 27
+        // binades an f16x2 operand scale has to spare), for one store instead of one atomic per workgroup
+        if (blockIdx.x == 0 && threadIdx.x == 0) *y_amax = *w_amax * sqrtf((float)(d - 1)) + *b_amax;
+        y_amax = nullptr;
+    }
     for (long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < rows;
          row += ((long long)gridDim.x * blockDim.x) >> 6) {
         const float4 *xp = reinterpret_cast<const float4 *>(x + row * d);
@@ -286,10 +294,12 @@ __global__ void lvt_layernorm_fwd_kernel(const float *__restrict__ x, long long 
     if (y_amax) lvt_block_amax_commit(am, y_amax, amax_scratch);
 }
 extern "C" int lvt_layernorm_fwd(const float *x, long long rows, int d, float eps, const float *w, const float *b,
-                                 float *y, float *mean, float *rstd, float *y_amax, void *stream) {
+                                 float *y, float *mean, float *rstd, float *y_amax, const float *w_amax, const float *b_amax,
+                                 void *stream) {
     LVT_REQUIRE(x && w && b && y && rows > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "layernorm_fwd: bad args (d=%d)", d);
-    hipLaunchKernelGGL(lvt_layernorm_fwd_kernel, dim3(grid_for(rows, 4, y_amax ? 2048 : 16384)), dim3(256), 0, (hipStream_t)stream,
-                       x, rows, d, eps, w, b, y, mean, rstd, y_amax);
+    LVT_REQUIRE(!w_amax == !b_amax, "layernorm_fwd: w_amax and b_amax come together");
+    hipLaunchKernelGGL(lvt_layernorm_fwd_kernel, dim3(grid_for(rows, 4, (y_amax && !w_amax) ? 2048 : 16384)), dim3(256), 0,
+                       (hipStream_t)stream, x, rows, d, eps, w, b, y, mean, rstd, y_amax, w_amax, b_amax);
     LVT_CHECK_LAUNCH("lvt_layernorm_fwd_kernel");
     return LVT_OK;
 }

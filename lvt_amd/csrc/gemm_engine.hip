@@ -51,6 +51,7 @@ struct KParams {
     int vec_epi;             // C / res / mask / partial rows are 16-byte aligned and N % 4 == 0: float4 epilogue
     float *colsum_partial;   // bwd-weight: [splits][N] column sums of B (= bias gradient), written by the m0 == 0 tiles
     const float *a_amax, *b_amax;   // f16x2 arithmetic: device scalars >= max |A|, max |B| (NULL: the operand is used unscaled)
+    const float *a_amax2, *b_amax2; // optional second bound per operand (the larger one counts)
     float *c_amax;                  // any arithmetic: when non-NULL, max |C| is folded in (integer atomic max on the bit pattern)
     lvt_conv_geom g;
     int Tq, Hq, Wq;          // A_CONVT_K: per-phase output extents
@@ -128,32 +129,43 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 // so the full 22 + sign bits hold for every element down to 2^-27 max |a| and degrade gradually below that.  A block is
 // three v_mfma_f32_32x32x16_f16: hi hi into one accumulator, hi lo + lo hi into a second one that is added with weight 2^-11
 // at the end (dropped: lo lo <= 2^-22 |a||b| worst case, 2^-24.6 rms -- the size of one fp32 rounding).
-// v_fma_mix{lo,hi}_f16 round (x * y + z) ONCE to fp16 into one half of the destination; v_fma_mix_f32 reads an fp16 half.
-__device__ __forceinline__ unsigned f16_pair(float a, float b, float s) {
-    unsigned r;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0\n\tv_fma_mixhi_f16 %0, %3, %2, 0" : "=&v"(r) : "v"(a), "v"(s), "v"(b));
+// Instruction choice (scratch/ubench/valu_rate_f16.hip, issue cost relative to v_add_f32): v_fma_mixlo/hi_f16 3.3, v_fma_mix_f32
+// 1.7, v_cvt_pk_f16_f32 1.7 (two elements), v_pk_mul_f32 1.75 (two elements).  Per PAIR of elements: t = v s (v_pk_mul_f32),
+// hi = RN16(t) (v_cvt_pk_f16_f32), t2 = v (2048 s) (v_pk_mul_f32), r = t2 - 2048 hi exactly (v_fma_mix_f32 reads the fp16 half
+// of hi directly), lo = RN16(r) (v_cvt_pk_f16_f32): 5.2 units per element; the first version (three v_fma_mix*_f16 forms per
+// element) cost 8.3 and made the main loops VALU-bound (profiles/r04_wide_gemm_loop_experiments.txt).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float f16_mix_lo(unsigned h, float k, float c) {        // half(h.lo) * k + c, one rounding
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(k), "v"(c));
     return r;
 }
-__device__ __forceinline__ float f16_resid_lo(float a, float s, unsigned h) {      // a * s - half(h.lo), exact
+__device__ __forceinline__ float f16_mix_hi(unsigned h, float k, float c) {        // half(h.hi) * k + c
     float r;
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(s), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(k), "v"(c));
     return r;
 }
-__device__ __forceinline__ float f16_resid_hi(float a, float s, unsigned h) {      // a * s - half(h.hi), exact
-    float r;
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(s), "v"(h));
-    return r;
+// LOSCALE = 2048: the scaled low term of this file; LOSCALE = 1: the unscaled one of conv_wgrad.hip
+template <int LOSCALE>
+__device__ __forceinline__ void f16_split_pair(float a, float b, float s, unsigned &ph, unsigned &pl) {
+    const f32x2 v = {a, b};
+    ph = __builtin_bit_cast(unsigned, __builtin_convertvector(v * s, f16x2v));
+    const f32x2 t2 = v * (s * (float)LOSCALE);
+    const f32x2 r = {f16_mix_lo(ph, -(float)LOSCALE, t2.x), f16_mix_hi(ph, -(float)LOSCALE, t2.y)};       // exact
+    pl = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2v));
 }
 __device__ __forceinline__ void split2(const float4 v, const float s, uint2 &ph, uint2 &pl) {
-    ph.x = f16_pair(v.x, v.y, s); ph.y = f16_pair(v.z, v.w, s);
-    pl.x = f16_pair(f16_resid_lo(v.x, s, ph.x), f16_resid_hi(v.y, s, ph.x), 2048.f);
-    pl.y = f16_pair(f16_resid_lo(v.z, s, ph.y), f16_resid_hi(v.w, s, ph.y), 2048.f);
+    f16_split_pair<2048>(v.x, v.y, s, ph.x, pl.x);
+    f16_split_pair<2048>(v.z, v.w, s, ph.y, pl.y);
 }
 // power-of-two scale of an operand from its max |a| (a device scalar; any upper bound works, a loose one costs range):
 // returns s = 2^e with max * s in [2^14, 2^15) and adds -e to `unscale` (the exponent that undoes it on the result).
-__device__ __forceinline__ float lvt_f16_scale(const float *amax, int &unscale) {
+__device__ __forceinline__ float lvt_f16_scale(const float *amax, int &unscale, const float *amax2 = nullptr) {
     if (!amax) return 1.f;
-    const int eb = (int)((__float_as_uint(*amax) >> 23) & 0xffu);                    // biased exponent (255: inf / nan propagate)
+    unsigned bits = __float_as_uint(*amax);
+    if (amax2) bits = max(bits, __float_as_uint(*amax2));                            // non-negative floats order like their bits
+    const int eb = (int)((bits >> 23) & 0xffu);                                      // biased exponent (255: inf / nan propagate)
     int se = 268 - eb;                                                               // 127 + 14 - (eb - 127)
     se = se < 2 ? 2 : (se > 252 ? 252 : se);
     unscale -= se - 127;
@@ -932,7 +944,7 @@ __global__ __launch_bounds__(NTHREADS, (MATH == 2 ? 2 : LVT_MINWAVES)) void lvt_
             }
     int unscale = 0;
     float sa = 1.f, sb = 1.f;
-    if (MATH == 2) { sa = lvt_f16_scale(p.a_amax, unscale); sb = lvt_f16_scale(p.b_amax, unscale); }
+    if (MATH == 2) { sa = lvt_f16_scale(p.a_amax, unscale, p.a_amax2); sb = lvt_f16_scale(p.b_amax, unscale, p.b_amax2); }
 
     constexpr bool COLSUM = (AMODE == A_CONV_M && BMODE == B_NPLAIN);
     constexpr bool COLSUM_A = (AMODE == A_MPLAIN);
@@ -1332,7 +1344,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void lvt_gemm_wide_kernel(const KP
     const int m0 = tc.m0, n0 = tc.n0, kbeg = tc.kbeg, kend = tc.kend;
 
     int unscale = 0;
-    const float sa = lvt_f16_scale(p.a_amax, unscale), sb = lvt_f16_scale(p.b_amax, unscale);
+    const float sa = lvt_f16_scale(p.a_amax, unscale, p.a_amax2), sb = lvt_f16_scale(p.b_amax, unscale, p.b_amax2);
 
     // ---- operand fetch state.  k-contiguous: thread = (row r0 + 64 i, k quad kq); m-contiguous: thread = (4 k rows, 4 columns).
     // The main loop carries NO bounds checks (one basic block: the split of tile k+1 and the loads of tile k+2 interleave
@@ -1428,7 +1440,10 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void lvt_gemm_wide_kernel(const KP
     for (int j = 0; j < TN; ++j) boff[j] = 2 * PSA + hrow<BN>(wn * (TN * 32) + j * 32 + l31) + 8 * half;
 
     // one k-tile: the MFMA block on buffer `cur`; with STORE the registers (tile kt+1) are split into the other buffer, with
-    // FETCH the loads of tile kt+2 follow -- no dependence on the MFMAs, so the scheduler is free to interleave them
+    // FETCH the loads of tile kt+2 follow -- no dependence on the MFMAs: one basic block that the scheduler interleaves
+    // (after the first 12 MFMAs in program order).  Measured alternatives (profiles/r04_wide_gemm_loop_experiments.txt): the
+    // two waves of a SIMD in anti-phase (waves 4..7 split before their MFMA block, 0..3 after it, straight-line blocks):
+    // 7 % SLOWER than this interleave.
     auto tile = [&](const unsigned short *cur, unsigned short *nxt, auto do_store, auto do_fetch) {
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 16) {
@@ -1440,6 +1455,15 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void lvt_gemm_wide_kernel(const KP
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const f16x8 *>(cur + boff[j] + q * PSB + ks);
             }
+#ifdef LVT_WX_NOMFMA        // (timing experiments, scratch/build_variant.sh: what the main loop costs without one of its parts)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j][0] += (float)a[0][i][0] + (float)b[0][j][0] + (float)a[1][i][1] + (float)b[1][j][1];
+                    acx[i][j][0] += (float)a[0][i][7] + (float)b[0][j][7];
+                }
+#else
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1455,9 +1479,14 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void lvt_gemm_wide_kernel(const KP
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0][j], acx[i][j], 0, 0, 0);
+#endif
             if (ks == 0) {
+#ifndef LVT_WX_NOSPLIT
                 if constexpr (decltype(do_store)::value) store(nxt);
+#endif
+#ifndef LVT_WX_NOFETCH
                 if constexpr (decltype(do_fetch)::value) fetch();
+#endif
             }
         }
     };
@@ -1808,6 +1837,7 @@ static void kparams_from_desc(const lvt_gemm_desc *d, KParams &p) {
     p.mask = d->mask; p.ldm = d->ldm;
     p.splits = d->splits > 1 ? d->splits : 1;
     p.a_amax = d->a_amax; p.b_amax = d->b_amax; p.c_amax = d->c_amax;
+    p.a_amax2 = d->a_amax2; p.b_amax2 = d->b_amax2;
 }
 
 static int gemm_batch(const lvt_gemm_desc *d) {

@@ -36,7 +36,7 @@ class GemmDesc(C.Structure):
         ("bias", C.c_void_p), ("res", C.c_void_p), ("ldr", C.c_longlong),
         ("mask", C.c_void_p), ("ldm", C.c_longlong), ("splits", C.c_int),
         ("a_colsum", C.c_void_p), ("c_plane", C.c_longlong),
-        ("a_amax", C.c_void_p), ("b_amax", C.c_void_p), ("c_amax", C.c_void_p),
+        ("a_amax", C.c_void_p), ("b_amax", C.c_void_p), ("a_amax2", C.c_void_p), ("b_amax2", C.c_void_p), ("c_amax", C.c_void_p),
     ]
 
 
@@ -114,7 +114,7 @@ def _declare(lib):
         "lvt_tanh_bwd": (ci, [vp, vp, cll, vp, vp, vp]),
         "lvt_axpy": (ci, [vp, vp, cll, vp, cf, vp, vp]),
         "lvt_add_periodic": (ci, [vp, vp, cll, ci, ci, vp]),
-        "lvt_layernorm_fwd": (ci, [vp, cll, ci, cf, vp, vp, vp, vp, vp, vp, vp]),
+        "lvt_layernorm_fwd": (ci, [vp, cll, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "lvt_layernorm_bwd_workspace_bytes": (sz, [ci]),
         "lvt_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, cll, ci, vp, vp, vp, vp, vp, vp, sz, vp]),
         "lvt_attn_softmax_fwd": (ci, [vp, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp]),
@@ -315,8 +315,8 @@ def prefetch_module_weights(module):
             todo.append(packed())
             skip = ("w_q", "w_k", "w_v")
         for name, p in m.named_parameters(recurse=False):
-            if p.dim() >= 2 and name not in skip:
-                todo.append(p)
+            if name not in skip and (p.dim() >= 2 or isinstance(m, torch.nn.LayerNorm)):
+                todo.append(p)          # (LayerNorm weight / bias: the a-priori bound of its output, lvt_layernorm_fwd)
     amax_prefetch(todo)
 
 

@@ -83,8 +83,11 @@ def layernorm_fwd(x, w, b, eps=1e-5, save_stats=True):
     y = torch.empty_like(x)
     mean = _f32(rows, like=x) if save_stats else None
     rstd = _f32(rows, like=x) if save_stats else None
+    # f16x2: the output feeds engine launches; its max |.| is the a-priori bound max |w| sqrt(d - 1) + max |b| (one store)
+    f16 = L.f16x2()
     L.check(L.lib().lvt_layernorm_fwd(L.ptr(x), rows, d, eps, L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(mean),
-                                      L.ptr(rstd), L.out_amax(y), L.stream_ptr()), "lvt_layernorm_fwd")
+                                      L.ptr(rstd), L.out_amax(y), L.ptr(L.amax_of(w)) if f16 else None,
+                                      L.ptr(L.amax_of(b)) if f16 else None, L.stream_ptr()), "lvt_layernorm_fwd")
     return y, mean, rstd
 
 

@@ -8,9 +8,11 @@ from . import binding as L
 
 def gemm(A, B, C_out, M, N, K, ta=0, tb=0, lda=None, ldb=None, ldc=None, a_kb=0, a_skb=0, b_kb=0,
          b_skb=0, batch_outer=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, flags=0,
-         bias=None, res=None, ldr=0, mask=None, ldm=0, splits=1, a_colsum=None, c_plane=0):
+         bias=None, res=None, ldr=0, mask=None, ldm=0, splits=1, a_colsum=None, c_plane=0, a_also=None, b_also=None):
     """C = epi(alpha * A @ B); see include/lvt_hip.h for the addressing rules.  With EPI_PLANES `C_out` is a bf16 tensor
-    that receives the exact 3-way bf16 split of the result (planes c_plane elements apart)."""
+    that receives the exact 3-way bf16 split of the result (planes c_plane elements apart).
+    a_also / b_also: a second tensor that the A / B operand of a batched launch reaches through its batch stride (address
+    differences): its max |.| enters the f16x2 operand scale next to A's / B's own."""
     L.require(A, B, C_out, bias, res, mask)
     d = L.GemmDesc()
     d.M, d.N, d.K, d.ta, d.tb = M, N, K, ta, tb
@@ -33,6 +35,8 @@ def gemm(A, B, C_out, M, N, K, ta=0, tb=0, lda=None, ldb=None, ldc=None, a_kb=0,
     if L.f16x2():
         # operand scales of the f16x2 arithmetic; the launch reports max |C| unless it is a split-K one (weight gradients)
         d.a_amax, d.b_amax = L.amax_of(A).data_ptr(), L.amax_of(B).data_ptr()
+        d.a_amax2 = L.amax_of(a_also).data_ptr() if a_also is not None else None
+        d.b_amax2 = L.amax_of(b_also).data_ptr() if b_also is not None else None
         if splits <= 1 and C_out.dtype == torch.float32:
             d.c_amax = L.new_amax(C_out).data_ptr()
     lib = L.lib()

@@ -142,12 +142,9 @@ def linear_wgrad_pair(dy0, x0, dy1, x1, n_out, k_in, rows):
         a, ab = linear_wgrad(dy0, x0, n_out, k_in, rows, want_bias=True)
         b, bb = linear_wgrad(dy1, x1, n_out, k_in, rows, want_bias=True)
         return torch.stack([a, b]), torch.stack([ab, bb])
-    if L.f16x2():
-        # each operand of this launch spans two tensors: its scale must cover both (the wrappers look at dy0 / x0 only)
-        L.set_amax(dy0, L.amax_merged(dy0, dy1))
-        L.set_amax(x0, L.amax_merged(x0, x1))
+    # (each operand of this launch spans two tensors: a_also / b_also bring the second one's max |.| into the f16x2 scale)
     G.gemm(dy0, x0, dw, n_out, k_in, rows, ta=1, tb=1, lda=n_out, ldb=k_in, batch_inner=2, sA=(0, da // es), sB=(0, dx // es),
-           sC=(0, n_out * k_in), splits=splits, a_colsum=db)
+           sC=(0, n_out * k_in), splits=splits, a_colsum=db, a_also=dy1, b_also=x1)
     return dw, db
 
 
