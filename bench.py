@@ -177,16 +177,21 @@ def timed_steps(step, steps, first_iter, world, device):
     return float(el.item()), step_stats(events), out
 
 
-def traffic_from_profile(name):
+def traffic_from_profile(name, launches_per_step=None):
     """HBM bytes per engine launch from this round's committed PMC passes (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in
-    separate runs of this command, summarised by scratch/pmc_summary.py): counters cannot be read inside the run."""
-    for cand in (name, name.replace("r03_", "r02_")):
-        try:
-            with open(os.path.join(ROOT, "profiles", cand)) as f:
-                return round(json.load(f)["hbm_bytes_per_launch"]), cand
-        except Exception:
-            continue
-    return None, None
+    separate runs of scratch/bench_leg.py, summarised by scratch/pmc_summary.py / scratch/profile_r04.sh): counters cannot be
+    read inside the run.  -> (bytes per launch or None, file name, stale?): the figure is STALE when the profiled code issued
+    another number of engine launches per step than the run that quotes it (the kernels changed since the pass)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            d = json.load(f)
+    except Exception:
+        return None, None, None
+    prof = d.get("engine_launches_per_step")
+    if prof is None and d.get("steps"):
+        prof = d["engine_launches"] / d["steps"]
+    stale = None if (prof is None or launches_per_step is None) else bool(abs(prof - launches_per_step) > 0.5)
+    return round(d["hbm_bytes_per_launch"]), name, stale
 
 
 def engine_summary(timer, steps, mode):
@@ -223,9 +228,9 @@ def instrumented(step, steps, first_iter):
 
 
 def roofline_block(es, mode, traffic_file, kernel_note):
-    traffic, src = traffic_from_profile(traffic_file)
+    traffic, src, stale = traffic_from_profile(traffic_file, es["launches_per_step"])
     return {"bound": "mfma", "achieved": round(es["achieved"], 2), "peak": round(es["peak"], 1), "unit": "TFLOP/s",
-            "frac": round(es["frac"], 4), "traffic": traffic,
+            "frac": round(es["frac"], 4), "traffic": traffic, "traffic_stale": stale,
             "traffic_unit": "HBM bytes per engine launch (rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE in "
                             "separate passes of this command, profiles/%s); algorithmic flops per launch = %.3e"
                             % (src, es["flops_per_launch"]),
@@ -723,14 +728,14 @@ def run(args):
     extra = {}
     if not args.no_legs:
         nl = max(10, args.steps)
-        extra["vqvae"] = leg_alone("vqvae", vq, nl, 3, world, device, "clips", "r03_vqvae_pmc_hbm_traffic.json",
+        extra["vqvae"] = leg_alone("vqvae", vq, nl, 3, world, device, "clips", "r04_vqvae_pmc_hbm_traffic.json",
                                    "lvt_conv_patch_kernel<0,1,2> / lvt_conv_wgrad_frames_kernel<0,1> (frame-resident 3x3 and "
                                    "4x4/stride-2 layers) + lvt_gemm_kernel<*> (1x1 and image-side layers)",
                                    not args.no_strict_f32)
         extra["dsfvt"] = leg_alone("dsfvt", ds, max(10, args.steps // 2), 2, world, device, "samples",
-                                   "r03_dsfvt_pmc_hbm_traffic.json",
-                                   "lvt_gemm_kernel<*> (QKV / proj / FFN products, their data and weight gradients) + "
-                                   "lvt_attn_fwd_kernel / lvt_attn_bwd_kernel (fused attention)", not args.no_strict_f32)
+                                   "r04_dsfvt_pmc_hbm_traffic.json",
+                                   "lvt_gemm_wide_kernel<*> (QKV / proj / FFN products, their data and weight gradients; f16x2) + "
+                                   "lvt_attn_fwd16_planes_kernel / lvt_attn_bwd_a16 / _b16 (fused attention, bf16x3)", not args.no_strict_f32)
         v1, v2 = extra["vqvae"]["clips_per_s"], extra["dsfvt"]["samples_per_s"]
         extra["legs_combined_harmonic"] = {"clips_per_s": round(1.0 / (1.0 / v1 + 1.0 / v2), 3),
                                            "note": "1/(1/vqvae + 1/dsfvt) of the two legs timed alone: cross-check of `value`"}
@@ -766,8 +771,8 @@ def run(args):
                                    % (clips_per_step, vq_per_step, args.batch_clips, args.dsfvt_batch, args.batches),
                        "global_batch_clips": clips_per_step * world, "parallelism": "dp%d" % world},
             "roofline": roofline_block(
-                es, math_mode, "r03_combined_pmc_hbm_traffic.json",
-                "the matrix-core engine launches of the step: lvt_gemm_kernel<*>, lvt_conv_patch_kernel<*>, "
+                es, math_mode, "r04_combined_pmc_hbm_traffic.json",
+                "the matrix-core engine launches of the step: lvt_gemm_wide_kernel<*>, lvt_gemm_kernel<*>, lvt_conv_patch_kernel<*>, "
                 "lvt_conv_wgrad_frames_kernel<*>, lvt_attn_fwd/bwd kernels; %d launches per step, event-timed in a second "
                 "pass of the same %d steps: %.2f ms of engine time in a %.2f ms instrumented step (unperturbed: %.2f ms)"
                 % (es["launches_per_step"], args.steps, es["ms_per_step"], instrumented_ms, ms)),

@@ -1291,7 +1291,9 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
             }
         }
         // the other weight buffer was last read in the previous step, which every wave has left (barrier below)
+#ifndef LVT_PX_NOBSPLIT      // (timing experiment: the weight tile is split + stored for step 0 only)
         if (has_next && bact) b_store(Bh0 + ((step + 1) & 1) * (NP * PSB));
+#endif
         if (new_chunk) {
             __syncthreads();              // every wave is done with the old patch
             patch_store();

@@ -16,10 +16,10 @@ eng = {"f": 0.0, "w": 0.0, "n": 0}
 for n, d in sorted(res.items(), key=lambda kv: -(kv[1].get("FETCH_SIZE", (0, 0, 0, 0))[1] + kv[1].get("WRITE_SIZE", (0, 0, 0, 0))[1])):
     f = d.get("FETCH_SIZE", (0, 0, 0, 0)); w = d.get("WRITE_SIZE", (0, 0, 0, 0))
     lines.append("%-64s %6d %12.0f %12.0f %12.0f %10.1f" % (n, f[0] or w[0], f[2], 2 * f[2], w[2], (f[3] or w[3]) / 1e3))
-    if any(k in n for k in ("lvt_gemm_kernel", "lvt_conv_patch_kernel", "lvt_conv_wgrad_frames_kernel", "lvt_attn_")):
+    if any(k in n for k in ("lvt_gemm_kernel", "lvt_gemm_wide_kernel", "lvt_conv_patch_kernel", "lvt_conv_wgrad_frames_kernel", "lvt_attn_")):
         eng["f"] += f[1]; eng["w"] += w[1]; eng["n"] += f[0]
 per_launch = (2 * eng["f"] + eng["w"]) * 1024 / max(eng["n"], 1)
-lines.append("engine (lvt_gemm_kernel<*>, lvt_conv_patch_kernel, lvt_conv_wgrad_frames_kernel, lvt_attn_*): %d launches, %.1f MB of HBM traffic per launch (fetch x2 + write), %.2f GB per step"
+lines.append("engine (lvt_gemm_kernel<*>, lvt_gemm_wide_kernel<*>, lvt_conv_patch_kernel, lvt_conv_wgrad_frames_kernel, lvt_attn_*): %d launches, %.1f MB of HBM traffic per launch (fetch x2 + write), %.2f GB per step"
              % (eng["n"], per_launch / 1e6, (2 * eng["f"] + eng["w"]) * 1024 / steps / 1e9))
 open(out_txt, "w").write("\n".join(lines[:48]) + "\n")
 json.dump({"engine_launches": eng["n"], "steps": steps, "fetch_KiB_raw": eng["f"], "write_KiB": eng["w"],
