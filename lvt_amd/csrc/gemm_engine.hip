@@ -1298,6 +1298,9 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
             __syncthreads();              // every wave is done with the old patch
             patch_store();
         }
+#ifdef LVT_PX_HALFBARRIERS   // (timing experiment, wrong results: a barrier every second step)
+        if ((step & 1) || new_chunk)
+#endif
         __syncthreads();
     }
     if constexpr (MATH == 2) {
@@ -2051,6 +2054,16 @@ extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const floa
             return LVT_OK;
         }
     }
+    {
+        // a 1x1x1 / stride 1 / unpadded convolution IS the product x (M x Ci) . wp (Ci x Co): in f16x2 mode it takes the wide
+        // pipelined kernel (no im2col index arithmetic in the loader, 256-row tiles)
+        static const int no_wide = getenv("LVT_NO_WIDE_GEMM") ? 1 : 0;
+        if (!no_wide && math_of(flags) == 2 && BK == 32 && g->Kt == 1 && g->Kh == 1 && g->Kw == 1 && g->st == 1 && g->sh == 1 &&
+            g->sw == 1 && g->pt == 0 && g->ph == 0 && g->pw == 0 && g->Ci % BK == 0 && p.M > 128 && lvt_aligned16(x) && lvt_aligned16(wp)) {
+            p.lda = g->Ci; p.a_kb = p.K; p.b_kb = p.K;
+            return launch_wide<0, 1>(p, 1, (hipStream_t)stream);
+        }
+    }
     if (g->Co <= 32) return launch_tile<A_CONV_K, B_NPLAIN, 128, 32, 4, 1>(p, 1, (hipStream_t)stream);
     return launch_tile<A_CONV_K, B_NPLAIN, 128, 128, 2, 2>(p, 1, (hipStream_t)stream);
 }
@@ -2127,6 +2140,15 @@ extern "C" int lvt_conv3d_bwd_data(const lvt_conv_geom *g, const float *dy, cons
     p.alpha = 1.f; p.flags = flags; p.bias = bias; p.res = res; p.ldr = g->Ci; p.mask = mask; p.ldm = g->Ci;
     p.splits = 1; p.g = *g;
     LVT_REQUIRE_AMAX(flags, ax, "conv3d_bwd_data"); set_amax(p, ax);
+    {
+        // 1x1x1 / stride 1 / unpadded: dx (M x Ci) = dy (M x Co) . wp^T, wp = (Ci x Co) read k-contiguous -- the wide kernel
+        static const int no_wide = getenv("LVT_NO_WIDE_GEMM") ? 1 : 0;
+        if (!no_wide && math_of(flags) == 2 && BK == 32 && g->Kt == 1 && g->Kh == 1 && g->Kw == 1 && g->st == 1 && g->sh == 1 &&
+            g->sw == 1 && g->pt == 0 && g->ph == 0 && g->pw == 0 && g->Co % BK == 0 && p.M > 128 && lvt_aligned16(dy) && lvt_aligned16(wp)) {
+            p.lda = g->Co; p.ldb = g->Co; p.a_kb = p.K; p.b_kb = p.K;
+            return launch_wide<0, 0>(p, 1, (hipStream_t)stream);
+        }
+    }
     const int ncls = g->st * g->sh * g->sw;
     if (g->Ci <= 32) return launch_tile<A_CONVT_K, B_CONVT_W, 128, 32, 4, 1>(p, ncls, (hipStream_t)stream);
     return launch_tile<A_CONVT_K, B_CONVT_W, 128, 128, 2, 2>(p, ncls, (hipStream_t)stream);
