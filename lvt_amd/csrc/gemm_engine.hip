@@ -159,6 +159,19 @@ __device__ __forceinline__ void split2(const float4 v, const float s, uint2 &ph,
     f16_split_pair<2048>(v.x, v.y, s, ph.x, pl.x);
     f16_split_pair<2048>(v.z, v.w, s, ph.y, pl.y);
 }
+// The same split with fewer live registers (three v_fma_mix* forms per element, 8.3 issue units): lvt_gemm_kernel sits at
+// 230-250 registers with its two accumulator sets, and the 5.2-unit sequence above made its m-contiguous loaders spill
+// (conv weight gradient by implicit GEMM: 58 -> 147 us).  LEAN = 1 selects it.
+__device__ __forceinline__ unsigned f16_pair_mix(float a, float b, float s) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0\n\tv_fma_mixhi_f16 %0, %3, %2, 0" : "=&v"(r) : "v"(a), "v"(s), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void split2_lean(const float4 v, const float s, uint2 &ph, uint2 &pl) {
+    ph.x = f16_pair_mix(v.x, v.y, s); ph.y = f16_pair_mix(v.z, v.w, s);
+    pl.x = f16_pair_mix(f16_mix_lo(ph.x, -1.f, v.x * s), f16_mix_hi(ph.x, -1.f, v.y * s), 2048.f);
+    pl.y = f16_pair_mix(f16_mix_lo(ph.y, -1.f, v.z * s), f16_mix_hi(ph.y, -1.f, v.w * s), 2048.f);
+}
 // power-of-two scale of an operand from its max |a| (a device scalar; any upper bound works, a loose one costs range):
 // returns s = 2^e with max * s in [2^14, 2^15) and adds -e to `unscale` (the exponent that undoes it on the result).
 __device__ __forceinline__ float lvt_f16_scale(const float *amax, int &unscale, const float *amax2 = nullptr) {
@@ -171,16 +184,18 @@ __device__ __forceinline__ float lvt_f16_scale(const float *amax, int &unscale, 
     unscale -= se - 127;
     return __uint_as_float((unsigned)se << 23);
 }
-template <int ROWS> __device__ __forceinline__ void store_split2_k(unsigned short *lds, int row, int k4, const float4 v, float s) {
+template <int ROWS, int LEAN = 0> __device__ __forceinline__ void store_split2_k(unsigned short *lds, int row, int k4, const float4 v, float s) {
     uint2 ph, pl;
-    split2(v, s, ph, pl);
+    if (LEAN) split2_lean(v, s, ph, pl);
+    else split2(v, s, ph, pl);
     unsigned short *d = lds + hrow<ROWS>(row) + k4;
     *reinterpret_cast<uint2 *>(d) = ph;
     *reinterpret_cast<uint2 *>(d + HPlane<ROWS>::SIZE) = pl;
 }
-template <int ROWS> __device__ __forceinline__ void store_split2_m(unsigned short *lds, int row4, int k, const float4 v, float s) {
+template <int ROWS, int LEAN = 0> __device__ __forceinline__ void store_split2_m(unsigned short *lds, int row4, int k, const float4 v, float s) {
     uint2 p[2];
-    split2(v, s, p[0], p[1]);
+    if (LEAN) split2_lean(v, s, p[0], p[1]);
+    else split2(v, s, p[0], p[1]);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         unsigned short *d = lds + q * HPlane<ROWS>::SIZE + k;
@@ -188,11 +203,11 @@ template <int ROWS> __device__ __forceinline__ void store_split2_m(unsigned shor
         d[hrow<ROWS>(row4 + 2)] = (unsigned short)(p[q].y & 0xffffu); d[hrow<ROWS>(row4 + 3)] = (unsigned short)(p[q].y >> 16);
     }
 }
-template <int ROWS> __device__ __forceinline__ void store_split2_block(unsigned short *lds, int row4, int k4, const float4 *v, float s) {
-    store_split2_k<ROWS>(lds, row4 + 0, k4, make_float4(v[0].x, v[1].x, v[2].x, v[3].x), s);
-    store_split2_k<ROWS>(lds, row4 + 1, k4, make_float4(v[0].y, v[1].y, v[2].y, v[3].y), s);
-    store_split2_k<ROWS>(lds, row4 + 2, k4, make_float4(v[0].z, v[1].z, v[2].z, v[3].z), s);
-    store_split2_k<ROWS>(lds, row4 + 3, k4, make_float4(v[0].w, v[1].w, v[2].w, v[3].w), s);
+template <int ROWS, int LEAN = 0> __device__ __forceinline__ void store_split2_block(unsigned short *lds, int row4, int k4, const float4 *v, float s) {
+    store_split2_k<ROWS, LEAN>(lds, row4 + 0, k4, make_float4(v[0].x, v[1].x, v[2].x, v[3].x), s);
+    store_split2_k<ROWS, LEAN>(lds, row4 + 1, k4, make_float4(v[0].y, v[1].y, v[2].y, v[3].y), s);
+    store_split2_k<ROWS, LEAN>(lds, row4 + 2, k4, make_float4(v[0].z, v[1].z, v[2].z, v[3].z), s);
+    store_split2_k<ROWS, LEAN>(lds, row4 + 3, k4, make_float4(v[0].w, v[1].w, v[2].w, v[3].w), s);
 }
 
 // Mixed-radix digits of a running GEMM-k index, k = ((t*nH + h)*nW + w)*nC + c.  Every loader decodes its
@@ -394,9 +409,9 @@ template <int BM, int MATH> struct AMLoaderBase {
         for (int i = 0; i < ITERS; ++i) store_split_m<BM>(lds, mq * 4, kk0 * KMUL + KSTEP * i, v[i]);
     }
     __device__ __forceinline__ void store_split2(unsigned short *lds, float s) const {
-        if (ITERS == 4) { store_split2_block<BM>(lds, mq * 4, kk0 * 4, v, s); return; }
+        if (ITERS == 4) { store_split2_block<BM, 1>(lds, mq * 4, kk0 * 4, v, s); return; }
 #pragma unroll
-        for (int i = 0; i < ITERS; ++i) store_split2_m<BM>(lds, mq * 4, kk0 * KMUL + KSTEP * i, v[i], s);
+        for (int i = 0; i < ITERS; ++i) store_split2_m<BM, 1>(lds, mq * 4, kk0 * KMUL + KSTEP * i, v[i], s);
     }
 };
 
@@ -488,6 +503,22 @@ template <int BM, int MATH> struct ALoader<A_ONEHOT_M, BM, MATH> : AMLoaderBase<
         bstride = p.oh_bstride; pstride = p.oh_pstride; P = p.oh_P;
     }
     int kcur;
+    // f16x2 planes of a 0 / 1 operand need no arithmetic: hi = 1.0h (0x3C00) or 0, lo = 0 (the generic split spilled registers
+    // here: 126 -> 228 us on the embedding weight gradients)
+    __device__ __forceinline__ void store_split2(unsigned short *lds, float) const {
+        static_assert(Base::ITERS == 4, "one-hot loader: 4 k rows per lane");
+        const float c[4][4] = {{this->v[0].x, this->v[1].x, this->v[2].x, this->v[3].x}, {this->v[0].y, this->v[1].y, this->v[2].y, this->v[3].y},
+                               {this->v[0].z, this->v[1].z, this->v[2].z, this->v[3].z}, {this->v[0].w, this->v[1].w, this->v[2].w, this->v[3].w}};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            uint2 h;
+            h.x = (c[r][0] != 0.f ? 0x3C00u : 0u) | (c[r][1] != 0.f ? 0x3C000000u : 0u);
+            h.y = (c[r][2] != 0.f ? 0x3C00u : 0u) | (c[r][3] != 0.f ? 0x3C000000u : 0u);
+            unsigned short *d = lds + hrow<BM>(this->mq * 4 + r) + this->kk0 * 4;
+            *reinterpret_cast<uint2 *>(d) = h;
+            *reinterpret_cast<uint2 *>(d + HPlane<BM>::SIZE) = make_uint2(0u, 0u);
+        }
+    }
     __device__ __forceinline__ void seek(int k0) { kcur = k0 + this->kk0 * Base::KMUL; }
     __device__ __forceinline__ void fetch(int kend) {
         const int kbase = kcur;
@@ -659,9 +690,9 @@ template <int BN, int MATH> struct BLoader<B_NPLAIN, BN, MATH> {
     }
     __device__ __forceinline__ void store_split2(unsigned short *lds, float s) const {
         if (!active) return;
-        if (ITERS == 4) { store_split2_block<BN>(lds, nq * 4, kk0 * 4, v, s); return; }
+        if (ITERS == 4) { store_split2_block<BN, 1>(lds, nq * 4, kk0 * 4, v, s); return; }
 #pragma unroll
-        for (int i = 0; i < ITERS; ++i) store_split2_m<BN>(lds, nq * 4, kk0 * KMUL + KSTEP * i, v[i], s);
+        for (int i = 0; i < ITERS; ++i) store_split2_m<BN, 1>(lds, nq * 4, kk0 * KMUL + KSTEP * i, v[i], s);
     }
 };
 
