@@ -187,9 +187,9 @@ def traffic_from_profile(name, launches_per_step=None):
             d = json.load(f)
     except Exception:
         return None, None, None
-    prof = d.get("engine_launches_per_step")
-    if prof is None and d.get("steps"):
-        prof = d["engine_launches"] / d["steps"]
+    # `engine_calls_per_step`: engine wrapper calls of one step of the profiled code, counted by scratch/bench_leg.py exactly as
+    # the KernelTimer of this run counts them (a wrapper call may be several kernel dispatches, which is what the counters see)
+    prof = d.get("engine_calls_per_step")
     stale = None if (prof is None or launches_per_step is None) else bool(abs(prof - launches_per_step) > 0.5)
     return round(d["hbm_bytes_per_launch"]), name, stale
 

@@ -1391,58 +1391,66 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void lvt_gemm_wide_kernel(const KP
     const int kk0 = TA ? tid >> 6 : 0, mq = tid & 63; // A m-contiguous: 8 k groups x 64 m quads
     const int bkk0 = (tid >> 5) & 7, bnq = tid & 31;  // B n-contiguous: 8 k groups x 32 n quads (threads 0..255)
     const bool bact = !TB || tid < 256;
-    const float *arow[4];
-    const float *brow[2];
-    const float *akp = nullptr, *bkp = nullptr;
-    int a_kin = 0, b_kin = 0; long long a_kbase = 0, b_kbase = 0;
+    // Addresses = a workgroup-uniform base that walks k (scalar registers, scalar arithmetic) + per-thread BYTE offsets that
+    // never change (the launcher keeps every operand below 4 GB per batch): the loop has no vector address arithmetic --
+    // 43 of its 115 VALU instructions before this.
+    const char *Ak = reinterpret_cast<const char *>(tc.A), *Bk = reinterpret_cast<const char *>(tc.B);
+    unsigned aoff[4], boff_g[TB ? 4 : 2];
+    int a_kin = 0, b_kin = 0;                           // position of the tile inside its k block (2-level k), uniform
     if (!TA) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) arow[i] = tc.A + (long long)min(m0 + r0 + 64 * i, p.M - 1) * p.lda;
-        const int kc = kbeg + kq * 4, blk = kc / p.a_kb;
-        a_kin = kc - blk * p.a_kb; a_kbase = (long long)blk * p.a_skb;
+        for (int i = 0; i < 4; ++i) aoff[i] = (unsigned)(((long long)min(m0 + r0 + 64 * i, p.M - 1) * p.lda + kq * 4) * 4);
+        const int blk = kbeg / p.a_kb;
+        a_kin = kbeg - blk * p.a_kb;
+        Ak += ((long long)blk * p.a_skb + a_kin) * 4;
     } else {
         const int m = m0 + mq * 4;
-        akp = tc.A + (m < p.M ? m : 0) + (long long)(kbeg + kk0 * 4) * p.lda;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aoff[i] = (unsigned)(((long long)(kk0 * 4 + i) * p.lda + (m < p.M ? m : 0)) * 4);
+        Ak += (long long)kbeg * p.lda * 4;
     }
     if (!TB) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) brow[i] = tc.B + (long long)min(n0 + r0 + 64 * i, p.N - 1) * p.ldb;
-        const int kc = kbeg + kq * 4, blk = kc / p.b_kb;
-        b_kin = kc - blk * p.b_kb; b_kbase = (long long)blk * p.b_skb;
+        for (int i = 0; i < 2; ++i) boff_g[i] = (unsigned)(((long long)min(n0 + r0 + 64 * i, p.N - 1) * p.ldb + kq * 4) * 4);
+        const int blk = kbeg / p.b_kb;
+        b_kin = kbeg - blk * p.b_kb;
+        Bk += ((long long)blk * p.b_skb + b_kin) * 4;
     } else {
         const int n = n0 + bnq * 4;
-        bkp = tc.B + (n < p.N ? n : 0) + (long long)(kbeg + bkk0 * 4) * p.ldb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) boff_g[i] = (unsigned)(((long long)(bkk0 * 4 + i) * p.ldb + (n < p.N ? n : 0)) * 4);
+        Bk += (long long)kbeg * p.ldb * 4;
     }
     const bool sum_on = TA && p.colsum_partial != nullptr && n0 == 0;
     float4 colacc = zero4();
     auto fetch = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const float4 *>(Ak + aoff[i]);
         if (!TA) {
-            const long long koff = a_kbase + a_kin;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = ldg4(arow[i] + koff);
             a_kin += BK;
-            const bool wrap = a_kin >= p.a_kb;              // (a_kb is a multiple of BK: at most one wrap per tile)
-            a_kin = wrap ? a_kin - p.a_kb : a_kin; a_kbase = wrap ? a_kbase + p.a_skb : a_kbase;
+            const bool wrap = a_kin >= p.a_kb;              // (a_kb is a multiple of BK: a tile never straddles two k blocks)
+            Ak += wrap ? ((long long)p.a_skb - p.a_kb + BK) * 4 : (long long)BK * 4;
+            a_kin = wrap ? 0 : a_kin;
         } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = ldg4(akp + (long long)i * p.lda);
-            akp += (long long)BK * p.lda;
+            Ak += (long long)BK * p.lda * 4;
             if (sum_on) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { colacc.x += av[i].x; colacc.y += av[i].y; colacc.z += av[i].z; colacc.w += av[i].w; }
             }
         }
         if (!TB) {
-            const long long koff = b_kbase + b_kin;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) bv[i] = ldg4(brow[i] + koff);
+            for (int i = 0; i < 2; ++i) bv[i] = *reinterpret_cast<const float4 *>(Bk + boff_g[i]);
             b_kin += BK;
             const bool wrap = b_kin >= p.b_kb;
-            b_kin = wrap ? b_kin - p.b_kb : b_kin; b_kbase = wrap ? b_kbase + p.b_skb : b_kbase;
-        } else if (bact) {
+            Bk += wrap ? ((long long)p.b_skb - p.b_kb + BK) * 4 : (long long)BK * 4;
+            b_kin = wrap ? 0 : b_kin;
+        } else {
+            if (bact) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bv[i] = ldg4(bkp + (long long)i * p.ldb);
-            bkp += (long long)BK * p.ldb;
+                for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const float4 *>(Bk + boff_g[i]);
+            }
+            Bk += (long long)BK * p.ldb * 4;
         }
     };
     auto store = [&](unsigned short *buf) {
@@ -1469,11 +1477,11 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void lvt_gemm_wide_kernel(const KP
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acx[i][j][r] = 0.f; }
 
-    int aoff[TM], boff[TN];
+    int fa[TM], fb[TN];                     // LDS offsets of this lane's operand fragments
 #pragma unroll
-    for (int i = 0; i < TM; ++i) aoff[i] = hrow<BM>(wm * (TM * 32) + i * 32 + l31) + 8 * half;
+    for (int i = 0; i < TM; ++i) fa[i] = hrow<BM>(wm * (TM * 32) + i * 32 + l31) + 8 * half;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) boff[j] = 2 * PSA + hrow<BN>(wn * (TN * 32) + j * 32 + l31) + 8 * half;
+    for (int j = 0; j < TN; ++j) fb[j] = 2 * PSA + hrow<BN>(wn * (TN * 32) + j * 32 + l31) + 8 * half;
 
     // one k-tile: the MFMA block on buffer `cur`; with STORE the registers (tile kt+1) are split into the other buffer, with
     // FETCH the loads of tile kt+2 follow -- no dependence on the MFMAs: one basic block that the scheduler interleaves
@@ -1487,9 +1495,9 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void lvt_gemm_wide_kernel(const KP
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const f16x8 *>(cur + aoff[i] + q * PSA + ks);
+                for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const f16x8 *>(cur + fa[i] + q * PSA + ks);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const f16x8 *>(cur + boff[j] + q * PSB + ks);
+                for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const f16x8 *>(cur + fb[j] + q * PSB + ks);
             }
 #ifdef LVT_WX_NOMFMA        // (timing experiments, scratch/build_variant.sh: what the main loop costs without one of its parts)
 #pragma unroll
@@ -1930,8 +1938,12 @@ extern "C" int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t work
     }
     int rc;
     static const int no_wide = getenv("LVT_NO_WIDE_GEMM") ? 1 : 0;
+    // (the wide kernel addresses its operands with 32-bit byte offsets from a per-batch base: each must span < 4 GB)
+    const long long a_span = d->ta ? (long long)d->K * d->lda : (long long)d->M * d->lda + (long long)(d->K / p.a_kb) * d->a_skb;
+    const long long b_span = d->tb ? (long long)d->K * d->ldb : (long long)d->N * d->ldb + (long long)(d->K / p.b_kb) * d->b_skb;
     const bool wide = !no_wide && math_of(d->flags) == 2 && BK == 32 && d->M > 128 && d->K % BK == 0 && p.a_kb % BK == 0 &&
-                      p.b_kb % BK == 0 && !(d->flags & (LVT_CAUSAL_KMAX | LVT_CAUSAL_KMIN | LVT_CAUSAL_TILE));
+                      p.b_kb % BK == 0 && a_span < (1LL << 30) && b_span < (1LL << 30) &&
+                      !(d->flags & (LVT_CAUSAL_KMAX | LVT_CAUSAL_KMIN | LVT_CAUSAL_TILE));
     if (wide && d->ta == 0 && d->tb == 0) rc = launch_wide<0, 0>(p, zc, s);
     else if (wide && d->ta == 0 && d->tb == 1) rc = launch_wide<0, 1>(p, zc, s);
     else if (wide) rc = launch_wide<1, 1>(p, zc, s);
@@ -2090,7 +2102,8 @@ extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const floa
         // pipelined kernel (no im2col index arithmetic in the loader, 256-row tiles)
         static const int no_wide = getenv("LVT_NO_WIDE_GEMM") ? 1 : 0;
         if (!no_wide && math_of(flags) == 2 && BK == 32 && g->Kt == 1 && g->Kh == 1 && g->Kw == 1 && g->st == 1 && g->sh == 1 &&
-            g->sw == 1 && g->pt == 0 && g->ph == 0 && g->pw == 0 && g->Ci % BK == 0 && p.M > 128 && lvt_aligned16(x) && lvt_aligned16(wp)) {
+            g->sw == 1 && g->pt == 0 && g->ph == 0 && g->pw == 0 && g->Ci % BK == 0 && p.M > 128 && lvt_aligned16(x) && lvt_aligned16(wp) &&
+            (long long)p.M * g->Ci < (1LL << 30)) {
             p.lda = g->Ci; p.a_kb = p.K; p.b_kb = p.K;
             return launch_wide<0, 1>(p, 1, (hipStream_t)stream);
         }
@@ -2175,7 +2188,8 @@ extern "C" int lvt_conv3d_bwd_data(const lvt_conv_geom *g, const float *dy, cons
         // 1x1x1 / stride 1 / unpadded: dx (M x Ci) = dy (M x Co) . wp^T, wp = (Ci x Co) read k-contiguous -- the wide kernel
         static const int no_wide = getenv("LVT_NO_WIDE_GEMM") ? 1 : 0;
         if (!no_wide && math_of(flags) == 2 && BK == 32 && g->Kt == 1 && g->Kh == 1 && g->Kw == 1 && g->st == 1 && g->sh == 1 &&
-            g->sw == 1 && g->pt == 0 && g->ph == 0 && g->pw == 0 && g->Co % BK == 0 && p.M > 128 && lvt_aligned16(dy) && lvt_aligned16(wp)) {
+            g->sw == 1 && g->pt == 0 && g->ph == 0 && g->pw == 0 && g->Co % BK == 0 && p.M > 128 && lvt_aligned16(dy) && lvt_aligned16(wp) &&
+            (long long)p.M * g->Co < (1LL << 30)) {
             p.lda = g->Co; p.ldb = g->Co; p.a_kb = p.K; p.b_kb = p.K;
             return launch_wide<0, 0>(p, 1, (hipStream_t)stream);
         }

@@ -28,4 +28,12 @@ torch.cuda.synchronize()
 for i in range(steps):
     step(warmup + i)
 torch.cuda.synchronize()
-print("done", which, steps, warmup)
+# engine wrapper calls per step, counted the way bench.py counts them (lvt_amd.hip.binding.KernelTimer keys): what the
+# bench line compares with when it quotes a PMC file of this run (traffic_stale)
+from lvt_amd.hip import binding as L
+L.TIMER = L.KernelTimer()
+step(warmup + steps)
+torch.cuda.synchronize()
+calls = sum(1 for k, _, _, _ in L.TIMER.records if k.startswith(("conv_", "gemm_", "attn_")))
+L.TIMER = None
+print("done", which, steps, warmup, "ENGINE_CALLS_PER_STEP", calls)

@@ -26,7 +26,13 @@ v=json.load(open("$OUT/r04_vqvae_pmc_hbm_traffic.json")); d=json.load(open("$OUT
 # one bench step = 2 VQ-VAE train steps + 1 DSFVT train step; both passes ran 1 + 3 steps
 vb=(2*v["fetch_KiB_raw"]+v["write_KiB"])*1024/v["steps"]; db=(2*d["fetch_KiB_raw"]+d["write_KiB"])*1024/d["steps"]
 vl=v["engine_launches"]/v["steps"]; dl=d["engine_launches"]/d["steps"]
+import re
+calls={wl: int(re.search(r"ENGINE_CALLS_PER_STEP (\d+)", open("/tmp/pf_%s.log" % wl).read()).group(1)) for wl in ("vqvae","dsfvt")}
+for wl, dd in (("vqvae", v), ("dsfvt", d)):
+    dd["engine_calls_per_step"] = calls[wl]; dd["git_head"] = "$HEAD"
+    json.dump(dd, open("$OUT/r04_%s_pmc_hbm_traffic.json" % wl, "w"), indent=1)
 json.dump({"hbm_bytes_per_launch": (2*vb+db)/(2*vl+dl), "engine_launches_per_step": 2*vl+dl, "hbm_bytes_per_step": 2*vb+db,
+           "engine_calls_per_step": 2*calls["vqvae"]+calls["dsfvt"],
            "git_head": "$HEAD",
            "note": "combined bench step = 2 x r04_vqvae_pmc_hbm_traffic.json + 1 x r04_dsfvt_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes)"},
           open("$OUT/r04_combined_pmc_hbm_traffic.json","w"), indent=1)
