@@ -14,8 +14,8 @@ for wl in vqvae dsfvt; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format rocpd -d /tmp/pf_$wl -- $CMD > /tmp/pf_$wl.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format rocpd -d /tmp/pw_$wl -- $CMD > /tmp/pw_$wl.log 2>&1
   python scratch/pmc_summary.py $(find /tmp/pf_$wl -name "*.db" | head -1) $(find /tmp/pw_$wl -name "*.db" | head -1) \
-    $OUT/r04_${wl}_pmc_hbm_traffic.txt $OUT/r04_${wl}_pmc_hbm_traffic.json 4 \
-    "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- $CMD ($wl train step; 1 + 3 steps; round 4, git $HEAD, LVT_MATH=${LVT_MATH:-f16x2})" > /dev/null
+    $OUT/r04_${wl}_pmc_hbm_traffic.txt $OUT/r04_${wl}_pmc_hbm_traffic.json 5 \
+    "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- $CMD ($wl train step; 1 + 3 + 1 steps; round 4, git $HEAD, LVT_MATH=${LVT_MATH:-f16x2})" > /dev/null
 done
 ls -la $OUT/r04_*
 head -32 $OUT/r04_vqvae_kernel_stats.txt | cut -c1-70,97-170
