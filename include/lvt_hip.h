@@ -62,7 +62,10 @@ int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long lon
  * on the bit pattern (exact and order-independent for non-negative floats), so *c must be zeroed (or hold a bound to keep)
  * before the launch; not produced by split-K launches (their consumers are optimizers, not GEMMs).                       */
 typedef struct { const float *a; const float *b; float *c; } lvt_amax_io;
-/* *out = max(*out, max_i |x[i]|): the stand-alone form for tensors that no engine launch produced.                        */
+/* *out = max(*out, max_i |x[i]|) over the FINITE entries of x: the stand-alone form for tensors that no engine launch
+ * produced.  Every max |.| of this interface skips inf / nan entries: such an element makes the products it takes part in
+ * non-finite through its own fp16 high term, exactly where the reference's result is non-finite, and leaves the scale -- and
+ * with it every other row and column of the result -- untouched.                                                          */
 int lvt_amax(const float *x, long long n, float *out, void *stream);
 /* The same for many tensors in one launch per 64 (the weights of a model, once per pass); `entries` is a HOST array.        */
 typedef struct { const float *x; long long n; float *out; } lvt_amax_entry;

@@ -289,7 +289,7 @@ __device__ __forceinline__ float attn_fwd16_body(const PlaneArgs pa, int H, floa
     float am = 0.f;          // max |o| of this lane's stores (reported through o_amax for the f16x2 engine launches downstream)
 #pragma unroll
     for (int dtile = 0; dtile < AT_D / 16; ++dtile)
-        am = fmaxf(am, fmaxf(fmaxf(fabsf(oacc[dtile][0]), fabsf(oacc[dtile][1])), fmaxf(fabsf(oacc[dtile][2]), fabsf(oacc[dtile][3]))));
+        am = fmaxf(am, fmaxf(fmaxf(lvt_absf(oacc[dtile][0]), lvt_absf(oacc[dtile][1])), fmaxf(lvt_absf(oacc[dtile][2]), lvt_absf(oacc[dtile][3]))));
     return am;
 }
 
@@ -475,7 +475,7 @@ __device__ __forceinline__ float attn_bwd_a16_body(const PlaneArgs pa, const uns
     float am = 0.f;          // max |dq| of this lane's stores
 #pragma unroll
     for (int dtile = 0; dtile < AT_D / 16; ++dtile)
-        am = fmaxf(am, fmaxf(fmaxf(fabsf(oacc[dtile][0]), fabsf(oacc[dtile][1])), fmaxf(fabsf(oacc[dtile][2]), fabsf(oacc[dtile][3]))));
+        am = fmaxf(am, fmaxf(fmaxf(lvt_absf(oacc[dtile][0]), lvt_absf(oacc[dtile][1])), fmaxf(lvt_absf(oacc[dtile][2]), lvt_absf(oacc[dtile][3]))));
     // ---- bias-bank gradient of this (sample, head, query half): two fixed-order stages through LDS ----
     float *R = reinterpret_cast<float *>(X);                          // [128 queries][4 kg][NR]
     float *R2 = R + 128 * 4 * NR;                                     // [8 parts][NB]
@@ -636,7 +636,7 @@ __device__ __forceinline__ float attn_bwd_b16_body(const PlaneArgs pa, const uns
 #pragma unroll
     for (int dtile = 0; dtile < AT_D / 16; ++dtile)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) am = fmaxf(am, fmaxf(fabsf(accv[dtile][e]), fabsf(acck[dtile][e])));
+        for (int e = 0; e < 4; ++e) am = fmaxf(am, fmaxf(lvt_absf(accv[dtile][e]), lvt_absf(acck[dtile][e])));
     return am;
 }
 

@@ -45,7 +45,7 @@ __global__ void lvt_to_channels_last_kernel(const float *__restrict__ in, int B,
             if (mode == 1) v = (v - a[c]) / s[c];
         }
         out[i] = v;
-        am = fmaxf(am, fabsf(v));
+        am = fmaxf(am, lvt_absf(v));
     }
     if (out_amax) lvt_block_amax_commit(am, out_amax, amax_scratch);
 }
@@ -159,7 +159,7 @@ __global__ void lvt_mse_bwd_kernel(const float *__restrict__ a, const float *__r
             r.x += z.x; r.y += z.y; r.z += z.z; r.w += z.w;
         }
         reinterpret_cast<float4 *>(out)[i] = r;
-        am = fmaxf(am, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
+        am = fmaxf(am, fmaxf(fmaxf(lvt_absf(r.x), lvt_absf(r.y)), fmaxf(lvt_absf(r.z), lvt_absf(r.w))));
     }
     if (out_amax) lvt_block_amax_commit(am, out_amax, amax_scratch);
 }
@@ -200,7 +200,7 @@ __global__ void lvt_tanh_bwd_kernel(const float *__restrict__ g, const float *__
         const float4 t = reinterpret_cast<const float4 *>(y)[i];
         const float4 r = make_float4(a.x * (1.f - t.x * t.x), a.y * (1.f - t.y * t.y), a.z * (1.f - t.z * t.z), a.w * (1.f - t.w * t.w));
         reinterpret_cast<float4 *>(out)[i] = r;
-        am = fmaxf(am, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
+        am = fmaxf(am, fmaxf(fmaxf(lvt_absf(r.x), lvt_absf(r.y)), fmaxf(lvt_absf(r.z), lvt_absf(r.w))));
     }
     if (out_amax) lvt_block_amax_commit(am, out_amax, amax_scratch);
 }
@@ -286,7 +286,7 @@ __global__ void lvt_layernorm_fwd_kernel(const float *__restrict__ x, long long 
                 o.x = (v[i].x - mean) * rstd * ww.x + bb.x; o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
                 o.z = (v[i].z - mean) * rstd * ww.z + bb.z; o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
                 yp[c] = o;
-                am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+                am = fmaxf(am, fmaxf(fmaxf(lvt_absf(o.x), lvt_absf(o.y)), fmaxf(lvt_absf(o.z), lvt_absf(o.w))));
             }
         }
         if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void lvt_layernorm_bwd_kernel(
                     o.x += z.x; o.y += z.y; o.z += z.z; o.w += z.w;
                 }
                 op[c] = o;
-                am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+                am = fmaxf(am, fmaxf(fmaxf(lvt_absf(o.x), lvt_absf(o.y)), fmaxf(lvt_absf(o.z), lvt_absf(o.w))));
             }
         }
     }
@@ -535,20 +535,20 @@ __global__ __launch_bounds__(256) void lvt_amax_kernel(const float *__restrict__
         const long long step = (long long)gridDim.x * blockDim.x;
         for (; i + step < n4; i += 2 * step) {
             const float4 v = *reinterpret_cast<const float4 *>(x + i * 4), u = *reinterpret_cast<const float4 *>(x + (i + step) * 4);
-            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-            m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fmaxf(fabsf(u.z), fabsf(u.w))));
+            m = fmaxf(m, fmaxf(fmaxf(lvt_absf(v.x), lvt_absf(v.y)), fmaxf(lvt_absf(v.z), lvt_absf(v.w))));
+            m1 = fmaxf(m1, fmaxf(fmaxf(lvt_absf(u.x), lvt_absf(u.y)), fmaxf(lvt_absf(u.z), lvt_absf(u.w))));
         }
         if (i < n4) {
             const float4 v = *reinterpret_cast<const float4 *>(x + i * 4);
-            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            m = fmaxf(m, fmaxf(fmaxf(lvt_absf(v.x), lvt_absf(v.y)), fmaxf(lvt_absf(v.z), lvt_absf(v.w))));
         }
         m = fmaxf(m, m1);
-        for (long long t = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += step) m = fmaxf(m, fabsf(x[t]));
+        for (long long t = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += step) m = fmaxf(m, lvt_absf(x[t]));
     } else {
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-            m = fmaxf(m, fabsf(x[i]));
+            m = fmaxf(m, lvt_absf(x[i]));
     }
-    // (fmaxf drops a NaN; that is fine here: a NaN element poisons the product through its own hi plane)
+    // (lvt_absf: the max is over the FINITE entries; an inf / nan element poisons its products through its own hi term)
     lvt_block_amax_commit(m, out, scratch);
 }
 // the same for up to 64 tensors per launch (the weights of a model, once per pass): blockIdx.y = tensor
@@ -560,10 +560,10 @@ __global__ __launch_bounds__(256) void lvt_amax_multi_kernel(const AmaxTable t) 
     float m = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const float4 v = *reinterpret_cast<const float4 *>(x + i * 4);
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        m = fmaxf(m, fmaxf(fmaxf(lvt_absf(v.x), lvt_absf(v.y)), fmaxf(lvt_absf(v.z), lvt_absf(v.w))));
     }
     for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        m = fmaxf(m, fabsf(x[i]));
+        m = fmaxf(m, lvt_absf(x[i]));
     lvt_block_amax_commit(m, t.out[blockIdx.y], scratch);
 }
 extern "C" int lvt_amax_multi(const lvt_amax_entry *entries, int n, void *stream) {

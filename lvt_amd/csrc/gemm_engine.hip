@@ -775,7 +775,7 @@ __device__ __forceinline__ void lvt_epilogue(const KParams &p, f32x16 (&acc)[BM 
                 float *cp = p.C + coff + orow * p.ldc + col;
                 if (flags & LVT_EPI_ACCUM) v += *cp;
                 *cp = v;
-                am = fmaxf(am, fabsf(v));
+                am = fmaxf(am, lvt_absf(v));
             }
         }
     }
@@ -899,7 +899,7 @@ __device__ __forceinline__ void lvt_epilogue_vec(const KParams &p, f32x16 (&acc)
                         const float4 mk = ldg4(p.mask + coff + orow * p.ldm + col);
                         v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
                     }
-                    if (!(flags & LVT_EPI_ACCUM)) am = fmaxf(am, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                    if (!(flags & LVT_EPI_ACCUM)) am = fmaxf(am, fmaxf(fmaxf(lvt_absf(v.x), lvt_absf(v.y)), fmaxf(lvt_absf(v.z), lvt_absf(v.w))));
                     if (flags & LVT_EPI_PLANES) {
                         // C is a bf16 image: the result leaves as its exact 3-way bf16 split, one plane c_plane elements
                         // after the other (the operand format of the fused attention kernels, attention_pipe.hip)
@@ -913,7 +913,7 @@ __device__ __forceinline__ void lvt_epilogue_vec(const KParams &p, f32x16 (&acc)
                         float4 *cp = reinterpret_cast<float4 *>(p.C + coff + orow * p.ldc + col);
                         if (flags & LVT_EPI_ACCUM) {
                             const float4 c = *cp; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
-                            am = fmaxf(am, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                            am = fmaxf(am, fmaxf(fmaxf(lvt_absf(v.x), lvt_absf(v.y)), fmaxf(lvt_absf(v.z), lvt_absf(v.w))));
                         }
                         *cp = v;
                     }

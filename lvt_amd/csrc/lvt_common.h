@@ -38,6 +38,12 @@ static inline __host__ __device__ long long lvt_cdiv(long long a, long long b) {
 // on this part, 8192 of them cost a stand-alone pass 50 us.  `scratch`: >= blockDim.x / 64 floats of LDS that every
 // thread may overwrite; all threads of the workgroup must call.
 #ifdef __HIPCC__
+// |a| of a FINITE a, else 0: the max |.| of an operand is taken over its finite entries -- an inf / nan element poisons the
+// products it takes part in through its own fp16 hi term (inf * s = inf), and must not collapse the scale of all the others
+__device__ __forceinline__ float lvt_absf(float a) {
+    const float b = fabsf(a);
+    return b < __builtin_inff() ? b : 0.f;
+}
 __device__ __forceinline__ void lvt_block_amax_commit(float m, float *dst, float *scratch) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
