@@ -284,3 +284,35 @@ def test_bench_self_launches_one_rank_per_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 1" in (r.stderr + r.stdout)
+
+
+def test_relu_decision_matching_helper_on_a_toy_network():
+    """tests/util_relu.py (the gradient comparison that is exact about ReLU units sitting on their threshold) on a two-layer
+    network with one planted undecided unit: a gradient that differs from fp64 only through that unit's decision is accepted
+    and the unit is named; the same gradient with a genuine error is rejected; reported decisions are matched exactly."""
+    from util_relu import ReluProbe, assert_grads_match, assert_grads_match_decisions, relu_probe
+    torch.manual_seed(0)
+    W1, W2, x = torch.randn(64, 32), torch.randn(8, 64), torch.randn(200, 32)
+    pre = x @ W1.t()
+    i, j = 5, 7
+    x[i] += (-pre[i, j] + 1e-8 * float(pre.abs().max())) * W1[j] / W1[j].dot(W1[j])        # pre-activation (i, j) ~ 1e-8 of the max
+
+    def run(dtype):
+        w1, w2 = W1.clone().to(dtype).requires_grad_(True), W2.clone().to(dtype).requires_grad_(True)
+        (torch.relu(x.to(dtype) @ w1.t()) @ w2.t()).pow(2).sum().backward()
+        return {"w1": w1.grad, "w2": w2.grad}
+
+    with relu_probe(ReluProbe(force={(0, (i, j)): False}, record=True)) as pr:
+        flipped = {k: v.float() for k, v in run(torch.float64).items()}
+    n, units = assert_grads_match(flipped, run, ["w1", "w2"])
+    assert n >= 1 and [(u[0], u[1]) for u in units] == [(0, (i, j))]
+    assert assert_grads_match({k: v.float() for k, v in run(torch.float64).items()}, run, ["w1", "w2"]) == (0, [])
+    masks = [m.clone() for m in pr.masks]
+    masks[0][i, j] = False                                             # what the path under test reports: unit (i, j) blocked
+    assert assert_grads_match_decisions(flipped, masks, run, ["w1", "w2"]) == (1, 0)
+    wrong = {k: v.clone() for k, v in flipped.items()}
+    wrong["w1"][0, 0] += 1.0
+    with pytest.raises(AssertionError):
+        assert_grads_match(wrong, run, ["w1", "w2"])
+    with pytest.raises(AssertionError):
+        assert_grads_match_decisions(wrong, masks, run, ["w1", "w2"])
