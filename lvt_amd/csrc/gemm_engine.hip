@@ -1547,7 +1547,9 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void lvt_gemm_wide_kernel(const KP
     int kt = 0;
     for (; kt + 2 < ntiles; ++kt) {
         tile(S0 + (kt & 1) * STAGE, S0 + ((kt + 1) & 1) * STAGE, yes_t(), yes_t());
+#ifndef LVT_WX_NOBARRIER    // (timing experiment, wrong results)
         __syncthreads();
+#endif
     }
     if (kt + 1 < ntiles) {
         tile(S0 + (kt & 1) * STAGE, S0 + ((kt + 1) & 1) * STAGE, yes_t(), no_t());
