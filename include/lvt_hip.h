@@ -372,10 +372,15 @@ int lvt_sample_categorical(const float *logits, long long rows, int V, float tem
 int lvt_embbag_fwd(const long long *idx, long long bstride, int P, long long rows, int nslots,
                    const int *slot_off, const int *tab_row, const float *table, int D, const float *bias,
                    const float *btable, const long long *bindex, float *out, void *stream);
-/* gradient of the tables: out[(s*V + code)][n] = sum_rows [idx(row,s) == code] * dout[row][n], executed as a
- * transposed one-hot GEMM on the matrix cores (deterministic split-K), idx(row,s) =
- * idx[b*bstride + off[s] + pos*pstride], row = b*P + pos.                                              */
+/* gradient of the tables: out[(s*V + code)][n] = sum_rows [idx(row,s) == code] * dout[row][n], idx(row,s) =
+ * idx[b*bstride + off[s] + pos*pstride], row = b*P + pos.  Tables of >= 512 rows with N in {64,128,256,512} are
+ * summed by a gather (one wave per output row adds its rows in ascending order: exact fp32 sums in a fixed order, no
+ * atomics, flags' math mode and dout_amax unused); the others, and every call carrying LVT_ONEHOT_DENSE, run as a
+ * transposed one-hot GEMM on the matrix cores (deterministic split-K).  Indices outside [0, V) contribute nothing. */
+#define LVT_ONEHOT_DENSE (1 << 19)
 size_t lvt_onehot_tn_workspace_bytes(int nslots, int V, int N, long long rows);
+/* 1 when lvt_onehot_tn_gemm sums this shape by the gather (callers that account matrix-core work ask)  */
+int lvt_onehot_tn_is_gather(int nslots, int V, int N, long long ldb, const float *dout, int flags);
 int lvt_onehot_tn_gemm(const long long *idx, int nslots, int V, const int *slot_off, long long bstride,
                        long long pstride, int P, long long rows, const float *dout, long long ldb, int N,
                        float *out, int flags, const float *dout_amax, void *workspace, size_t workspace_bytes,

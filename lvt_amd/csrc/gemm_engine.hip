@@ -2311,6 +2311,10 @@ extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, con
 }
 
 // ---- one-hot transposed GEMM (embedding / one-hot-linear weight gradients) ----------------------------
+// (tables with enough rows go to the gather in transformer.hip: exact fp32 sums in row order, no zero multiplies)
+bool lvt_onehot_gather_ok(int nslots, int V, int N, long long ldb, const float *dout);
+int lvt_onehot_gather_launch(const long long *idx, int nslots, int V, const int *slot_off, long long bstride, long long pstride,
+                             int P, long long rows, const float *dout, long long ldb, int N, float *out, hipStream_t s);
 static int onehot_splits(int M, int N, long long rows) {
     const long long tiles = lvt_cdiv(M, 128) * lvt_cdiv(N, 128);
     const int s = choose_splits(tiles, (int)rows, 512);
@@ -2318,6 +2322,9 @@ static int onehot_splits(int M, int N, long long rows) {
 }
 extern "C" size_t lvt_onehot_tn_workspace_bytes(int nslots, int V, int N, long long rows) {
     return (size_t)onehot_splits(nslots * V, N, rows) * nslots * V * (size_t)N * sizeof(float);
+}
+extern "C" int lvt_onehot_tn_is_gather(int nslots, int V, int N, long long ldb, const float *dout, int flags) {
+    return !(flags & LVT_ONEHOT_DENSE) && lvt_onehot_gather_ok(nslots, V, N, ldb, dout);
 }
 extern "C" int lvt_onehot_tn_gemm(const long long *idx, int nslots, int V, const int *slot_off, long long bstride,
                                   long long pstride, int P, long long rows, const float *dout, long long ldb, int N,
@@ -2332,6 +2339,8 @@ extern "C" int lvt_onehot_tn_gemm(const long long *idx, int nslots, int V, const
         lvt_set_error("onehot_tn_gemm: workspace %zu < %zu", workspace_bytes, need);
         return LVT_EWORKSPACE;
     }
+    if (lvt_onehot_tn_is_gather(nslots, V, N, ldb, dout, flags))
+        return lvt_onehot_gather_launch(idx, nslots, V, slot_off, bstride, pstride, P, rows, dout, ldb, N, out, (hipStream_t)stream);
     KParams p; memset(&p, 0, sizeof(p));
     p.M = nslots * V; p.N = N; p.K = (int)rows;
     LVT_REQUIRE(math_of(flags) != 2 || dout_amax, "onehot_tn_gemm: LVT_MATH_F16X2 needs dout_amax");

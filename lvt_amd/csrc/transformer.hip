@@ -290,6 +290,160 @@ extern "C" int lvt_embbag_fwd(const long long *idx, long long bstride, int P, lo
     return LVT_OK;
 }
 
+// ---- embedding-bag weight gradient as a gather --------------------------------------------------------
+// dTable[(slot, code)][:] = sum over the rows whose index in that slot equals `code` of dOut[row][:]
+// (the weight gradient of the one-hot Conv3d / Embedding / one-hot Linear inputs, videotransformer.py:41-57, 80-89,
+// 139-160).  As a dense one-hot GEMM this is 2*nslots*V*N*rows flops of which one in V is not a multiply by zero; here
+// every output row is owned by one wave, which adds its rows in ascending order (a fixed order, no atomics: bit-
+// reproducible) - nslots*rows*N additions in all.
+//   workgroup = 8 waves x CPW codes of one slot.  The slot's indices stream through LDS in 1024-row chunks (double
+//   buffered, one barrier per chunk, the next chunk's indices already in flight); each wave compares a 64-row
+//   group against its codes with one ballot per code and appends the hits to a per-(wave, code) row list in LDS.
+//   The lists are drained eight rows at a time - eight independent row loads in flight per wave instead of one load
+//   per hit, which is what a hit-by-hit loop would be bound by - and the rows are added in list (= row) order.
+#define OHG_WAVES 8
+#define OHG_CHUNK 1024
+#define OHG_CAP 128
+struct OhSlots { int n; int off[32]; };
+
+template <int NV, int CPW>
+__global__ __launch_bounds__(OHG_WAVES * 64) void lvt_onehot_gather_kernel(
+    const long long *__restrict__ idx, OhSlots sl, int V, long long bstride, long long pstride, int P, int rows,
+    const float *__restrict__ dout, long long ldb, float *__restrict__ out) {
+    constexpr int VW = NV >= 4 ? 4 : NV, NVEC = NV / VW, N = NV * 64, NT = OHG_WAVES * 64, PER = OHG_CHUNK / NT;
+    __shared__ int codes[2][OHG_CHUNK];
+    __shared__ int hits[OHG_WAVES][CPW][OHG_CAP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int code0 = (blockIdx.x * OHG_WAVES + wave) * CPW;
+    const long long *ip = idx + sl.off[blockIdx.y];
+
+    float acc[CPW][NV];
+    int cnt[CPW];
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+        cnt[u] = 0;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) acc[u][e] = 0.f;
+    }
+    auto fetch = [&](int row) -> int {
+        if (row >= rows) return -1;
+        const int b = row / P, pos = row - b * P;
+        const long long c = ip[b * bstride + pos * pstride];
+        return (c >= 0 && c < V) ? (int)c : -1;
+    };
+    auto drain = [&](int u) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");       // the list was written by other lanes of this wave
+        const int *h = hits[wave][u];
+        const int n = cnt[u];                                        // wave-uniform
+        for (int j = 0; j < n; j += 8) {
+            float v[8][NV];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (j + t < n) {
+                    const float *src = dout + (long long)h[j + t] * ldb;
+#pragma unroll
+                    for (int q = 0; q < NVEC; ++q) {
+                        const float *s = src + (q * 64 + lane) * VW;
+                        if constexpr (VW == 4) {
+                            const float4 f = *reinterpret_cast<const float4 *>(s);
+                            v[t][q * 4] = f.x; v[t][q * 4 + 1] = f.y; v[t][q * 4 + 2] = f.z; v[t][q * 4 + 3] = f.w;
+                        } else if constexpr (VW == 2) {
+                            const float2 f = *reinterpret_cast<const float2 *>(s);
+                            v[t][0] = f.x; v[t][1] = f.y;
+                        } else {
+                            v[t][0] = *s;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (j + t < n) {
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) acc[u][e] += v[t][e];
+                }
+        }
+        cnt[u] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");       // reads done before the list is appended to again
+    };
+
+    int nxt[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) nxt[e] = fetch(e * NT + tid);
+    int it = 0;
+    for (int r0 = 0; r0 < rows; r0 += OHG_CHUNK, ++it) {
+        int *cb = codes[it & 1];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) cb[e * NT + tid] = nxt[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < PER; ++e) nxt[e] = fetch(r0 + OHG_CHUNK + e * NT + tid);
+        for (int g = 0; g < OHG_CHUNK / 64; ++g) {
+            const int c = cb[g * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < CPW; ++u) {
+                const bool hit = c == code0 + u;
+                const unsigned long long m = __ballot(hit);
+                if (m) {
+                    if (hit) hits[wave][u][cnt[u] + __popcll(m & ((1ull << lane) - 1ull))] = r0 + g * 64 + lane;
+                    cnt[u] += __popcll(m);
+                    if (cnt[u] > OHG_CAP - 64) drain(u);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+        drain(u);
+        if (code0 + u < V) {
+            float *dst = out + ((long long)blockIdx.y * V + code0 + u) * N;
+#pragma unroll
+            for (int q = 0; q < NVEC; ++q) {
+                float *d = dst + (q * 64 + lane) * VW;
+                if constexpr (VW == 4)
+                    *reinterpret_cast<float4 *>(d) = make_float4(acc[u][q * 4], acc[u][q * 4 + 1], acc[u][q * 4 + 2], acc[u][q * 4 + 3]);
+                else if constexpr (VW == 2)
+                    *reinterpret_cast<float2 *>(d) = make_float2(acc[u][0], acc[u][1]);
+                else
+                    *d = acc[u][0];
+            }
+        }
+    }
+}
+
+// the gather needs enough output rows to fill the chip (one wave per output row); the few-row tables (class and
+// slice embeddings, V = 16 .. 32) stay on the split-K one-hot GEMM
+bool lvt_onehot_gather_ok(int nslots, int V, int N, long long ldb, const float *dout) {
+    return (N == 64 || N == 128 || N == 256 || N == 512) && (long long)nslots * V >= 512 && ldb % 4 == 0 && lvt_aligned16(dout);
+}
+template <int NV>
+static void ohg_launch(bool two, dim3 grid, hipStream_t s, const long long *idx, const OhSlots &sl, int V, long long bstride,
+                       long long pstride, int P, int rows, const float *dout, long long ldb, float *out) {
+    if (two)
+        hipLaunchKernelGGL((lvt_onehot_gather_kernel<NV, 2>), grid, dim3(OHG_WAVES * 64), 0, s, idx, sl, V, bstride, pstride, P,
+                           rows, dout, ldb, out);
+    else
+        hipLaunchKernelGGL((lvt_onehot_gather_kernel<NV, 1>), grid, dim3(OHG_WAVES * 64), 0, s, idx, sl, V, bstride, pstride, P,
+                           rows, dout, ldb, out);
+}
+int lvt_onehot_gather_launch(const long long *idx, int nslots, int V, const int *slot_off, long long bstride, long long pstride,
+                             int P, long long rows, const float *dout, long long ldb, int N, float *out, hipStream_t s) {
+    OhSlots sl; sl.n = nslots;
+    for (int i = 0; i < nslots; ++i) sl.off[i] = slot_off[i];
+    // two codes per wave once that still leaves >= 512 workgroups (half the index scans per output row; measured at 16384
+    // rows x 128: 28 slots x 512 codes 84 us with one code per wave - 1792 workgroups, 1.75 rounds of the chip - 32 slots 69 us)
+    const bool two = (long long)nslots * lvt_cdiv(V, OHG_WAVES * 2) >= 512;
+    const dim3 grid((unsigned)lvt_cdiv(V, OHG_WAVES * (two ? 2 : 1)), (unsigned)nslots);
+    switch (N) {
+    case 64: ohg_launch<1>(two, grid, s, idx, sl, V, bstride, pstride, P, (int)rows, dout, ldb, out); break;
+    case 128: ohg_launch<2>(two, grid, s, idx, sl, V, bstride, pstride, P, (int)rows, dout, ldb, out); break;
+    case 256: ohg_launch<4>(two, grid, s, idx, sl, V, bstride, pstride, P, (int)rows, dout, ldb, out); break;
+    default: ohg_launch<8>(two, grid, s, idx, sl, V, bstride, pstride, P, (int)rows, dout, ldb, out); break;
+    }
+    LVT_CHECK_LAUNCH("lvt_onehot_gather_kernel");
+    return LVT_OK;
+}
+
 // out[d2][d1][d0] (contiguous) = in[i0*s0 + i1*s1 + i2*s2] : generic 3-D permute for weight re-layouts
 __global__ void lvt_permute3_kernel(const float *__restrict__ in, long long s0, long long s1, long long s2, int n0,
                                     int n1, int n2, float *__restrict__ out) {

@@ -17,6 +17,7 @@ CAUSAL_KMAX, CAUSAL_KMIN, CAUSAL_TILE = 1 << 8, 1 << 9, 1 << 10      # causal at
 ABI_VERSION = 400           # lvt_version() of the library this module binds (argument lists below)
 MATH_F32 = 1 << 16          # per-call arithmetic selectors of the engine entry points (include/lvt_hip.h)
 MATH_F16X2 = 1 << 18
+ONEHOT_DENSE = 1 << 19
 
 
 class LvtError(RuntimeError):
@@ -130,6 +131,7 @@ def _declare(lib):
         "lvt_sample_categorical": (ci, [vp, cll, ci, cf, vp, vp, cll, vp, vp, cll, vp]),
         "lvt_embbag_fwd": (ci, [vp, cll, ci, cll, ci, P(ci), P(ci), vp, ci, vp, vp, vp, vp, vp]),
         "lvt_onehot_tn_workspace_bytes": (sz, [ci, ci, ci, cll]),
+        "lvt_onehot_tn_is_gather": (ci, [ci, ci, ci, cll, vp, ci]),
         "lvt_onehot_tn_gemm": (ci, [vp, ci, ci, P(ci), cll, cll, ci, cll, vp, cll, ci, vp, ci, vp, vp, sz, vp]),
         "lvt_permute3": (ci, [vp, cll, cll, cll, ci, ci, ci, vp, vp]),
         "lvt_row_gather": (ci, [vp, vp, cll, ci, ci, vp, vp]),

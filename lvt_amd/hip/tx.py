@@ -118,29 +118,36 @@ def embbag_fwd(idx, bstride, P, rows, slot_off, tab_row, table, D, bias=None, bt
     return out
 
 
-def _onehot_once(idx, V, slot_off, bstride, pstride, P, rows, dout, N, ldb):
+def _onehot_once(idx, V, slot_off, bstride, pstride, P, rows, dout, N, ldb, dense):
     lib = L.lib()
     ns = len(slot_off)
     out = torch.empty(ns * V, N, dtype=torch.float32, device=dout.device)
     nws = lib.lvt_onehot_tn_workspace_bytes(ns, V, N, rows)
     ws = L.workspace(nws, dout.device, "onehot")
+    ldb = ldb if ldb is not None else N
+    flags = L.math_flag() | (L.ONEHOT_DENSE if dense else 0)
+    gather = bool(lib.lvt_onehot_tn_is_gather(ns, V, N, ldb, L.ptr(dout), flags))
     t0 = L.TIMER.begin() if L.TIMER is not None else None
-    L.check(lib.lvt_onehot_tn_gemm(L.ptr(idx), ns, V, _iarr(slot_off), bstride, pstride, P, rows, L.ptr(dout),
-                                   ldb if ldb is not None else N, N, L.ptr(out), L.math_flag(),
-                                   L.ptr(L.amax_of(dout)) if L.f16x2() else None, L.ptr(ws), nws, L.stream_ptr()),
+    L.check(lib.lvt_onehot_tn_gemm(L.ptr(idx), ns, V, _iarr(slot_off), bstride, pstride, P, rows, L.ptr(dout), ldb, N,
+                                   L.ptr(out), flags, L.ptr(L.amax_of(dout)) if (L.f16x2() and not gather) else None,
+                                   L.ptr(ws), nws, L.stream_ptr()),
             "lvt_onehot_tn_gemm")
     if t0 is not None:
-        L.TIMER.end("gemm_onehot_tn", 2.0 * ns * V * N * rows, t0)
+        if gather:
+            L.TIMER.end("embbag_wgrad_gather", 0.0, t0)     # row sums: no matrix-core work to account
+        else:
+            L.TIMER.end("gemm_onehot_tn", 2.0 * ns * V * N * rows, t0)
     return out
 
 
-def onehot_tn_gemm(idx, V, slot_off, bstride, pstride, P, rows, dout, N, ldb=None):
-    """-> (nslots*V, N) gradient of the gathered table."""
+def onehot_tn_gemm(idx, V, slot_off, bstride, pstride, P, rows, dout, N, ldb=None, dense=False):
+    """-> (nslots*V, N) gradient of the gathered table (dense=True: always the one-hot GEMM on the matrix cores)."""
     L.require(idx, dout)
     if len(slot_off) <= MAX_SLOTS:
-        return _onehot_once(idx, V, slot_off, bstride, pstride, P, rows, dout, N, ldb)
-    return torch.cat([_onehot_once(idx, V, slot_off[s:s + MAX_SLOTS], bstride, pstride, P, rows, dout, N, ldb)
+        return _onehot_once(idx, V, slot_off, bstride, pstride, P, rows, dout, N, ldb, dense)
+    return torch.cat([_onehot_once(idx, V, slot_off[s:s + MAX_SLOTS], bstride, pstride, P, rows, dout, N, ldb, dense)
                       for s in range(0, len(slot_off), MAX_SLOTS)], 0)
+
 
 
 def permute3(x, strides, shape):

@@ -94,6 +94,41 @@ def test_embbag_and_onehot_grad():
     assert rel_err(gb, refb) < 1e-5
 
 
+@pytest.mark.parametrize("N,ns,nv,b,P,pstride,ldb", [
+    (64, 1, 512, 5, 300, 1, 64),          # one code per wave; rows (1500) not a multiple of the 1024-row chunk
+    (128, 32, 512, 2, 1024, 1, 128),      # two codes per wave (>= 512 workgroups)
+    (256, 3, 520, 3, 256, 2, 320),        # V not a multiple of the 8 codes of a workgroup, strided positions, padded rows
+    (512, 4, 512, 4, 1024, 1, 512),       # the DSFVT decoder table
+])
+def test_onehot_gather_is_the_row_ordered_fp32_sum(N, ns, nv, b, P, pstride, ldb):
+    """The gather behind lvt_onehot_tn_gemm adds the rows of one (slot, code) in ascending row order in fp32: bit-equal
+    to numpy's sequential np.add.at, whatever the tiling.  Covers indices outside [0, V) (no contribution), a code
+    that owns every row of a slot (the hit list drains at capacity) and codes that own none (zero rows written)."""
+    import numpy as np
+    from lvt_amd.hip import binding as L, tx
+    g = torch.Generator().manual_seed(N + ns)
+    idx = torch.randint(-2, nv + 3, (b, ns, P * pstride), generator=g)
+    idx[:, 0] = 7                                                      # a hot code: all rows of slot 0
+    if ns > 1:
+        idx[:, 1] = torch.randint(0, 3, (b, P * pstride), generator=g)   # codes 3.. of slot 1 own nothing
+    dout = torch.randn(b * P, ldb, generator=g) * torch.logspace(-3, 3, b * P)[:, None]
+    off = [k * P * pstride for k in range(ns)]
+    lib = L.lib()
+    assert lib.lvt_onehot_tn_is_gather(ns, nv, N, ldb, L.ptr(dout.to(DEV)), 0) == 1
+    got = tx.onehot_tn_gemm(idx.to(DEV), nv, off, ns * P * pstride, pstride, P, b * P, dout.to(DEV), N, ldb=ldb)
+    ref = np.zeros((ns * nv, N), np.float32)
+    d = dout[:, :N].numpy()
+    for k in range(ns):
+        code = idx[:, k, ::pstride].reshape(-1).numpy()
+        m = (code >= 0) & (code < nv)
+        np.add.at(ref, k * nv + code[m], d[m])
+    assert torch.equal(got.cpu(), torch.from_numpy(ref))
+    again = tx.onehot_tn_gemm(idx.to(DEV), nv, off, ns * P * pstride, pstride, P, b * P, dout.to(DEV), N, ldb=ldb)
+    assert torch.equal(got, again)
+    dense = tx.onehot_tn_gemm(idx.to(DEV), nv, off, ns * P * pstride, pstride, P, b * P, dout.to(DEV), N, ldb=ldb, dense=True)
+    assert rel_err(dense, got) < 1e-5
+
+
 def test_xent_fwd_bwd():
     from lvt_amd.hip import tx
     b, nc, P, V = 3, 4, 256, 512
