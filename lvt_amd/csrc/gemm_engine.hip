@@ -192,6 +192,12 @@ template <int ROWS, int LEAN = 0> __device__ __forceinline__ void store_split2_k
     *reinterpret_cast<uint2 *>(d) = ph;
     *reinterpret_cast<uint2 *>(d + HPlane<ROWS>::SIZE) = pl;
 }
+// (timing experiments LVT_WX_ARAW / LVT_WX_BRAW: the operand arrives as ready fp16 planes -- same bytes, no arithmetic)
+template <int ROWS> __device__ __forceinline__ void store_raw2_k(unsigned short *lds, int row, int k4, const float4 v) {
+    unsigned short *d = lds + hrow<ROWS>(row) + k4;
+    *reinterpret_cast<uint2 *>(d) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+    *reinterpret_cast<uint2 *>(d + HPlane<ROWS>::SIZE) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+}
 template <int ROWS, int LEAN = 0> __device__ __forceinline__ void store_split2_m(unsigned short *lds, int row4, int k, const float4 v, float s) {
     uint2 p[2];
     if (LEAN) split2_lean(v, s, p[0], p[1]);
@@ -1457,13 +1463,21 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void lvt_gemm_wide_kernel(const KP
         unsigned short *Ah = buf, *Bh = buf + 2 * PSA;
         if (!TA) {
 #pragma unroll
+#ifdef LVT_WX_ARAW
+            for (int i = 0; i < 4; ++i) store_raw2_k<BM>(Ah, r0 + 64 * i, kq * 4, av[i]);
+#else
             for (int i = 0; i < 4; ++i) store_split2_k<BM>(Ah, r0 + 64 * i, kq * 4, av[i], sa);
+#endif
         } else {
             store_split2_block<BM>(Ah, mq * 4, kk0 * 4, av, sa);
         }
         if (!TB) {
 #pragma unroll
+#ifdef LVT_WX_BRAW
+            for (int i = 0; i < 2; ++i) store_raw2_k<BN>(Bh, r0 + 64 * i, kq * 4, bv[i]);
+#else
             for (int i = 0; i < 2; ++i) store_split2_k<BN>(Bh, r0 + 64 * i, kq * 4, bv[i], sb);
+#endif
         } else if (bact) {
             store_split2_block<BN>(Bh, bnq * 4, bkk0 * 4, bv, sb);
         }

@@ -17,7 +17,7 @@ def timeit(fn, n=30):
 r = lambda *s: torch.randn(*s, device=dev)
 M = 16384
 out = []
-for (N, K, tb, ta, name) in [(512, 512, 0, 0, "NT K=512"), (512, 3072, 0, 0, "NT K=3072"), (1024, 512, 1, 0, "NN N=1024"), (512, 512, 1, 1, "TN wgrad")]:
+for (N, K, tb, ta, name) in [(512, 512, 0, 0, "NT K=512"), (512, 3072, 0, 0, "NT K=3072"), (3072, 512, 0, 0, "NT N=3072 K=512"), (1536, 512, 0, 0, "NT N=1536 K=512"), (1024, 512, 1, 0, "NN N=1024"), (512, 512, 1, 1, "TN wgrad")]:
     if ta == 0:
         A, B, C = r(M, K), (r(N, K) if tb == 0 else r(K, N)), torch.empty(M, N, device=dev)
         t = timeit(lambda: G.gemm(A, B, C, M, N, K, tb=tb))
