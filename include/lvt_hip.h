@@ -213,9 +213,9 @@ int lvt_conv3d_bwd_data(const lvt_conv_geom *g, const float *dy, const float *wp
  * db (nullable, Co_real floats) = sum_pixels dy: the bias gradient, accumulated from the dy tiles the kernel streams
  * anyway (no second pass over dy).                                                                         */
 size_t lvt_conv3d_bwd_weight_workspace_bytes(const lvt_conv_geom *g);
-/* 1 when lvt_conv3d_bwd_weight can also produce db for this geometry.  The 3x3 / pad 1 layers of 16x16 frames with 256
- * channels on one side run on the frame-resident weight-gradient kernel (csrc/conv_wgrad.hip: patch and dy row staged once
- * per frame / image row, taps are row offsets of a transposing LDS read); pass db == NULL there and use lvt_colsum(dy). */
+/* 1 when lvt_conv3d_bwd_weight can also produce db for this geometry: every served geometry (since ABI 400 the frame-
+ * resident weight-gradient kernels of csrc/conv_wgrad.hip -- 3x3 / pad 1 layers of 16x16 frames and the 4x4 / stride 2 layer
+ * with 256 channels on one side -- sum the dy rows / patches they stage as well).  Kept for callers written against 300.  */
 int lvt_conv3d_bwd_weight_fuses_bias(const lvt_conv_geom *g, int flags);
 /* flags: 0, LVT_MATH_F32 or LVT_MATH_F16X2 (ax->a = max |x|, ax->b = max |dy|; ax may be NULL otherwise).  The
  * frame-resident kernel keeps the fp16 low term UNSCALED in f16x2 mode (one accumulator set for nine taps): full 22-bit

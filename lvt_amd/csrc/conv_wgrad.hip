@@ -37,6 +37,10 @@ struct WgParams {
     int Cp, N, frames_per_split, nchunks;
     float *partial; long long partial_stride;
     const float *p_amax, *q_amax;        // MATH == 2: max |P|, max |Q| (device scalars)
+    // bias gradient = column sums of dy, accumulated from the dy tiles as they are staged (each element is staged exactly once per
+    // workgroup that sums): sum_mode 1: dy is the slab operand, the workgroup of chunk 0 (class 0) of every split sums all 256
+    // channels; 2: dy is the patch operand, every workgroup sums its own 32 channels.  colsum_partial[split][channel].
+    int sum_mode; float *colsum_partial;
 };
 // MODE 0: 3x3 / stride 1 / pad 1 on 16x16 frames: nine taps over the 18x18 patch, as described above.
 // MODE 1: 4x4 / stride 2 / pad 1 between a 32x32 frame (patch operand, Cp channels) and a 16x16 frame (slab operand, 256
@@ -126,6 +130,9 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
 
     constexpr int PUNITS = WG_PIX * 8, PPASS = (PUNITS + WG_THREADS - 1) / WG_THREADS;
     float4 pv[PPASS], qv[2];
+    // (a thread stages the same channel quad of every pixel it touches: tid & 63 of the slab, tid & 7 of the patch)
+    const bool sum_q = p.sum_mode == 1 && pc == 0 && cls == 0, sum_p = p.sum_mode == 2;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
     auto patch_fetch = [&](int f) {
         const float *xf = p.P + (long long)f * (MODE == 1 ? 1024 : 256) * Cp + pc * 32;
 #pragma unroll
@@ -148,6 +155,7 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
         for (int j = 0; j < PPASS; ++j) {
             const int u = tid + WG_THREADS * j;
             if (u < PUNITS) {
+                if (MODE == 0 && sum_p) { cs.x += pv[j].x; cs.y += pv[j].y; cs.z += pv[j].z; cs.w += pv[j].w; }    // (halo: zeros)
                 unsigned short *d = patch + (u >> 3) * WG_PP + (u & 7) * 4;
                 if (MATH == 2) {
                     uint2 ph, pl;
@@ -170,6 +178,10 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
         for (int j = 0; j < 2; ++j) qv[j] = *reinterpret_cast<const float4 *>(src + (tid + WG_THREADS * j) * 4);
     };
     auto slab_store = [&](unsigned short *slab) {
+        if (sum_q) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { cs.x += qv[j].x; cs.y += qv[j].y; cs.z += qv[j].z; cs.w += qv[j].w; }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int u = tid + WG_THREADS * j;
@@ -277,6 +289,23 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
             buf ^= 1;
         }
     }
+    if (sum_q || sum_p) {
+        // threads that staged the same channel quad are combined in thread order through LDS (every wave is past the last barrier
+        // of the loop, the operand images are dead): a fixed order
+        float *scratch = reinterpret_cast<float *>(lds);
+        *reinterpret_cast<float4 *>(&scratch[tid * 4]) = cs;              // slab: [wave][quad 0..63]; patch: [tid >> 3][quad 0..7]
+        __syncthreads();
+        if (sum_q && tid < WG_CQ) {
+            float t = 0.f;
+            for (int w = 0; w < WG_THREADS / 64; ++w) t += scratch[(w * 64 + (tid >> 2)) * 4 + (tid & 3)];
+            p.colsum_partial[(long long)split * WG_CQ + tid] = t;
+        }
+        if (sum_p && tid < 32) {
+            float t = 0.f;
+            for (int i = 0; i < WG_THREADS / 8; ++i) t += scratch[(i * 8 + (tid >> 2)) * 4 + (tid & 3)];
+            p.colsum_partial[(long long)split * Cp + pc * 32 + tid] = t;
+        }
+    }
     // partial[split][tap * Cp + pc * 32 + m][32 * wave + n]: lane = column n, 16 rows m per register file
     float *out = p.partial + (long long)split * p.partial_stride + (long long)(pc * 32) * WG_CQ + wave * 32 + (lane & 31);
 #pragma unroll
@@ -309,6 +338,18 @@ __global__ void lvt_unpack_wgrad_swapped_kernel(const float *__restrict__ partia
     }
 }
 
+// db[c] = sum over the splits of colsum_partial[split][c]: one wave per channel, lanes over the splits, butterfly (a fixed tree)
+__global__ void lvt_wgrad_bias_reduce_kernel(const float *__restrict__ colsum_partial, int splits, int C, int Co_real,
+                                             float *__restrict__ db) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (c >= Co_real) return;
+    float s = 0.f;
+    for (int k = lane; k < splits; k += 64) s += colsum_partial[(long long)k * C + c];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) db[c] = s;
+}
+
 // ---- host side (called from lvt_conv3d_bwd_weight in gemm_engine.hip) -----------------------------------------------
 // 0: not served; 1: 3x3, patch = x / slab = dy; 2: 3x3 swapped; 3: 4x4 stride 2, patch = x (32x32 frames) / slab = dy (256 ch)
 static int wg_role(const lvt_conv_geom *g, int flags = 0) {
@@ -335,12 +376,12 @@ int lvt_wgrad_frames_role(const lvt_conv_geom *g, int flags) { return wg_role(g,
 size_t lvt_wgrad_frames_workspace_bytes(const lvt_conv_geom *g) {
     const int role = wg_role(g);
     if (!role) return 0;
-    return (size_t)wg_splits(g, role) * g->Kh * g->Kw * g->Ci * g->Co * sizeof(float);
+    return (size_t)wg_splits(g, role) * ((size_t)g->Kh * g->Kw * g->Ci * g->Co + g->Co) * sizeof(float);     // + the bias partials
 }
 int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, int Ci_real, int Co_real,
                             void *workspace, hipStream_t s, void (*unpack_plain)(const float *, long long, int, float *,
                                                                                  const lvt_conv_geom *, int, int, hipStream_t),
-                            const float *x_amax, const float *dy_amax) {
+                            const float *x_amax, const float *dy_amax, float *db) {
     const int role = wg_role(g);
     const bool f16 = x_amax && dy_amax;                  // LVT_MATH_F16X2 (checked by the caller)
     WgParams p;
@@ -350,6 +391,8 @@ int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float 
     const int splits = wg_splits(g, role);
     p.frames_per_split = (g->N + splits - 1) / splits;
     p.partial = (float *)workspace; p.partial_stride = (long long)g->Kh * g->Kw * g->Ci * g->Co;
+    p.sum_mode = db ? (role == 2 ? 2 : 1) : 0;             // dy is the patch operand in role 2, the slab (256 = Co channels) otherwise
+    p.colsum_partial = p.partial + (long long)splits * p.partial_stride;
     if (role == 3 && f16)
         hipLaunchKernelGGL((lvt_conv_wgrad_frames_kernel<1, 2>), dim3((unsigned)(4 * p.nchunks * splits)), dim3(WG_THREADS), 0, s, p);
     else if (role == 3)
@@ -367,5 +410,10 @@ int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float 
                            dim3(256), 0, s, (const float *)p.partial, p.partial_stride, splits, dw, g->Ci, g->Co, Ci_real, Co_real);
     }
     LVT_CHECK_LAUNCH("wgrad unpack");
+    if (db) {
+        hipLaunchKernelGGL(lvt_wgrad_bias_reduce_kernel, dim3((unsigned)lvt_cdiv(Co_real, 4)), dim3(256), 0, s,
+                           (const float *)p.colsum_partial, splits, g->Co, Co_real, db);
+        LVT_CHECK_LAUNCH("lvt_wgrad_bias_reduce_kernel");
+    }
     return LVT_OK;
 }

@@ -2221,7 +2221,7 @@ size_t lvt_wgrad_frames_workspace_bytes(const lvt_conv_geom *g);
 int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, int Ci_real, int Co_real,
                             void *workspace, hipStream_t s, void (*unpack_plain)(const float *, long long, int, float *,
                                                                                  const lvt_conv_geom *, int, int, hipStream_t),
-                            const float *x_amax, const float *dy_amax);
+                            const float *x_amax, const float *dy_amax, float *db);
 // the tiled unpack kernel turns a [64 co][4 ci x taps] tile through dynamic LDS: served while that tile fits in 64 KB
 static bool unpack_tiled_ok(const lvt_conv_geom *g, int Ci_real, int Co_real) {
     const int taps = g->Kt * g->Kh * g->Kw;
@@ -2244,8 +2244,14 @@ static void unpack_plain_wgrad(const float *partial, long long stride, int split
     hipLaunchKernelGGL(lvt_unpack_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, partial, stride, splits, L, dw, taps,
                        g->Ci, g->Co, Ci_real, Co_real, (const float *)nullptr, (float *)nullptr);
 }
-// 1 when lvt_conv3d_bwd_weight also produces the bias gradient (db) for this geometry; the frame-resident path does not
-extern "C" int lvt_conv3d_bwd_weight_fuses_bias(const lvt_conv_geom *g, int flags) { return g && lvt_wgrad_frames_role(g, flags) == 0 ? 1 : 0; }
+// 1 when lvt_conv3d_bwd_weight also produces the bias gradient (db) for this geometry: every served geometry does (the implicit-
+// GEMM path sums the dy tiles it streams, the frame-resident kernels the dy rows / patches they stage)
+// (LVT_NO_FRAME_BIAS=1: A/B switch -- the frame-resident geometries answer 0 again and callers fall back to lvt_colsum)
+extern "C" int lvt_conv3d_bwd_weight_fuses_bias(const lvt_conv_geom *g, int flags) {
+    static const int off = getenv("LVT_NO_FRAME_BIAS") ? 1 : 0;
+    if (!g) return 0;
+    return off && lvt_wgrad_frames_role(g, flags) ? 0 : 1;
+}
 
 static int bwd_weight_splits(const lvt_conv_geom *g) {
     const long long Mg = (long long)g->Kt * g->Kh * g->Kw * g->Ci;
@@ -2279,10 +2285,8 @@ extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, con
     LVT_REQUIRE_AMAX(flags, ax, "conv3d_bwd_weight");
     const bool f16 = math_of(flags) == 2;
     if (lvt_wgrad_frames_role(g, flags) && lvt_aligned16(x) && lvt_aligned16(dy)) {
-        LVT_REQUIRE(!db, "conv3d_bwd_weight: this geometry runs on the frame-resident kernel, which leaves the bias gradient "
-                         "to lvt_colsum (see lvt_conv3d_bwd_weight_fuses_bias)");
         rc = lvt_wgrad_frames_launch(g, x, dy, dw, Ci_real, Co_real, workspace, (hipStream_t)stream, unpack_plain_wgrad,
-                                     f16 ? ax->a : nullptr, f16 ? ax->b : nullptr);
+                                     f16 ? ax->a : nullptr, f16 ? ax->b : nullptr, db);
         if (rc) return rc;
         LVT_CHECK_LAUNCH("conv3d_bwd_weight (frame-resident)");
         return LVT_OK;

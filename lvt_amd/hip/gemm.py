@@ -288,7 +288,6 @@ def conv_bwd_weight(g, x, dy, Ci_real, Co_real, want_bias=False):
     dw = torch.empty(Co_real, Ci_real, g.Kt, g.Kh, g.Kw, dtype=torch.float32, device=x.device)
     nws = lib.lvt_conv3d_bwd_weight_workspace_bytes(C.byref(g))
     ws = L.workspace(nws, x.device, "wgrad")
-    # (the frame-resident kernel of the 3x3 layers leaves the bias gradient to a column-sum launch: db stays None)
     fused_bias = want_bias and bool(lib.lvt_conv3d_bwd_weight_fuses_bias(C.byref(g), L.math_flag()))
     db = torch.empty(Co_real, dtype=torch.float32, device=x.device) if fused_bias else None
     io = L.amax_io(x, dy)

@@ -241,11 +241,13 @@ def test_frame_resident_weight_gradient(Ci, Co, N, math_mode):
     y.backward(gy)
     dev = _dev()
     g = G.conv_geom(N, 1, H, H, Ci, Co, (1, 3, 3), (1, 1, 1), (0, 1, 1))
-    fused = L.lib().lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g), L.math_flag())
-    assert fused == (0 if math_mode != "f32" else 1)
+    assert L.lib().lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g), L.math_flag()) == 1
+    # the bias gradient rides on the dy rows (dy = slab operand, Co == 256) or patches (dy = patch operand) the kernel stages
     dw, db = G.conv_bwd_weight(g, _nhwc(x.detach()).to(dev), _nhwc(gy).to(dev), Ci, Co, want_bias=True)
-    assert (db is None) == (fused == 0)
     assert rel_err(dw.squeeze(2), w.grad) < 5e-5
+    assert rel_err(db, gy.sum((0, 2, 3))) < 2e-6
+    dw2, db2 = G.conv_bwd_weight(g, _nhwc(x.detach()).to(dev), _nhwc(gy).to(dev), Ci, Co, want_bias=True)
+    assert torch.equal(db, db2) and torch.equal(dw, dw2)          # fixed summation order
 
 
 @pytest.mark.parametrize("Cin,Cout,N", [(256, 128, 3), (32, 128, 1), (64, 256, 5), (32, 128, 512)])
@@ -304,9 +306,11 @@ def test_frame_resident_weight_gradient_stride2(Ci, N, math_mode):
     y.backward(gy)
     dev = _dev()
     g = G.conv_geom(N, 1, 32, 32, Ci, Co, (1, 4, 4), (1, 2, 2), (0, 1, 1))
-    assert L.lib().lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g), L.math_flag()) == (0 if math_mode != "f32" else 1)
-    dw = G.conv_bwd_weight(g, _nhwc(x.detach()).to(dev), _nhwc(gy).to(dev), Ci, Co)
+    assert L.lib().lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g), L.math_flag()) == 1
+    dw, db = G.conv_bwd_weight(g, _nhwc(x.detach()).to(dev), _nhwc(gy).to(dev), Ci, Co, want_bias=True)
     assert rel_err(dw.squeeze(2), w.grad) < 5e-5
+    assert rel_err(db, gy.sum((0, 2, 3))) < 2e-6                  # summed from the dy rows the parity classes' chunk 0 stages
+    assert rel_err(G.conv_bwd_weight(g, _nhwc(x.detach()).to(dev), _nhwc(gy).to(dev), Ci, Co).squeeze(2), w.grad) < 5e-5   # db == NULL
 
 
 def test_conv3d_causal_geometry():

@@ -232,14 +232,14 @@ def test_frame_resident_kernel_routing_of_the_vqvae_layers():
         assert lib.lvt_conv3d_uses_patch_kernel(ctypes.byref(g), 0) == 1                    # forward
         assert lib.lvt_conv3d_uses_patch_kernel(ctypes.byref(G.swapped_geom(g)), 0) == 1    # backward-data as a forward conv
         assert lib.lvt_conv3d_uses_patch_kernel(ctypes.byref(g), F32) == 0                  # f32 mode: implicit GEMM
-        assert lib.lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g), 0) == 0                # frame-resident weight gradient
+        assert lib.lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g), 0) == 1                # every route sums dy itself
         assert lib.lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(g), F32) == 1
     sg = G.swapped_geom(k4a)
     assert (sg.Ci, sg.Co, sg.ph, sg.pw, sg.Ho, sg.Wo) == (128, 256, 1, 1, 16, 16)
     k2 = geom(128, 256, 4, 2, 1, 32)                    # Conv 128->256 k4 s2 and, mirrored, ConvTranspose 256->128
     assert lib.lvt_conv3d_fwd_uses_parity_kernel(ctypes.byref(k2), 0) == 1
     assert lib.lvt_conv3d_bwd_data_uses_phase_kernel(ctypes.byref(k2), 0) == 1
-    assert lib.lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(k2), 0) == 0
+    assert lib.lvt_conv3d_bwd_weight_fuses_bias(ctypes.byref(k2), 0) == 1
     assert lib.lvt_conv3d_fwd_uses_parity_kernel(ctypes.byref(k2), F32) == 0
     # layers that stay on the engine: 1x1, the image-side 4 -> 128 layer, other frame sizes
     for g in (geom(128, 256, 1, 1, 0, 16), geom(4, 128, 4, 2, 1, 64), geom(256, 256, 3, 1, 1, 32)):
