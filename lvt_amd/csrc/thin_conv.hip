@@ -20,8 +20,10 @@
 // ------------------------------------------------------------------------------------------------
 #define TC_CK 16
 #define TC_LDX 20                       // floats per staged pixel (16 + 4 pad): b128 reads conflict-free
-#define TC_TH 8
+#ifndef TC_P
 #define TC_P 1                         // positions per thread (rows lh + 8*p)
+#endif
+#define TC_TH (8 * TC_P)
 #define TC_TW 32
 
 __device__ __forceinline__ float tc_comp(const float4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }

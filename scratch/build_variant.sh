@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage: scratch/build_variant.sh NAME "-DFLAG ..."   -> scratch/variants/lib_NAME.so
+# usage: scratch/build_variant.sh NAME "-DFLAG ..." [unit, default gemm_engine]   -> scratch/variants/lib_NAME.so
 set -e
 cd "$(dirname "$0")/../lvt_amd/csrc"
 mkdir -p ../../scratch/variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wno-unused-result $2 -c gemm_engine.hip -o ../../scratch/variants/ge_$1.o
-OTHERS=$(ls *.o | grep -v gemm_engine.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wno-unused-result $2 -c ${3:-gemm_engine}.hip -o ../../scratch/variants/ge_$1.o
+OTHERS=$(ls *.o | grep -v ${3:-gemm_engine}.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OTHERS ../../scratch/variants/ge_$1.o -o ../../scratch/variants/lib_$1.so
 rm ../../scratch/variants/ge_$1.o
