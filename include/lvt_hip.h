@@ -223,12 +223,15 @@ int lvt_conv3d_bwd_weight_fuses_bias(const lvt_conv_geom *g, int flags);
 int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, float *db,
                           int Ci_real, int Co_real, int flags, const lvt_amax_io *ax, void *workspace,
                           size_t workspace_bytes, void *stream);
-/* Image-side layer (3 channels carried as 4): LDS-tiled fp32 FMA kernel that reads the 128-channel activation exactly
- * once instead of spending MFMA tiles on padding columns.
+/* Image-side layer (3 channels carried as 4).
  * lvt_convt4_fwd: ConvTranspose2d(Ci -> Cr<=3, k4 s2 p1) forward, x (N,Hi,Wi,Ci) -> y (N,2Hi,2Wi,4) (+tanh);
- *                 w in torch layout (Ci, Cr, 4, 4), bias (Cr).   (K6 of resdecoder.py:56,68)                   */
+ *                 w in torch layout (Ci, Cr, 4, 4), bias (Cr).   (K6 of resdecoder.py:56,68)
+ * flags: 0 / LVT_MATH_F32: an LDS-tiled fp32 FMA kernel that reads the activation exactly once instead of spending 32-wide
+ * MFMA tiles on padding columns (ax may be NULL).  LVT_MATH_F16X2 (ax->a = max |x|, ax->b = max |w| required) with Ci == 128,
+ * Hi % 8 == 0, Wi % 32 == 0: the matrix cores -- rows = input positions, 16 columns = (output phase, channel), reduction over
+ * the 3 x 3 neighbours x Ci on v_mfma_f32_16x16x32_f16, persistent workgroups, weights split once per workgroup.          */
 int lvt_convt4_fwd(const float *x, const float *w, const float *bias, int N, int Hi, int Wi, int Ci, int Cr,
-                   int act_tanh, float *y, void *stream);
+                   int act_tanh, float *y, int flags, const lvt_amax_io *ax, void *stream);
 /* out[n] (+)= sum_m g[m*ld + n]  (bias gradients).  workspace >= lvt_colsum_workspace_bytes.        */
 size_t lvt_colsum_workspace_bytes(long long M, int N);
 int lvt_colsum(const float *g, long long M, int N, long long ld, float *out, void *workspace,

@@ -136,10 +136,203 @@ __global__ __launch_bounds__(256) void lvt_convt4_fwd_kernel(const float *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same layer on the matrix cores (round 4, LVT_MATH_F16X2): as a GEMM the rows are the INPUT positions, the 16 columns are
+// (output phase rh, rw; channel c carried as 4) and the reduction runs over (neighbour dh, dw in 3 x 3; ci) = 9 x 128, with a
+// zero weight where tap (phase, neighbour) does not exist (16 of the 36 (phase, neighbour) pairs do): 2.25x the useful products,
+// on a pipe that has them to spare -- 58 GFLOP executed per 512 frames against an HBM pass of 268 MB.  v_mfma_f32_16x16x32_f16:
+// A = 16 positions of an image row x 32 channels, B = 32 channels x the 16 columns, three products per block (hi hi, hi lo, lo hi;
+// gemm_engine.hip describes the split).
+//   * persistent workgroups (8 waves, one per CU) walk bands of 8 x 32 input positions; wave w owns row w of the band (two
+//     16-position tiles);
+//   * the weights are split ONCE per workgroup into fp16 planes [neighbour][column][ci] (78 KB of LDS, row pitch 136 halves:
+//     conflict-free 16-byte fragment reads);
+//   * the band's 10 x 34 halo patch is staged per 32-channel chunk as two planes (pixel pitch 40 halves), the next chunk's
+//     global loads (or the next band's first chunk) in flight under the MFMAs of the current one.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 tm_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 tm_f16x2 __attribute__((ext_vector_type(2)));
+typedef float tm_f32x4 __attribute__((ext_vector_type(4)));
+typedef float tm_f32x2 __attribute__((ext_vector_type(2)));
+#define TM_R 8
+#define TM_W 32
+#define TM_PW (TM_W + 2)
+#define TM_PIX ((TM_R + 2) * TM_PW)
+#define TM_CK 32
+#define TM_CI 128
+#define TM_XP (TM_CK + 8)
+#define TM_XPL (TM_PIX * TM_XP)
+#define TM_WP (TM_CI + 8)
+#define TM_WPL (9 * 16 * TM_WP)
+#define TM_THREADS 512
+
+__device__ __forceinline__ float tm_mix(unsigned h, int hi, float c) {        // c - 2048 * half(h.lo | h.hi), one rounding (exact here)
+    float r;
+    if (hi) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(-2048.f), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(-2048.f), "v"(c));
+    return r;
+}
+// a s = hi + lo / 2048 (gemm_engine.hip: f16_split_pair<2048>)
+__device__ __forceinline__ void tm_split_pair(float a, float b, float s, unsigned &ph, unsigned &pl) {
+    const tm_f32x2 v = {a, b};
+    ph = __builtin_bit_cast(unsigned, __builtin_convertvector(v * s, tm_f16x2));
+    const tm_f32x2 t2 = v * (s * 2048.f);
+    const tm_f32x2 r = {tm_mix(ph, 0, t2.x), tm_mix(ph, 1, t2.y)};
+    pl = __builtin_bit_cast(unsigned, __builtin_convertvector(r, tm_f16x2));
+}
+__device__ __forceinline__ void tm_split4(const float4 v, float s, unsigned short *hi, unsigned short *lo) {
+    uint2 ph, pl;
+    tm_split_pair(v.x, v.y, s, ph.x, pl.x);
+    tm_split_pair(v.z, v.w, s, ph.y, pl.y);
+    *reinterpret_cast<uint2 *>(hi) = ph;
+    *reinterpret_cast<uint2 *>(lo) = pl;
+}
+__device__ __forceinline__ float tm_scale(const float *amax, int &unscale) {       // = lvt_f16_scale (gemm_engine.hip)
+    const int eb = (int)((__float_as_uint(*amax) >> 23) & 0xffu);
+    int se = 268 - eb;
+    se = se < 2 ? 2 : (se > 252 ? 252 : se);
+    unscale -= se - 127;
+    return __uint_as_float((unsigned)se << 23);
+}
+
+__global__ __launch_bounds__(TM_THREADS) void lvt_convt4_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                                     const float *__restrict__ bias, int N, int Hi, int Wi, int Cr,
+                                                                     int act_tanh, float *__restrict__ y,
+                                                                     const float *__restrict__ x_amax, const float *__restrict__ w_amax) {
+    __shared__ __attribute__((aligned(16))) unsigned short Wp[2 * TM_WPL];
+    __shared__ __attribute__((aligned(16))) unsigned short Xp[2 * TM_XPL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    int unscale = 0;
+    const float sx = tm_scale(x_amax, unscale), sw = tm_scale(w_amax, unscale);
+
+    // weight planes: column n = (rh, rw, c), neighbour (dh, dw); tap k of a dimension serves (phase, neighbour) =
+    // k = 0: (1, 2), 1: (0, 1), 2: (1, 1), 3: (0, 0)
+    for (int idx = tid; idx < 9 * 16 * (TM_CI / 4); idx += TM_THREADS) {
+        const int ci4 = idx & 31, n = (idx >> 5) & 15, nbr = idx >> 9;
+        const int dh = nbr / 3, dw = nbr - 3 * dh, rh = n >> 3, rw = (n >> 2) & 1, c = n & 3;
+        const int kh = rh == 0 ? (dh == 1 ? 1 : dh == 0 ? 3 : -1) : (dh == 2 ? 0 : dh == 1 ? 2 : -1);
+        const int kw = rw == 0 ? (dw == 1 ? 1 : dw == 0 ? 3 : -1) : (dw == 2 ? 0 : dw == 1 ? 2 : -1);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kh >= 0 && kw >= 0 && c < Cr) {
+            const float *wp = w + ((long long)(ci4 * 4) * Cr + c) * 16 + kh * 4 + kw;
+            v = make_float4(wp[0], wp[Cr * 16], wp[2 * Cr * 16], wp[3 * Cr * 16]);
+        }
+        unsigned short *d = Wp + (nbr * 16 + n) * TM_WP + ci4 * 4;
+        tm_split4(v, sw, d, d + TM_WPL);
+    }
+
+    const int nbw = Wi / TM_W, nbh = Hi / TM_R;
+    const int nbands = N * nbh * nbw;
+    constexpr int NSLOT = TM_PIX * (TM_CK / 4), NLD = (NSLOT + TM_THREADS - 1) / TM_THREADS;
+    int loff[NLD], ph_[NLD], pw_[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int u = tid + TM_THREADS * i;
+        const int pix = u >> 3, q4 = u & 7;
+        loff[i] = u < NSLOT ? pix * TM_XP + q4 * 4 : -1;
+        ph_[i] = pix / TM_PW; pw_[i] = pix - ph_[i] * TM_PW;
+    }
+    long long goff[NLD];                       // float offset of the slot's (pixel, channel quad) in x, chunk 0; -1: zero fill
+    float4 pre[2][NLD];                        // two chunks in flight: chunk c + 2 is requested when chunk c has been stored
+    auto setup = [&](int band, int &img, int &h0, int &w0) {
+        const int bw = band % nbw; const int t = band / nbw;
+        const int bh = t % nbh; img = t / nbh;
+        h0 = bh * TM_R; w0 = bw * TM_W;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int hi = h0 + ph_[i] - 1, wi = w0 + pw_[i] - 1;
+            goff[i] = (loff[i] >= 0 && (unsigned)hi < (unsigned)Hi && (unsigned)wi < (unsigned)Wi)
+                          ? (((long long)img * Hi + hi) * Wi + wi) * TM_CI + (tid & 7) * 4 : -1;
+        }
+    };
+    auto fetch = [&](int chunk, float4 *dst) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            dst[i] = goff[i] >= 0 ? *reinterpret_cast<const float4 *>(x + goff[i] + chunk * TM_CK) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    const int n_ = m, rh = n_ >> 3, rw = (n_ >> 2) & 1, c_ = n_ & 3;
+    const float bias_c = c_ < Cr ? bias[c_] : 0.f;
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+
+    int band = blockIdx.x, img = 0, h0 = 0, w0 = 0;
+    if (band < nbands) { setup(band, img, h0, w0); fetch(0, pre[0]); fetch(1, pre[1]); }
+    for (; band < nbands; band += gridDim.x) {
+        tm_f32x4 acc[2], acx[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc[t][r] = 0.f; acx[t][r] = 0.f; }
+        const int cimg = img, ch0 = h0, cw0 = w0;
+        static_assert(TM_CI / TM_CK == 4, "the prefetch schedule below is written for four chunks per band");
+        const bool more = band + (int)gridDim.x < nbands;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+#ifdef TM_X_NOSTAGE      // (timing experiments: the loaded values still have to arrive)
+                if (loff[i] >= 0 && pre[c & 1][i].x == 12345.f) Xp[loff[i]] = 1;
+#else
+                if (loff[i] >= 0) tm_split4(pre[c & 1][i], sx, Xp + loff[i], Xp + TM_XPL + loff[i]);
+#endif
+            __syncthreads();                                   // (first pass: the weight planes as well)
+            // chunk c + 2 into the registers just stored: chunks 2, 3 of this band, then chunks 0, 1 of the next one
+            if (c < 2) fetch(c + 2, pre[c & 1]);
+            else if (more) {
+                if (c == 2) setup(band + gridDim.x, img, h0, w0);
+                fetch(c - 2, pre[c & 1]);
+            }
+#ifndef TM_X_NOBLOCK
+#pragma unroll
+            for (int nbr = 0; nbr < 9; ++nbr) {
+                const int dh = nbr / 3, dw = nbr - 3 * dh;
+                const unsigned short *bp = Wp + (nbr * 16 + m) * TM_WP + c * TM_CK + 8 * kq;
+                const tm_f16x8 bh = *reinterpret_cast<const tm_f16x8 *>(bp), bl = *reinterpret_cast<const tm_f16x8 *>(bp + TM_WPL);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned short *ap = Xp + ((wave + dh) * TM_PW + 16 * t + m + dw) * TM_XP + 8 * kq;
+                    const tm_f16x8 ah = *reinterpret_cast<const tm_f16x8 *>(ap), al = *reinterpret_cast<const tm_f16x8 *>(ap + TM_XPL);
+#ifdef TM_X_NOMFMA
+                    acc[t][0] += (float)ah[0] + (float)bl[1] + (float)al[2] + (float)bh[3];
+#else
+                    acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acx[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[t], 0, 0, 0);
+                    acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acx[t], 0, 0, 0);
+#endif
+                }
+            }
+#endif
+            __syncthreads();                                   // every wave is done with this chunk's patch
+        }
+        // lane = column (rh, rw, c) of positions (row ch0 + wave, columns cw0 + 16 t + 4 kq + i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = ldexpf(fmaf(acx[t][i], 1.f / 2048.f, acc[t][i]), unscale) + bias_c;
+                if (act_tanh) v = tanhf(v);
+                if (c_ >= Cr) v = 0.f;
+                const int qh = ch0 + wave, qw = cw0 + 16 * t + 4 * kq + i;
+                y[(((long long)cimg * Ho + 2 * qh + rh) * Wo + 2 * qw + rw) * 4 + c_] = v;
+            }
+    }
+}
+
 extern "C" int lvt_convt4_fwd(const float *x, const float *w, const float *bias, int N, int Hi, int Wi, int Ci, int Cr,
-                              int act_tanh, float *y, void *stream) {
+                              int act_tanh, float *y, int flags, const lvt_amax_io *ax, void *stream) {
     LVT_REQUIRE(x && w && bias && y && N > 0 && Hi > 0 && Wi > 0, "convT4_fwd: bad args");
     LVT_REQUIRE(Ci % TC_CK == 0 && Cr >= 1 && Cr <= 3, "convT4_fwd: needs Ci %% 16 == 0 and 1..3 output channels");
+    LVT_REQUIRE(!(flags & LVT_MATH_F16X2) || (ax && ax->a && ax->b), "convT4_fwd: LVT_MATH_F16X2 needs ax->a = max |x|, ax->b = max |w|");
+    static const int no_mfma = getenv("LVT_NO_CONVT4_MFMA") ? 1 : 0;
+    if ((flags & LVT_MATH_F16X2) && !no_mfma && Ci == TM_CI && Hi % TM_R == 0 && Wi % TM_W == 0 && lvt_aligned16(x) &&
+        (long long)N * (Hi / TM_R) * (Wi / TM_W) < 0x7fffffffLL) {
+        const long long nbands = (long long)N * (Hi / TM_R) * (Wi / TM_W);
+        const unsigned grid = (unsigned)(nbands < LVT_NUM_CU ? nbands : LVT_NUM_CU);       // persistent: one workgroup per CU
+        hipLaunchKernelGGL(lvt_convt4_mfma_kernel, dim3(grid), dim3(TM_THREADS), 0, (hipStream_t)stream, x, w, bias, N, Hi, Wi, Cr,
+                           act_tanh, y, ax->a, ax->b);
+        LVT_CHECK_LAUNCH("lvt_convt4_mfma_kernel");
+        return LVT_OK;
+    }
     const long long blocks = (long long)N * lvt_cdiv(Hi, TC_TH) * lvt_cdiv(Wi, TC_TW);
     LVT_REQUIRE(blocks < 0x7fffffffLL, "convT4_fwd: grid too large");
     hipLaunchKernelGGL(lvt_convt4_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, N,

@@ -98,7 +98,7 @@ def _declare(lib):
         "lvt_conv3d_bwd_weight_workspace_bytes": (sz, [P(ConvGeom)]),
         "lvt_conv3d_bwd_weight_fuses_bias": (ci, [P(ConvGeom), ci]),
         "lvt_conv3d_bwd_weight": (ci, [P(ConvGeom), vp, vp, vp, vp, ci, ci, ci, P(AmaxIO), vp, sz, vp]),
-        "lvt_convt4_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+        "lvt_convt4_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, vp]),
         "lvt_colsum_workspace_bytes": (sz, [cll, ci]),
         "lvt_colsum": (ci, [vp, cll, ci, cll, vp, vp, sz, vp]),
         "lvt_vq_nearest_workspace_bytes": (sz, [cll, ci, ci]),

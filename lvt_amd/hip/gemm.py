@@ -272,9 +272,10 @@ def convT4_fwd(x, w, bias, act_tanh):
     L.require(x, w, bias)
     N, _, Hi, Wi, Ci = x.shape
     y = torch.empty(N, 1, 2 * Hi, 2 * Wi, 4, dtype=torch.float32, device=x.device)
+    io = L.amax_io(x, w)
     t0 = L.TIMER.begin() if L.TIMER is not None else None
     L.check(L.lib().lvt_convt4_fwd(L.ptr(x), L.ptr(w), L.ptr(bias), N, Hi, Wi, Ci, w.shape[1], 1 if act_tanh else 0,
-                                   L.ptr(y), L.stream_ptr()), "lvt_convt4_fwd")
+                                   L.ptr(y), L.math_flag(), L.io_ref(io), L.stream_ptr()), "lvt_convt4_fwd")
     if t0 is not None:
         L.TIMER.end("thin_convT_fwd", 2.0 * N * 4 * Hi * Wi * 4 * 4 * Ci, t0)
     return y

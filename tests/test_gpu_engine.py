@@ -165,11 +165,15 @@ def test_conv_transpose_as_bwd_data(Cin, Cout, H):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,Ci,Cr,Hi,Wi,act", [(2, 128, 3, 32, 32, True), (3, 32, 3, 5, 7, False), (1, 16, 1, 9, 40, True),
-                                               (2, 48, 2, 8, 33, False)])
-def test_thin_conv_transpose_forward(N, Ci, Cr, Hi, Wi, act):
-    """The dedicated image-side ConvTranspose2d(Ci -> <=3, k4 s2 p1) kernel (K6): full and ragged tiles, 1..3 real
-    channels, with and without tanh; the carried 4th channel is exactly act(0) = 0."""
+@pytest.mark.parametrize("N,Ci,Cr,Hi,Wi,act,tol", [
+    (2, 128, 3, 32, 32, True, 2e-6), (3, 32, 3, 5, 7, False, 2e-6), (1, 16, 1, 9, 40, True, 2e-6), (2, 48, 2, 8, 33, False, 2e-6),
+    # (new in round 4; 512-term sums over many more outputs: the fp32 FMA kernel itself reaches 2.7e-6 on the 70-frame case)
+    (70, 128, 3, 32, 32, True, 4e-6), (3, 128, 2, 8, 64, False, 4e-6), (1, 128, 1, 40, 32, True, 4e-6)])
+def test_thin_conv_transpose_forward(N, Ci, Cr, Hi, Wi, act, tol, math_mode):
+    """The dedicated image-side ConvTranspose2d(Ci -> <=3, k4 s2 p1) kernels (K6): full and ragged tiles, 1..3 real
+    channels, with and without tanh; the carried 4th channel is exactly act(0) = 0.  In f16x2 mode the 128-channel cases
+    whose extents divide into 8 x 32 bands run on the matrix-core kernel (more bands than workgroups included), everything
+    else on the fp32 FMA kernel."""
     from lvt_amd.hip import gemm as G
     x, w, b = _rand(N, Ci, Hi, Wi), _rand(Ci, Cr, 4, 4, seed=1) * 0.1, _rand(Cr, seed=2)
     y = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1)
@@ -179,7 +183,7 @@ def test_thin_conv_transpose_forward(N, Ci, Cr, Hi, Wi, act):
     yd = G.convT4_fwd(_nhwc(x).to(dev), w.to(dev), b.to(dev), act).cpu()
     assert yd.shape == (N, 1, 2 * Hi, 2 * Wi, 4)
     got = yd[:, 0].permute(0, 3, 1, 2)
-    assert rel_err(got[:, :Cr], y.float()) < 2e-6
+    assert rel_err(got[:, :Cr], y.float()) < tol
     assert (got[:, Cr:] == 0).all()
 
 
