@@ -20,6 +20,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 #define WG_THREADS 512
+#define WG_SUM_PARTS 8                   // pixel ranges per split for the column sums of the slab operand (extra workgroups)
 #define WG_PW 18
 #define WG_PIX (WG_PW * WG_PW)
 #define WG_PP 32                         // patch pixel pitch (bf16): 64 B -> the 4 rows of a transposing read tile the 64 banks
@@ -37,10 +38,13 @@ struct WgParams {
     int Cp, N, frames_per_split, nchunks;
     float *partial; long long partial_stride;
     const float *p_amax, *q_amax;        // MATH == 2: max |P|, max |Q| (device scalars)
-    // bias gradient = column sums of dy, accumulated from the dy tiles as they are staged (each element is staged exactly once per
-    // workgroup that sums): sum_mode 1: dy is the slab operand, the workgroup of chunk 0 (class 0) of every split sums all 256
-    // channels; 2: dy is the patch operand, every workgroup sums its own 32 channels.  colsum_partial[split][channel].
-    int sum_mode; float *colsum_partial;
+    // bias gradient = column sums of dy, by the same launch.  sum_mode 2: dy is the patch operand -- every workgroup adds up the
+    // 32-channel patches it stages (once per frame: not in the row loop).  sum_mode 1: dy is the slab operand -- `nsum` EXTRA
+    // workgroups (blockIdx >= nmain) stream one range of dy rows each and do nothing else; they run beside the matrix
+    // workgroups (the rows are in L2 / MALL from their staging).  Summing inside slab_store instead put a branch into the row loop
+    // and cost the stride-2 kernel 36 % (459 -> 625 us: its 24 MFMAs per row leave the scheduler one block to interleave).
+    // colsum_partial[split or range][channel].
+    int sum_mode, nmain, nsplits, nsum; float *colsum_partial;
 };
 // MODE 0: 3x3 / stride 1 / pad 1 on 16x16 frames: nine taps over the 18x18 patch, as described above.
 // MODE 1: 4x4 / stride 2 / pad 1 between a 32x32 frame (patch operand, Cp channels) and a 16x16 frame (slab operand, 256
@@ -119,9 +123,40 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
     float sp = 1.f, sq = 1.f;
     if (MATH == 2) { sp = wg_f16_scale(p.p_amax, unscale); sq = wg_f16_scale(p.q_amax, unscale); }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= p.nmain) {
+        // column sums of the slab operand over the frames of split (blockIdx - nmain): thread = (pixel tid >> 6 of eight, channel
+        // quad tid & 63), four independent running sums, combined in a fixed order
+        // (one workgroup streams ~16 GB/s: the pixels are cut into nsum = 8 x splits ranges so that none outlasts the matrix work)
+        const int split = blockIdx.x - p.nmain;                                    // index of the pixel range
+        const long long per = (((long long)p.N * 256 + p.nsum - 1) / p.nsum + 7) / 8 * 8;
+        const long long px0 = split * per, px1 = min((long long)p.N * 256, px0 + per);
+        const float *src = p.Q + (tid & 63) * 4;
+        float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0, c3 = c0;
+        long long px = px0 + (tid >> 6);
+        for (; px + 24 < px1; px += 32) {
+            const float4 a = *reinterpret_cast<const float4 *>(src + px * WG_CQ), b = *reinterpret_cast<const float4 *>(src + (px + 8) * WG_CQ);
+            const float4 c = *reinterpret_cast<const float4 *>(src + (px + 16) * WG_CQ), d = *reinterpret_cast<const float4 *>(src + (px + 24) * WG_CQ);
+            c0.x += a.x; c0.y += a.y; c0.z += a.z; c0.w += a.w; c1.x += b.x; c1.y += b.y; c1.z += b.z; c1.w += b.w;
+            c2.x += c.x; c2.y += c.y; c2.z += c.z; c2.w += c.w; c3.x += d.x; c3.y += d.y; c3.z += d.z; c3.w += d.w;
+        }
+        for (; px < px1; px += 8) {
+            const float4 a = *reinterpret_cast<const float4 *>(src + px * WG_CQ);
+            c0.x += a.x; c0.y += a.y; c0.z += a.z; c0.w += a.w;
+        }
+        float *scratch = reinterpret_cast<float *>(lds);
+        *reinterpret_cast<float4 *>(&scratch[tid * 4]) = make_float4((c0.x + c1.x) + (c2.x + c3.x), (c0.y + c1.y) + (c2.y + c3.y),
+                                                                     (c0.z + c1.z) + (c2.z + c3.z), (c0.w + c1.w) + (c2.w + c3.w));
+        __syncthreads();
+        if (tid < WG_CQ) {
+            float t = 0.f;
+            for (int w = 0; w < WG_THREADS / 64; ++w) t += scratch[(w * 64 + (tid >> 2)) * 4 + (tid & 3)];
+            p.colsum_partial[(long long)split * WG_CQ + tid] = t;
+        }
+        return;
+    }
     // workgroup b runs on XCD b % 8 and every XCD has its own L2: the chunks of one split read the same frames (all of
     // the slab operand, the same patch pixels), so the split index is the fast one -- its low bits pick the XCD
-    const int nsplits = gridDim.x / (p.nchunks * (MODE == 1 ? 4 : 1));
+    const int nsplits = p.nsplits;
     const int split = blockIdx.x % nsplits;
     const int pc = MODE == 1 ? (blockIdx.x / nsplits) >> 2 : blockIdx.x / nsplits;       // 32-channel chunk of the patch operand
     const int cls = MODE == 1 ? (blockIdx.x / nsplits) & 3 : 0;                          // parity class (py, px)
@@ -130,8 +165,8 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
 
     constexpr int PUNITS = WG_PIX * 8, PPASS = (PUNITS + WG_THREADS - 1) / WG_THREADS;
     float4 pv[PPASS], qv[2];
-    // (a thread stages the same channel quad of every pixel it touches: tid & 63 of the slab, tid & 7 of the patch)
-    const bool sum_q = p.sum_mode == 1 && pc == 0 && cls == 0, sum_p = p.sum_mode == 2;
+    // (a thread stages the same channel quad tid & 7 of every patch pixel it touches)
+    const bool sum_p = p.sum_mode == 2;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
     auto patch_fetch = [&](int f) {
         const float *xf = p.P + (long long)f * (MODE == 1 ? 1024 : 256) * Cp + pc * 32;
@@ -178,10 +213,6 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
         for (int j = 0; j < 2; ++j) qv[j] = *reinterpret_cast<const float4 *>(src + (tid + WG_THREADS * j) * 4);
     };
     auto slab_store = [&](unsigned short *slab) {
-        if (sum_q) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) { cs.x += qv[j].x; cs.y += qv[j].y; cs.z += qv[j].z; cs.w += qv[j].w; }
-        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int u = tid + WG_THREADS * j;
@@ -289,18 +320,13 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
             buf ^= 1;
         }
     }
-    if (sum_q || sum_p) {
+    if (sum_p) {
         // threads that staged the same channel quad are combined in thread order through LDS (every wave is past the last barrier
         // of the loop, the operand images are dead): a fixed order
         float *scratch = reinterpret_cast<float *>(lds);
-        *reinterpret_cast<float4 *>(&scratch[tid * 4]) = cs;              // slab: [wave][quad 0..63]; patch: [tid >> 3][quad 0..7]
+        *reinterpret_cast<float4 *>(&scratch[tid * 4]) = cs;              // [tid >> 3][quad 0..7]
         __syncthreads();
-        if (sum_q && tid < WG_CQ) {
-            float t = 0.f;
-            for (int w = 0; w < WG_THREADS / 64; ++w) t += scratch[(w * 64 + (tid >> 2)) * 4 + (tid & 3)];
-            p.colsum_partial[(long long)split * WG_CQ + tid] = t;
-        }
-        if (sum_p && tid < 32) {
+        if (tid < 32) {
             float t = 0.f;
             for (int i = 0; i < WG_THREADS / 8; ++i) t += scratch[(i * 8 + (tid >> 2)) * 4 + (tid & 3)];
             p.colsum_partial[(long long)split * Cp + pc * 32 + tid] = t;
@@ -376,7 +402,7 @@ int lvt_wgrad_frames_role(const lvt_conv_geom *g, int flags) { return wg_role(g,
 size_t lvt_wgrad_frames_workspace_bytes(const lvt_conv_geom *g) {
     const int role = wg_role(g);
     if (!role) return 0;
-    return (size_t)wg_splits(g, role) * ((size_t)g->Kh * g->Kw * g->Ci * g->Co + g->Co) * sizeof(float);     // + the bias partials
+    return (size_t)wg_splits(g, role) * ((size_t)g->Kh * g->Kw * g->Ci * g->Co + WG_SUM_PARTS * g->Co) * sizeof(float);     // + the bias partials
 }
 int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, int Ci_real, int Co_real,
                             void *workspace, hipStream_t s, void (*unpack_plain)(const float *, long long, int, float *,
@@ -393,14 +419,18 @@ int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float 
     p.partial = (float *)workspace; p.partial_stride = (long long)g->Kh * g->Kw * g->Ci * g->Co;
     p.sum_mode = db ? (role == 2 ? 2 : 1) : 0;             // dy is the patch operand in role 2, the slab (256 = Co channels) otherwise
     p.colsum_partial = p.partial + (long long)splits * p.partial_stride;
+    p.nsplits = splits;
+    p.nmain = (role == 3 ? 4 : 1) * p.nchunks * splits;
+    p.nsum = p.sum_mode == 1 ? WG_SUM_PARTS * splits : splits;
+    const unsigned grid = (unsigned)(p.nmain + (p.sum_mode == 1 ? p.nsum : 0));
     if (role == 3 && f16)
-        hipLaunchKernelGGL((lvt_conv_wgrad_frames_kernel<1, 2>), dim3((unsigned)(4 * p.nchunks * splits)), dim3(WG_THREADS), 0, s, p);
+        hipLaunchKernelGGL((lvt_conv_wgrad_frames_kernel<1, 2>), dim3(grid), dim3(WG_THREADS), 0, s, p);
     else if (role == 3)
-        hipLaunchKernelGGL((lvt_conv_wgrad_frames_kernel<1, 1>), dim3((unsigned)(4 * p.nchunks * splits)), dim3(WG_THREADS), 0, s, p);
+        hipLaunchKernelGGL((lvt_conv_wgrad_frames_kernel<1, 1>), dim3(grid), dim3(WG_THREADS), 0, s, p);
     else if (f16)
-        hipLaunchKernelGGL((lvt_conv_wgrad_frames_kernel<0, 2>), dim3((unsigned)(p.nchunks * splits)), dim3(WG_THREADS), 0, s, p);
+        hipLaunchKernelGGL((lvt_conv_wgrad_frames_kernel<0, 2>), dim3(grid), dim3(WG_THREADS), 0, s, p);
     else
-        hipLaunchKernelGGL((lvt_conv_wgrad_frames_kernel<0, 1>), dim3((unsigned)(p.nchunks * splits)), dim3(WG_THREADS), 0, s, p);
+        hipLaunchKernelGGL((lvt_conv_wgrad_frames_kernel<0, 1>), dim3(grid), dim3(WG_THREADS), 0, s, p);
     LVT_CHECK_LAUNCH("lvt_conv_wgrad_frames_kernel");
     if (role != 2) {
         unpack_plain(p.partial, p.partial_stride, splits, dw, g, Ci_real, Co_real, s);
@@ -412,7 +442,7 @@ int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float 
     LVT_CHECK_LAUNCH("wgrad unpack");
     if (db) {
         hipLaunchKernelGGL(lvt_wgrad_bias_reduce_kernel, dim3((unsigned)lvt_cdiv(Co_real, 4)), dim3(256), 0, s,
-                           (const float *)p.colsum_partial, splits, g->Co, Co_real, db);
+                           (const float *)p.colsum_partial, p.nsum, g->Co, Co_real, db);
         LVT_CHECK_LAUNCH("lvt_wgrad_bias_reduce_kernel");
     }
     return LVT_OK;
