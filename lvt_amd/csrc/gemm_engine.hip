@@ -2079,6 +2079,11 @@ extern "C" int lvt_conv3d_fwd_parity(const lvt_conv_geom *g, const float *x, con
     return LVT_OK;
 }
 
+// image-side 4 -> 128 channel k4 s2 convolution of the f16x2 arithmetic (thin_conv.hip)
+bool lvt_conv4s2_img_ok(const lvt_conv_geom *g, int flags);
+int lvt_conv4s2_img_launch(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias, const float *res,
+                           const float *mask, float *y, int flags, const float *x_amax, const float *w_amax, float *y_amax,
+                           hipStream_t s);
 extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias,
                               const float *res, const float *mask, float *y, int flags, const lvt_amax_io *ax, void *stream) {
     int rc = check_geom(g, "conv3d_fwd"); if (rc) return rc;
@@ -2095,6 +2100,8 @@ extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const floa
     p.alpha = 1.f; p.flags = flags; p.bias = bias; p.res = res; p.ldr = g->Co; p.mask = mask; p.ldm = g->Co;
     p.splits = 1; p.g = *g;
     LVT_REQUIRE_AMAX(flags, ax, "conv3d_fwd"); set_amax(p, ax);
+    if (lvt_conv4s2_img_ok(g, flags) && lvt_aligned16(x) && lvt_aligned16(wp) && M * g->Co < (1LL << 40))
+        return lvt_conv4s2_img_launch(g, x, wp, bias, res, mask, y, flags, ax->a, ax->b, ax->c, (hipStream_t)stream);
     {
         auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
         bool ok = patch_conv_eligible(g, flags) && al16(x) && al16(wp) && al16(y);
@@ -2125,6 +2132,9 @@ extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const floa
         }
     }
     if (g->Co <= 32) return launch_tile<A_CONV_K, B_NPLAIN, 128, 32, 4, 1>(p, 1, (hipStream_t)stream);
+#ifdef LVT_CX_SMALLK64
+    if (p.K <= 64) return launch_tile<A_CONV_K, B_NPLAIN, 64, 128, 2, 2>(p, 1, (hipStream_t)stream);
+#endif
     return launch_tile<A_CONV_K, B_NPLAIN, 128, 128, 2, 2>(p, 1, (hipStream_t)stream);
 }
 

@@ -318,6 +318,143 @@ __global__ __launch_bounds__(TM_THREADS) void lvt_convt4_mfma_kernel(const float
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The image-side strided convolution 4 -> 128 channels, k4 s2 p1 (the first encoder layer and, as the backward-data of the
+// ConvTranspose above, the first decoder gradient), LVT_MATH_F16X2.  Its reduction is 16 taps x 4 channels = 64 long: on the
+// implicit-GEMM tile engine a 128 x 128 tile is two k-tiles between an im2col gather and a 64 KB epilogue (144 us per launch
+// for a 268 MB output, 16 B gathers).  Here a wave owns 32 consecutive output pixels of one image row and all 128 channels:
+//   * A operand straight from global memory: lane (pixel m, half h) needs the taps (kh = step, kw = 2h, 2h + 1) x 4 channels of a
+//     k-step, i.e. TWO ADJACENT input pixels = one 32-byte run; split in registers, no LDS, next tile's loads under the MFMAs;
+//   * B operand: the 64 x 128 weight split once per workgroup into fp16 planes [column][k] (37 KB of LDS);
+//   * 48 MFMAs (32x32x16) per tile; the epilogue writes 128-byte runs per pixel (bias / residual / ReLU / mask as on the engine)
+//     and folds max |y| for the next layer's scale.  Workgroups are persistent (waves are independent: no barrier in the loop).
+// ------------------------------------------------------------------------------------------------
+typedef float ic_f32x16 __attribute__((ext_vector_type(16)));
+#define IC_KP (64 + 8)                 // halves per weight column
+#define IC_PL (128 * IC_KP)
+#define IC_THREADS 256
+struct IcParams {
+    const float *x, *wp, *bias, *res, *mask; float *y;
+    int N, Hi, Wi, Ho, Wo, flags;
+    const float *x_amax, *w_amax; float *y_amax;
+};
+template <bool RES, bool MASK>
+__global__ __launch_bounds__(IC_THREADS, 2) void lvt_conv4s2_img_kernel(const IcParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned short Bp[2 * IC_PL];
+    __shared__ float amax_scratch[IC_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    int unscale = 0;
+    const float sx = tm_scale(p.x_amax, unscale), sw = tm_scale(p.w_amax, unscale);
+    // weight planes: Bp[column n][k] = wp[k][n], k = tap * 4 + ci
+    for (int idx = tid; idx < 16 * 128; idx += IC_THREADS) {
+        const int n = idx & 127, k4 = idx >> 7;
+        const float *w = p.wp + (long long)(k4 * 4) * 128 + n;
+        unsigned short *d = Bp + n * IC_KP + k4 * 4;
+        tm_split4(make_float4(w[0], w[128], w[256], w[384]), sw, d, d + IC_PL);
+    }
+    __syncthreads();
+
+    const int nwt = p.Wo / 32;
+    const long long ntiles = (long long)p.N * p.Ho * nwt, tstep = (long long)gridDim.x * (IC_THREADS / 64);
+    float4 a[4][2], an[4][2];
+    auto fetch = [&](long long t, float4 (&dst)[4][2]) {
+        const int wt = (int)(t % nwt); const long long r = t / nwt;
+        const int oh = (int)(r % p.Ho); const long long img = r / p.Ho;
+        const int iw0 = 2 * (wt * 32 + m) - 1 + 2 * h;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const int ih = 2 * oh - 1 + s_;
+            const bool rok = (unsigned)ih < (unsigned)p.Hi;
+            const float *src = p.x + ((img * p.Hi + ih) * p.Wi + iw0) * 4;
+            dst[s_][0] = (rok && (unsigned)iw0 < (unsigned)p.Wi) ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dst[s_][1] = (rok && (unsigned)(iw0 + 1) < (unsigned)p.Wi) ? *reinterpret_cast<const float4 *>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    float am = 0.f;
+    long long t = (long long)blockIdx.x * (IC_THREADS / 64) + wave;
+    if (t < ntiles) fetch(t, a);
+    for (; t < ntiles; t += tstep) {
+        if (t + tstep < ntiles) fetch(t + tstep, an);
+        ic_f32x16 acc[4], acx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; acx[j][r] = 0.f; }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            uint4 uh, ul;
+            tm_split_pair(a[s_][0].x, a[s_][0].y, sx, uh.x, ul.x); tm_split_pair(a[s_][0].z, a[s_][0].w, sx, uh.y, ul.y);
+            tm_split_pair(a[s_][1].x, a[s_][1].y, sx, uh.z, ul.z); tm_split_pair(a[s_][1].z, a[s_][1].w, sx, uh.w, ul.w);
+            const tm_f16x8 ah = __builtin_bit_cast(tm_f16x8, uh), al = __builtin_bit_cast(tm_f16x8, ul);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned short *bp = Bp + (32 * j + m) * IC_KP + 16 * s_ + 8 * h;
+                const tm_f16x8 bh = *reinterpret_cast<const tm_f16x8 *>(bp), bl = *reinterpret_cast<const tm_f16x8 *>(bp + IC_PL);
+                acx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acx[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[j], 0, 0, 0);
+                acx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acx[j], 0, 0, 0);
+            }
+        }
+        // lane = channel 32 j + m of pixels (r & 3) + 8 (r >> 2) + 4 h of the tile: 128-byte runs per pixel and j
+        const long long row0 = t * 32;                       // tiles are consecutive 32-pixel runs of the (N, Ho, Wo) raster
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = 32 * j + m;
+            const float bias = (p.flags & LVT_EPI_BIAS) ? p.bias[col] : 0.f;
+            // the residual / mask values of the 16 rows are requested together, before the first store (the compiler must keep
+            // a load behind every earlier store to memory it cannot tell apart: one by one they cost a round trip each --
+            // 331 us per launch for the masked backward-data use against 69 us for the plain one)
+            float rv[16], mv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long o = (row0 + (r & 3) + 8 * (r >> 2) + 4 * h) * 128 + col;
+                rv[r] = RES ? p.res[o] : 0.f;
+                mv[r] = MASK ? p.mask[o] : 1.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long o = (row0 + (r & 3) + 8 * (r >> 2) + 4 * h) * 128 + col;
+                float v = ldexpf(fmaf(acx[j][r], 1.f / 2048.f, acc[j][r]), unscale) + bias + rv[r];
+                if (p.flags & LVT_EPI_RELU) v = fmaxf(v, 0.f);
+                v = mv[r] > 0.f ? v : 0.f;
+                p.y[o] = v;
+                am = fmaxf(am, lvt_absf(v));
+            }
+        }
+        if (t + tstep < ntiles) {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) { a[s_][0] = an[s_][0]; a[s_][1] = an[s_][1]; }
+        }
+    }
+    if (p.y_amax) lvt_block_amax_commit(am, p.y_amax, amax_scratch);
+}
+// serves: Kt = 1, 4x4, stride 2, pad 1, Ci = 4 (3 carried as 4), Co = 128, Wo % 32 == 0, epilogue flags within
+// BIAS | RESIDUAL | RELU | MASK, f16x2 arithmetic (called from lvt_conv3d_fwd, gemm_engine.hip)
+bool lvt_conv4s2_img_ok(const lvt_conv_geom *g, int flags) {
+    static const int off = getenv("LVT_NO_IMG_CONV") ? 1 : 0;
+    return !off && (flags & LVT_MATH_F16X2) && !(flags & ~(LVT_EPI_BIAS | LVT_EPI_RESIDUAL | LVT_EPI_RELU | LVT_EPI_MASK | LVT_MATH_F16X2)) &&
+           g->Kt == 1 && g->Kh == 4 && g->Kw == 4 && g->st == 1 && g->sh == 2 && g->sw == 2 && g->pt == 0 && g->ph == 1 && g->pw == 1 &&
+           g->Ti == 1 && g->To == 1 && g->Ci == 4 && g->Co == 128 && g->Wo % 32 == 0 && g->Hi == 2 * g->Ho && g->Wi == 2 * g->Wo;
+}
+int lvt_conv4s2_img_launch(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias, const float *res,
+                           const float *mask, float *y, int flags, const float *x_amax, const float *w_amax, float *y_amax,
+                           hipStream_t s) {
+    IcParams p;
+    p.x = x; p.wp = wp; p.bias = bias; p.res = res; p.mask = mask; p.y = y;
+    p.N = g->N; p.Hi = g->Hi; p.Wi = g->Wi; p.Ho = g->Ho; p.Wo = g->Wo; p.flags = flags;
+    p.x_amax = x_amax; p.w_amax = w_amax; p.y_amax = y_amax;
+    const long long ntiles = (long long)g->N * g->Ho * (g->Wo / 32), wgs = lvt_cdiv(ntiles, IC_THREADS / 64);
+    const unsigned grid = (unsigned)(wgs < 2 * LVT_NUM_CU ? wgs : 2 * LVT_NUM_CU);          // persistent: two workgroups per CU
+    const bool r_ = flags & LVT_EPI_RESIDUAL, m_ = flags & LVT_EPI_MASK;
+    if (r_ && m_) hipLaunchKernelGGL((lvt_conv4s2_img_kernel<true, true>), dim3(grid), dim3(IC_THREADS), 0, s, p);
+    else if (r_) hipLaunchKernelGGL((lvt_conv4s2_img_kernel<true, false>), dim3(grid), dim3(IC_THREADS), 0, s, p);
+    else if (m_) hipLaunchKernelGGL((lvt_conv4s2_img_kernel<false, true>), dim3(grid), dim3(IC_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((lvt_conv4s2_img_kernel<false, false>), dim3(grid), dim3(IC_THREADS), 0, s, p);
+    LVT_CHECK_LAUNCH("lvt_conv4s2_img_kernel");
+    return LVT_OK;
+}
+
 extern "C" int lvt_convt4_fwd(const float *x, const float *w, const float *bias, int N, int Hi, int Wi, int Ci, int Cr,
                               int act_tanh, float *y, int flags, const lvt_amax_io *ax, void *stream) {
     LVT_REQUIRE(x && w && bias && y && N > 0 && Hi > 0 && Wi > 0, "convT4_fwd: bad args");

@@ -317,6 +317,32 @@ def test_frame_resident_weight_gradient_stride2(Ci, N, math_mode):
     assert rel_err(G.conv_bwd_weight(g, _nhwc(x.detach()).to(dev), _nhwc(gy).to(dev), Ci, Co).squeeze(2), w.grad) < 5e-5   # db == NULL
 
 
+@pytest.mark.parametrize("N,H,W,real_ci", [(3, 64, 64, 3), (70, 64, 64, 4), (2, 16, 128, 3), (5, 6, 64, 4)])
+def test_image_side_strided_conv(N, H, W, real_ci, math_mode):
+    """Conv(<=4 -> 128, k4 s2 p1) on images: the first encoder layer and the backward-data of the decoder's output layer.  In
+    f16x2 mode it runs on its own kernel (a wave = 32 output pixels x 128 channels, A operand straight from global memory;
+    more tiles than resident waves, ragged heights, zero-padded 4th channel included), otherwise on the implicit-GEMM engine;
+    every epilogue the layers use (bias + ReLU; residual + ReLU-mask), the reported max |y| and run-to-run equality."""
+    from lvt_amd.hip import gemm as G, binding as L
+    x = _rand(N, 4, H, W)
+    x[:, real_ci:] = 0
+    w, b = _rand(128, 4, 4, 4, seed=1) * 0.1, _rand(128, seed=2)
+    w[:, real_ci:] = 0
+    res, msrc = _rand(N, 128, H // 2, W // 2, seed=3), _rand(N, 128, H // 2, W // 2, seed=4)
+    y0 = F.conv2d(x.double(), w.double(), None, stride=2, padding=1)
+    dev = _dev()
+    g = G.conv_geom(N, 1, H, W, 4, 128, (1, 4, 4), (1, 2, 2), (0, 1, 1))
+    wp = G.pack_weight(g, w.unsqueeze(2).to(dev), 4, 128)
+    xd = _nhwc(x).to(dev)
+    y1 = G.conv_fwd(g, xd, wp, bias=b.to(dev), flags=L.EPI_RELU)
+    assert rel_err(_nchw(y1), torch.relu(y0 + b.double().view(1, -1, 1, 1)).float()) < TOL
+    if L.f16x2():
+        assert float(L.amax_of(y1)) == float(y1.abs().max())            # the launch reported max |y|
+    y2 = G.conv_fwd(g, xd, wp, res=_nhwc(res).to(dev), mask=_nhwc(msrc).to(dev))
+    assert rel_err(_nchw(y2), ((y0 + res.double()) * (msrc > 0)).float()) < TOL
+    assert torch.equal(y1, G.conv_fwd(g, xd, wp, bias=b.to(dev), flags=L.EPI_RELU))
+
+
 def test_conv3d_causal_geometry():
     """MaskedConv3d geometry (K16): kernel 3x3x3, front pads (2,2,1), T=2 to exercise the t taps."""
     from lvt_amd.hip import gemm as G
