@@ -874,54 +874,117 @@ __device__ __forceinline__ void lvt_epilogue_vec(const KParams &p, f32x16 (&acc)
 #pragma unroll
             for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * SW + 32 * j + l31] = acc[i][j][r];
         __syncthreads();
+        if (AMODE != A_KPLAIN && AMODE != A_MPLAIN && p.splits <= 1 && (flags & LVT_EPI_MASK) && !(flags & (LVT_EPI_PLANES | LVT_EPI_ACCUM))) {
+            constexpr int NU = 32 * C4 / 64;
+            // MASK forms of the convolution kernels (ReLU-backward: the mask is an activation of the forward pass, cold in the
+            // caches): every mask / residual value of the sub-tile is requested before the first store -- a load may not pass an
+            // earlier store to memory the compiler cannot tell apart, and behind the per-iteration flag test each one sat in its own
+            // block, one round trip per 256-byte row segment.  -0.15 ms per VQ-VAE step.  The plain GEMMs and the other forms keep the
+            // loop below: in the DSFVT step the two-phase form gained nothing on the masked product and cost the others registers
+            // (profiles/r04_wide_gemm_loop_experiments.txt, block 11).
+            long long oaddr[NU];                       // orow of the unit, -1: outside the matrix
+            int ocol[NU];
 #pragma unroll
-        for (int u = 0; u < 32 * C4 / 64; ++u) {
-            const int idx = lane + 64 * u;
-            const int rowl = idx / C4, c4 = idx % C4;
-            const int row = m0 + wm * (TM * 32) + i * 32 + rowl;
-            const int col = n0 + wn * SW + 4 * c4;
-            if (row < p.M && col < p.N) {
-                float4 v = *reinterpret_cast<const float4 *>(&tile[rowl * SW + 4 * c4]);
-                long long orow = row;
-                if (AMODE == A_PATCH) orow = patch_orow(row);
-                if (AMODE == A_PATCHT) orow = patcht_orow(row, cls);
-                if (AMODE == A_CONVT_K) {
-                    const lvt_conv_geom &g = p.g;
-                    int m = row;
-                    const int qw = m % p.Wq; m /= p.Wq;
-                    const int qh = m % p.Hq; m /= p.Hq;
-                    const int qt = m % p.Tq; const int n = m / p.Tq;
-                    orow = (((long long)n * g.Ti + (g.st * qt + rt)) * g.Hi + (g.sh * qh + rh)) * g.Wi + (g.sw * qw + rw);
+            for (int u = 0; u < NU; ++u) {
+                const int idx = lane + 64 * u;
+                const int rowl = idx / C4, c4 = idx % C4;
+                const int row = m0 + wm * (TM * 32) + i * 32 + rowl;
+                const int col = n0 + wn * SW + 4 * c4;
+                ocol[u] = col;
+                long long orow = -1;
+                if (row < p.M && col < p.N) {
+                    orow = row;
+                    if (AMODE == A_PATCH) orow = patch_orow(row);
+                    if (AMODE == A_PATCHT) orow = patcht_orow(row, cls);
+                    if (AMODE == A_CONVT_K) {
+                        const lvt_conv_geom &g = p.g;
+                        int m = row;
+                        const int qw = m % p.Wq; m /= p.Wq;
+                        const int qh = m % p.Hq; m /= p.Hq;
+                        const int qt = m % p.Tq; const int n = m / p.Tq;
+                        orow = (((long long)n * g.Ti + (g.st * qt + rt)) * g.Hi + (g.sh * qh + rh)) * g.Wi + (g.sw * qw + rw);
+                    }
                 }
-                if (p.splits > 1) {
-                    *reinterpret_cast<float4 *>(p.partial + split * p.partial_stride + (long long)z * p.M * p.N + orow * p.N + col) = v;
-                } else {
+                oaddr[u] = orow;
+            }
+            float4 rv[NU], mv[NU];
+            if (flags & LVT_EPI_RESIDUAL) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) rv[u] = oaddr[u] >= 0 ? ldg4(p.res + coff + oaddr[u] * p.ldr + ocol[u]) : zero4();
+            } else {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) rv[u] = zero4();
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) mv[u] = oaddr[u] >= 0 ? ldg4(p.mask + coff + oaddr[u] * p.ldm + ocol[u]) : zero4();
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int idx = lane + 64 * u;
+                const int rowl = idx / C4, c4 = idx % C4;
+                const int col = ocol[u];
+                const long long orow = oaddr[u];
+                if (orow >= 0) {
+                    float4 v = *reinterpret_cast<const float4 *>(&tile[rowl * SW + 4 * c4]);
                     v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
                     if (flags & LVT_EPI_BIAS) { const float4 b = ldg4(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                    if (flags & LVT_EPI_RESIDUAL) { const float4 b = ldg4(p.res + coff + orow * p.ldr + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                    v.x += rv[u].x; v.y += rv[u].y; v.z += rv[u].z; v.w += rv[u].w;
                     if (flags & LVT_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     if (flags & LVT_EPI_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
-                    if (flags & LVT_EPI_MASK) {
-                        const float4 mk = ldg4(p.mask + coff + orow * p.ldm + col);
-                        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                    v.x = mv[u].x > 0.f ? v.x : 0.f; v.y = mv[u].y > 0.f ? v.y : 0.f; v.z = mv[u].z > 0.f ? v.z : 0.f; v.w = mv[u].w > 0.f ? v.w : 0.f;
+                    am = fmaxf(am, fmaxf(fmaxf(lvt_absf(v.x), lvt_absf(v.y)), fmaxf(lvt_absf(v.z), lvt_absf(v.w))));
+                    *reinterpret_cast<float4 *>(p.C + coff + orow * p.ldc + col) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 32 * C4 / 64; ++u) {
+                const int idx = lane + 64 * u;
+                const int rowl = idx / C4, c4 = idx % C4;
+                const int row = m0 + wm * (TM * 32) + i * 32 + rowl;
+                const int col = n0 + wn * SW + 4 * c4;
+                if (row < p.M && col < p.N) {
+                    float4 v = *reinterpret_cast<const float4 *>(&tile[rowl * SW + 4 * c4]);
+                    long long orow = row;
+                    if (AMODE == A_PATCH) orow = patch_orow(row);
+                    if (AMODE == A_PATCHT) orow = patcht_orow(row, cls);
+                    if (AMODE == A_CONVT_K) {
+                        const lvt_conv_geom &g = p.g;
+                        int m = row;
+                        const int qw = m % p.Wq; m /= p.Wq;
+                        const int qh = m % p.Hq; m /= p.Hq;
+                        const int qt = m % p.Tq; const int n = m / p.Tq;
+                        orow = (((long long)n * g.Ti + (g.st * qt + rt)) * g.Hi + (g.sh * qh + rh)) * g.Wi + (g.sw * qw + rw);
                     }
-                    if (!(flags & LVT_EPI_ACCUM)) am = fmaxf(am, fmaxf(fmaxf(lvt_absf(v.x), lvt_absf(v.y)), fmaxf(lvt_absf(v.z), lvt_absf(v.w))));
-                    if (flags & LVT_EPI_PLANES) {
-                        // C is a bf16 image: the result leaves as its exact 3-way bf16 split, one plane c_plane elements
-                        // after the other (the operand format of the fused attention kernels, attention_pipe.hip)
-                        uint2 p1, p2, p3;
-                        split3(v, p1, p2, p3);
-                        unsigned short *cp = reinterpret_cast<unsigned short *>(p.C) + coff + orow * p.ldc + col;
-                        *reinterpret_cast<uint2 *>(cp) = p1;
-                        *reinterpret_cast<uint2 *>(cp + p.c_plane) = p2;
-                        *reinterpret_cast<uint2 *>(cp + 2 * p.c_plane) = p3;
+                    if (p.splits > 1) {
+                        *reinterpret_cast<float4 *>(p.partial + split * p.partial_stride + (long long)z * p.M * p.N + orow * p.N + col) = v;
                     } else {
-                        float4 *cp = reinterpret_cast<float4 *>(p.C + coff + orow * p.ldc + col);
-                        if (flags & LVT_EPI_ACCUM) {
-                            const float4 c = *cp; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
-                            am = fmaxf(am, fmaxf(fmaxf(lvt_absf(v.x), lvt_absf(v.y)), fmaxf(lvt_absf(v.z), lvt_absf(v.w))));
+                        v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+                        if (flags & LVT_EPI_BIAS) { const float4 b = ldg4(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                        if (flags & LVT_EPI_RESIDUAL) { const float4 b = ldg4(p.res + coff + orow * p.ldr + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                        if (flags & LVT_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        if (flags & LVT_EPI_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+                        if (flags & LVT_EPI_MASK) {
+                            const float4 mk = ldg4(p.mask + coff + orow * p.ldm + col);
+                            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
                         }
-                        *cp = v;
+                        if (!(flags & LVT_EPI_ACCUM)) am = fmaxf(am, fmaxf(fmaxf(lvt_absf(v.x), lvt_absf(v.y)), fmaxf(lvt_absf(v.z), lvt_absf(v.w))));
+                        if (flags & LVT_EPI_PLANES) {
+                            // C is a bf16 image: the result leaves as its exact 3-way bf16 split, one plane c_plane elements
+                            // after the other (the operand format of the fused attention kernels, attention_pipe.hip)
+                            uint2 p1, p2, p3;
+                            split3(v, p1, p2, p3);
+                            unsigned short *cp = reinterpret_cast<unsigned short *>(p.C) + coff + orow * p.ldc + col;
+                            *reinterpret_cast<uint2 *>(cp) = p1;
+                            *reinterpret_cast<uint2 *>(cp + p.c_plane) = p2;
+                            *reinterpret_cast<uint2 *>(cp + 2 * p.c_plane) = p3;
+                        } else {
+                            float4 *cp = reinterpret_cast<float4 *>(p.C + coff + orow * p.ldc + col);
+                            if (flags & LVT_EPI_ACCUM) {
+                                const float4 c = *cp; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
+                                am = fmaxf(am, fmaxf(fmaxf(lvt_absf(v.x), lvt_absf(v.y)), fmaxf(lvt_absf(v.z), lvt_absf(v.w))));
+                            }
+                            *cp = v;
+                        }
                     }
                 }
             }
