@@ -217,6 +217,11 @@ size_t lvt_conv3d_bwd_weight_workspace_bytes(const lvt_conv_geom *g);
  * resident weight-gradient kernels of csrc/conv_wgrad.hip -- 3x3 / pad 1 layers of 16x16 frames and the 4x4 / stride 2 layer
  * with 256 channels on one side -- sum the dy rows / patches they stage as well).  Kept for callers written against 300.  */
 int lvt_conv3d_bwd_weight_fuses_bias(const lvt_conv_geom *g, int flags);
+/* In `flags` of lvt_conv3d_bwd_weight / lvt_conv3d_bwd_weight_fuses_bias: db (Ci_real floats) = column sums of X instead of dy --
+ * the bias gradient of a TRANSPOSED convolution, whose weight gradient is this call with the operands swapped (x = the gradient of
+ * the layer's output).  Served where the query answers 1 (the 4x4 / stride 2 frame-resident kernel: 32x32 <-> 16x16 frames, 256
+ * channels on the small side); elsewhere use lvt_colsum(x).                                                                  */
+#define LVT_WGRAD_DB_OF_X (1 << 20)
 /* flags: 0, LVT_MATH_F32 or LVT_MATH_F16X2 (ax->a = max |x|, ax->b = max |dy|; ax may be NULL otherwise).  The
  * frame-resident kernel keeps the fp16 low term UNSCALED in f16x2 mode (one accumulator set for nine taps): full 22-bit
  * operands within 2^-16 of the operand's max, gradually fewer bits below (csrc/conv_wgrad.hip).                          */

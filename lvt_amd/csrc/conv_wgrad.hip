@@ -38,8 +38,9 @@ struct WgParams {
     int Cp, N, frames_per_split, nchunks;
     float *partial; long long partial_stride;
     const float *p_amax, *q_amax;        // MATH == 2: max |P|, max |Q| (device scalars)
-    // bias gradient = column sums of dy, by the same launch.  sum_mode 2: dy is the patch operand -- every workgroup adds up the
-    // 32-channel patches it stages (once per frame: not in the row loop).  sum_mode 1: dy is the slab operand -- `nsum` EXTRA
+    // bias gradient = column sums of dy (or, for a transposed layer whose operands arrive swapped, of x), by the same launch.
+    // sum_mode 2: the summed tensor is the patch operand -- every workgroup adds up the 32-channel patches it stages (once per
+    // frame: not in the row loop; MODE 1: one partial row per (split, parity class), the classes tile the pixels exactly once).  sum_mode 1: dy is the slab operand -- `nsum` EXTRA
     // workgroups (blockIdx >= nmain) stream one range of dy rows each and do nothing else; they run beside the matrix
     // workgroups (the rows are in L2 / MALL from their staging).  Summing inside slab_store instead put a branch into the row loop
     // and cost the stride-2 kernel 36 % (459 -> 625 us: its 24 MFMAs per row leave the scheduler one block to interleave).
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
         for (int j = 0; j < PPASS; ++j) {
             const int u = tid + WG_THREADS * j;
             if (u < PUNITS) {
-                if (MODE == 0 && sum_p) { cs.x += pv[j].x; cs.y += pv[j].y; cs.z += pv[j].z; cs.w += pv[j].w; }    // (halo: zeros)
+                if (sum_p) { cs.x += pv[j].x; cs.y += pv[j].y; cs.z += pv[j].z; cs.w += pv[j].w; }    // (halo / out-of-range: zeros)
                 unsigned short *d = patch + (u >> 3) * WG_PP + (u & 7) * 4;
                 if (MATH == 2) {
                     uint2 ph, pl;
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
         if (tid < 32) {
             float t = 0.f;
             for (int i = 0; i < WG_THREADS / 8; ++i) t += scratch[(i * 8 + (tid >> 2)) * 4 + (tid & 3)];
-            p.colsum_partial[(long long)split * Cp + pc * 32 + tid] = t;
+            p.colsum_partial[((long long)split * (MODE == 1 ? 4 : 1) + cls) * Cp + pc * 32 + tid] = t;
         }
     }
     // partial[split][tap * Cp + pc * 32 + m][32 * wave + n]: lane = column n, 16 rows m per register file
@@ -402,12 +403,13 @@ int lvt_wgrad_frames_role(const lvt_conv_geom *g, int flags) { return wg_role(g,
 size_t lvt_wgrad_frames_workspace_bytes(const lvt_conv_geom *g) {
     const int role = wg_role(g);
     if (!role) return 0;
-    return (size_t)wg_splits(g, role) * ((size_t)g->Kh * g->Kw * g->Ci * g->Co + WG_SUM_PARTS * g->Co) * sizeof(float);     // + the bias partials
+    const size_t bias_rows = (size_t)WG_SUM_PARTS * g->Co > (size_t)4 * g->Ci ? (size_t)WG_SUM_PARTS * g->Co : (size_t)4 * g->Ci;
+    return (size_t)wg_splits(g, role) * ((size_t)g->Kh * g->Kw * g->Ci * g->Co + bias_rows) * sizeof(float);     // + the bias partials
 }
 int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, int Ci_real, int Co_real,
                             void *workspace, hipStream_t s, void (*unpack_plain)(const float *, long long, int, float *,
                                                                                  const lvt_conv_geom *, int, int, hipStream_t),
-                            const float *x_amax, const float *dy_amax, float *db) {
+                            const float *x_amax, const float *dy_amax, float *db, int db_of_x) {
     const int role = wg_role(g);
     const bool f16 = x_amax && dy_amax;                  // LVT_MATH_F16X2 (checked by the caller)
     WgParams p;
@@ -417,11 +419,12 @@ int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float 
     const int splits = wg_splits(g, role);
     p.frames_per_split = (g->N + splits - 1) / splits;
     p.partial = (float *)workspace; p.partial_stride = (long long)g->Kh * g->Kw * g->Ci * g->Co;
-    p.sum_mode = db ? (role == 2 ? 2 : 1) : 0;             // dy is the patch operand in role 2, the slab (256 = Co channels) otherwise
+    // dy is the patch operand in role 2, the slab (256 = Co channels) otherwise; x (db_of_x: role 3 only) is the patch operand there
+    p.sum_mode = db ? ((role == 2 || db_of_x) ? 2 : 1) : 0;
     p.colsum_partial = p.partial + (long long)splits * p.partial_stride;
     p.nsplits = splits;
     p.nmain = (role == 3 ? 4 : 1) * p.nchunks * splits;
-    p.nsum = p.sum_mode == 1 ? WG_SUM_PARTS * splits : splits;
+    p.nsum = p.sum_mode == 1 ? WG_SUM_PARTS * splits : (role == 3 ? 4 * splits : splits);
     const unsigned grid = (unsigned)(p.nmain + (p.sum_mode == 1 ? p.nsum : 0));
     if (role == 3 && f16)
         hipLaunchKernelGGL((lvt_conv_wgrad_frames_kernel<1, 2>), dim3(grid), dim3(WG_THREADS), 0, s, p);
@@ -442,7 +445,7 @@ int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float 
     LVT_CHECK_LAUNCH("wgrad unpack");
     if (db) {
         hipLaunchKernelGGL(lvt_wgrad_bias_reduce_kernel, dim3((unsigned)lvt_cdiv(Co_real, 4)), dim3(256), 0, s,
-                           (const float *)p.colsum_partial, p.nsum, g->Co, Co_real, db);
+                           (const float *)p.colsum_partial, p.nsum, db_of_x ? g->Ci : g->Co, db_of_x ? Ci_real : Co_real, db);
         LVT_CHECK_LAUNCH("lvt_wgrad_bias_reduce_kernel");
     }
     return LVT_OK;

@@ -2294,7 +2294,7 @@ size_t lvt_wgrad_frames_workspace_bytes(const lvt_conv_geom *g);
 int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, int Ci_real, int Co_real,
                             void *workspace, hipStream_t s, void (*unpack_plain)(const float *, long long, int, float *,
                                                                                  const lvt_conv_geom *, int, int, hipStream_t),
-                            const float *x_amax, const float *dy_amax, float *db);
+                            const float *x_amax, const float *dy_amax, float *db, int db_of_x);
 // the tiled unpack kernel turns a [64 co][4 ci x taps] tile through dynamic LDS: served while that tile fits in 64 KB
 static bool unpack_tiled_ok(const lvt_conv_geom *g, int Ci_real, int Co_real) {
     const int taps = g->Kt * g->Kh * g->Kw;
@@ -2323,6 +2323,7 @@ static void unpack_plain_wgrad(const float *partial, long long stride, int split
 extern "C" int lvt_conv3d_bwd_weight_fuses_bias(const lvt_conv_geom *g, int flags) {
     static const int off = getenv("LVT_NO_FRAME_BIAS") ? 1 : 0;
     if (!g) return 0;
+    if (flags & LVT_WGRAD_DB_OF_X) return !off && lvt_wgrad_frames_role(g, flags) == 3;      // (the stride-2 frame-resident kernel only)
     return off && lvt_wgrad_frames_role(g, flags) ? 0 : 1;
 }
 
@@ -2354,12 +2355,16 @@ extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, con
     }
     const long long pix = (long long)g->N * g->To * g->Ho * g->Wo;
     LVT_REQUIRE(pix < 0x7fffffffLL, "conv3d_bwd_weight: too many positions");
-    LVT_REQUIRE((flags & ~(LVT_MATH_F32 | LVT_MATH_F16X2)) == 0, "conv3d_bwd_weight: only LVT_MATH_* is accepted in flags");
+    LVT_REQUIRE((flags & ~(LVT_MATH_F32 | LVT_MATH_F16X2 | LVT_WGRAD_DB_OF_X)) == 0, "conv3d_bwd_weight: only LVT_MATH_* / LVT_WGRAD_DB_OF_X are accepted in flags");
+    const int db_of_x = (flags & LVT_WGRAD_DB_OF_X) ? 1 : 0;
+    flags &= ~LVT_WGRAD_DB_OF_X;
+    LVT_REQUIRE(!db_of_x || !db || (lvt_wgrad_frames_role(g, flags) == 3 && lvt_aligned16(x) && lvt_aligned16(dy)),
+                "conv3d_bwd_weight: LVT_WGRAD_DB_OF_X is served by the stride-2 frame-resident kernel only (lvt_conv3d_bwd_weight_fuses_bias)");
     LVT_REQUIRE_AMAX(flags, ax, "conv3d_bwd_weight");
     const bool f16 = math_of(flags) == 2;
     if (lvt_wgrad_frames_role(g, flags) && lvt_aligned16(x) && lvt_aligned16(dy)) {
         rc = lvt_wgrad_frames_launch(g, x, dy, dw, Ci_real, Co_real, workspace, (hipStream_t)stream, unpack_plain_wgrad,
-                                     f16 ? ax->a : nullptr, f16 ? ax->b : nullptr, db);
+                                     f16 ? ax->a : nullptr, f16 ? ax->b : nullptr, db, db_of_x);
         if (rc) return rc;
         LVT_CHECK_LAUNCH("conv3d_bwd_weight (frame-resident)");
         return LVT_OK;

@@ -18,6 +18,7 @@ ABI_VERSION = 400           # lvt_version() of the library this module binds (ar
 MATH_F32 = 1 << 16          # per-call arithmetic selectors of the engine entry points (include/lvt_hip.h)
 MATH_F16X2 = 1 << 18
 ONEHOT_DENSE = 1 << 19
+WGRAD_DB_OF_X = 1 << 20
 
 
 class LvtError(RuntimeError):

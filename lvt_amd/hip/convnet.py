@@ -13,11 +13,15 @@ transposed passes through `conv_bwd_data(wt=...)` (3x3, as a forward convolution
 `conv_bwd_data(wph=...)` (stride 2, phase by phase), weight gradients inside `conv_bwd_weight`.  The extra
 weight packs are made next to the forward one; every other geometry takes the implicit-GEMM engine.
 """
+import os
+
 import torch
 
 from . import binding as L
 from . import gemm as G
 from . import ew
+
+BIAS_OF_X = not os.environ.get("LVT_NO_BIAS_OF_X")      # A/B switch: transposed layers' bias gradient inside the weight-gradient launch
 
 
 class Layer:
@@ -128,7 +132,11 @@ def stack_backward(layers, x, outs, saved, grad_out, need_input_grad=False):
         if ly.kind == "conv":
             dw, db = G.conv_bwd_weight(g, inp, gp, ly.cin, ly.cout, want_bias=True)     # db rides on the dy stream
         else:
-            dw = G.conv_bwd_weight(g, gp, inp, ly.cout, ly.cin)
+            # transposed layer: the same call with the operands swapped; its bias gradient is the column sum of gp, which the
+            # stride-2 frame-resident kernel adds up from the patches it stages
+            dw, db = G.conv_bwd_weight(g, gp, inp, ly.cout, ly.cin, want_bias=True, bias_of_x=BIAS_OF_X)
+            if not BIAS_OF_X:
+                db = None
         if db is None:
             db = G.colsum(gp, gp.numel() // co, co)[:ly.cout]
         grads[i] = (dw, db)      # dw is (Co, Ci, Kt, Kh, Kw); callers view it as the parameter shape

@@ -281,20 +281,23 @@ def convT4_fwd(x, w, bias, act_tanh):
     return y
 
 
-def conv_bwd_weight(g, x, dy, Ci_real, Co_real, want_bias=False):
+def conv_bwd_weight(g, x, dy, Ci_real, Co_real, want_bias=False, bias_of_x=False):
     """-> dw, or (dw, db) with want_bias: db = column sums of dy (the bias gradient of a forward conv), produced by
-    the same launch."""
+    the same launch.  bias_of_x: db = column sums of x instead (the bias gradient of a transposed layer, whose weight
+    gradient is this call with the operands swapped); db is None where the launch cannot produce it."""
     L.require(x, dy)
     lib = L.lib()
     dw = torch.empty(Co_real, Ci_real, g.Kt, g.Kh, g.Kw, dtype=torch.float32, device=x.device)
     nws = lib.lvt_conv3d_bwd_weight_workspace_bytes(C.byref(g))
     ws = L.workspace(nws, x.device, "wgrad")
-    fused_bias = want_bias and bool(lib.lvt_conv3d_bwd_weight_fuses_bias(C.byref(g), L.math_flag()))
-    db = torch.empty(Co_real, dtype=torch.float32, device=x.device) if fused_bias else None
+    xflag = L.WGRAD_DB_OF_X if bias_of_x else 0
+    fused_bias = want_bias and bool(lib.lvt_conv3d_bwd_weight_fuses_bias(C.byref(g), L.math_flag() | xflag))
+    db = torch.empty(Ci_real if bias_of_x else Co_real, dtype=torch.float32, device=x.device) if fused_bias else None
     io = L.amax_io(x, dy)
     t0 = L.TIMER.begin() if L.TIMER is not None else None
     L.check(lib.lvt_conv3d_bwd_weight(C.byref(g), L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), Ci_real, Co_real,
-                                      L.math_flag(), L.io_ref(io), L.ptr(ws), nws, L.stream_ptr()), "lvt_conv3d_bwd_weight")
+                                      L.math_flag() | (xflag if fused_bias else 0), L.io_ref(io), L.ptr(ws), nws, L.stream_ptr()),
+            "lvt_conv3d_bwd_weight")
     if t0 is not None:
         L.TIMER.end("conv_bwd_weight", conv_flops(g), t0)
     return (dw, db) if want_bias else dw

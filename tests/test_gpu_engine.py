@@ -315,6 +315,12 @@ def test_frame_resident_weight_gradient_stride2(Ci, N, math_mode):
     assert rel_err(dw.squeeze(2), w.grad) < 5e-5
     assert rel_err(db, gy.sum((0, 2, 3))) < 2e-6                  # summed from the dy rows the parity classes' chunk 0 stages
     assert rel_err(G.conv_bwd_weight(g, _nhwc(x.detach()).to(dev), _nhwc(gy).to(dev), Ci, Co).squeeze(2), w.grad) < 5e-5   # db == NULL
+    # the transposed layer's bias gradient: column sums of the x operand (LVT_WGRAD_DB_OF_X), from the patches the kernel stages
+    dw2, dbx = G.conv_bwd_weight(g, _nhwc(x.detach()).to(dev), _nhwc(gy).to(dev), Ci, Co, want_bias=True, bias_of_x=True)
+    if math_mode == "f32":
+        assert dbx is None                                         # implicit-GEMM route: callers fall back to lvt_colsum
+    else:
+        assert rel_err(dbx, x.detach().sum((0, 2, 3))) < 2e-6 and torch.equal(dw2, dw)
 
 
 @pytest.mark.parametrize("N,H,W,real_ci", [(3, 64, 64, 3), (70, 64, 64, 4), (2, 16, 128, 3), (5, 6, 64, 4)])
