@@ -111,8 +111,7 @@ def test_dsfvt_train_step_64_slices_equals_mean_of_chunks(math_mode):
         if k.endswith("dt_bank"):
             # a DSFVT block is one frame deep: the temporal bank has ONE column, i.e. the same number added to every
             # score of a row, whose softmax gradient is exactly zero -- what is left is rounding noise
-            # (the fused backward forms dS with delta_i = sum_d dO_id O_id, rounded separately from sum_j P_ij dP_ij: the row
-            # sums of dS then cancel to ~1e-7 of their terms instead of exactly, i.e. ~1e-3 of the h-bank gradient here)
+            # (the row sums of dS = P o (dP - delta) cancel to ~1e-7 of their terms, not exactly: ~1e-3 of the h-bank gradient)
             assert float(gf.abs().max()) < 5e-3 * float(g_full[k.replace("dt_bank", "dh_bank")].abs().max()), k
             continue
         acc = parts[0][1][k].double()
