@@ -174,6 +174,11 @@ typedef struct {
 /* w: [Co_real][Ci_real][Kt][Kh][Kw] (torch layout)  ->  wp: [taps][Ci][Co], zero padded.            */
 int lvt_conv3d_pack_weight(const lvt_conv_geom *g, const float *w, int Ci_real, int Co_real,
                            float *wp, void *stream);
+/* Many packs in one launch (`entries` is a HOST array; 64 per launch): kind 0 = lvt_conv3d_pack_weight, 1 = _pack_weight_t, 2 =
+ * _pack_weight_phases, 3 = _pack_weight_parity of the (Co_real, Ci_real, taps) weight `w` into `dst` (same layouts, same bits);
+ * taps = Kt*Kh*Kw (16 for kinds 2, 3), Ci / Co the padded channel counts of the geometry.                                  */
+typedef struct { const float *w; float *dst; int kind, taps, Ci, Co, Ci_real, Co_real; } lvt_pack_entry;
+int lvt_conv3d_pack_weights_multi(const lvt_pack_entry *entries, int n, void *stream);
 /* Packed weights of the convolution that IS the backward-data pass of a stride-1 convolution: channels swapped, taps
  * reversed: wt[taps-1-tap][co][ci] = w[co][ci][tap].  `lvt_conv3d_fwd` on the swapped geometry (Ci <-> Co, same kernel
  * and padding k-1-p) with these weights computes dx; for 3x3 / pad 1 layers of 16x16 frames that launch runs on the

@@ -2049,6 +2049,50 @@ extern "C" int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t work
 }
 
 // ---- convolution entry points -------------------------------------------------------------------
+// all weight packs of a convolution stack in ONE launch (blockIdx.y = entry): a VQ-VAE pass makes 24 of them, each a ~5 us launch
+// in front of the layer that needs it; kind 0: lvt_pack_weight_kernel, 1: _t, 2: _phases, 3: _parity (same element functions)
+struct PackTable { const float *w[64]; float *dst[64]; int kind[64], taps[64], Ci[64], Co[64], Ci_real[64], Co_real[64]; };
+__global__ void lvt_pack_weights_multi_kernel(const PackTable t) {
+    const int e = blockIdx.y;
+    const float *__restrict__ w = t.w[e];
+    float *__restrict__ dst = t.dst[e];
+    const int kind = t.kind[e], taps = t.taps[e], Ci = t.Ci[e], Co = t.Co[e], Ci_real = t.Ci_real[e], Co_real = t.Co_real[e];
+    const long long total = (long long)(kind >= 2 ? 16 : taps) * Ci * Co;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int co, ci, tap;
+        if (kind == 0 || kind == 3) { co = i % Co; const long long q = i / Co; ci = q % Ci; tap = (int)(q / Ci); }      // [..][ci][co]
+        else { ci = i % Ci; const long long q = i / Ci; co = q % Co; tap = (int)(q / Co); }                                  // [..][co][ci]
+        int src_tap = tap;                                                      // index into the layer's own tap order
+        if (kind == 1) src_tap = taps - 1 - tap;
+        else if (kind == 2) { const int ph = tap >> 2, tp = tap & 3; src_tap = (3 - (ph >> 1) - 2 * (tp >> 1)) * 4 + 3 - (ph & 1) - 2 * (tp & 1); }
+        else if (kind == 3) { const int cls = tap >> 2, tp = tap & 3; src_tap = (2 * (tp >> 1) + (cls >> 1)) * 4 + 2 * (tp & 1) + (cls & 1); }
+        float v = 0.f;
+        if (co < Co_real && ci < Ci_real) v = w[((long long)co * Ci_real + ci) * (kind >= 2 ? 16 : taps) + src_tap];
+        dst[i] = v;
+    }
+}
+extern "C" int lvt_conv3d_pack_weights_multi(const lvt_pack_entry *entries, int n, void *stream) {
+    LVT_REQUIRE(entries && n > 0, "pack_weights_multi: bad args");
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = n - base < 64 ? n - base : 64;
+        PackTable t;
+        long long biggest = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const lvt_pack_entry &e = entries[base + i];
+            LVT_REQUIRE(e.w && e.dst && e.kind >= 0 && e.kind <= 3 && e.taps > 0 && e.Ci > 0 && e.Co > 0 && e.Ci_real <= e.Ci &&
+                            e.Co_real <= e.Co && (e.kind < 2 || e.taps == 16), "pack_weights_multi: bad entry %d", base + i);
+            t.w[i] = e.w; t.dst[i] = e.dst; t.kind[i] = e.kind; t.taps[i] = e.taps; t.Ci[i] = e.Ci; t.Co[i] = e.Co;
+            t.Ci_real[i] = e.Ci_real; t.Co_real[i] = e.Co_real;
+            const long long total = (long long)e.taps * e.Ci * e.Co;
+            if (total > biggest) biggest = total;
+        }
+        const unsigned bx = (unsigned)(lvt_cdiv(biggest, 256) < 1024 ? lvt_cdiv(biggest, 256) : 1024);
+        hipLaunchKernelGGL(lvt_pack_weights_multi_kernel, dim3(bx, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream, t);
+        LVT_CHECK_LAUNCH("lvt_pack_weights_multi_kernel");
+    }
+    return LVT_OK;
+}
+
 static int check_geom(const lvt_conv_geom *g, const char *who) {
     LVT_REQUIRE(g, "%s: null geometry", who);
     LVT_REQUIRE(g->N > 0 && g->Ti > 0 && g->Hi > 0 && g->Wi > 0 && g->To > 0 && g->Ho > 0 && g->Wo > 0,

@@ -46,6 +46,11 @@ class AmaxEntry(C.Structure):
     _fields_ = [("x", C.c_void_p), ("n", C.c_longlong), ("out", C.c_void_p)]
 
 
+class PackEntry(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p), ("kind", C.c_int), ("taps", C.c_int), ("Ci", C.c_int), ("Co", C.c_int),
+                ("Ci_real", C.c_int), ("Co_real", C.c_int)]
+
+
 class AmaxIO(C.Structure):
     """lvt_amax_io: device scalars with max |.| of the two operands (f16x2 mode) and of the result (optional)."""
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p)]
@@ -89,6 +94,7 @@ def _declare(lib):
         "lvt_conv3d_pack_weight_parity": (ci, [P(ConvGeom), vp, ci, ci, vp, vp]),
         "lvt_amax": (ci, [vp, cll, vp, vp]),
         "lvt_amax_multi": (ci, [P(AmaxEntry), ci, vp]),
+        "lvt_conv3d_pack_weights_multi": (ci, [P(PackEntry), ci, vp]),
         "lvt_amax_merge": (ci, [vp, vp, vp, vp]),
         "lvt_conv3d_fwd_parity": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, P(AmaxIO), vp]),
         "lvt_conv3d_fwd": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, P(AmaxIO), vp]),

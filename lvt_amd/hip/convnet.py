@@ -71,22 +71,38 @@ def stack_forward(layers, x, params, want_grad=True):
     (the transposed weight packs it needs are made here, next to the forward ones).
     Returns (outs, saved) where outs[i] is the post-activation output of layer i."""
     outs, geoms, packed = [], [], []
+    # every weight pack of the stack in ONE launch up front (24 ~5 us launches per VQ-VAE pass otherwise, each in front of the
+    # layer that needs it): the geometries follow from the shapes alone
+    pb = G.PackBatch()
+    shape = tuple(x.shape)
+    for i, (ly, (w, b)) in enumerate(zip(layers, params)):
+        g = _geom(ly, shape)
+        wt = wph = wq = None
+        if ly.kind == "conv":
+            wp = pb.plain(g, w, ly.cin, ly.cout)
+            if want_grad and i > 0 and G.bwd_data_by_phases(g):
+                wph = pb.phases(g, w, ly.cin, ly.cout)          # for this layer's backward-data
+            if G.fwd_by_parity(g):
+                wq = pb.parity(g, w, ly.cin, ly.cout)           # this layer's forward (4x4 / stride 2)
+            # backward-data of the 3x3 layers runs as a forward convolution over transposed weights (frame-resident kernel)
+            if want_grad and G.bwd_data_as_conv(g):
+                wt = pb.t(g, w, ly.cin, ly.cout)
+            shape = (g.N, g.To, g.Ho, g.Wo, g.Co)
+        else:
+            wp = pb.plain(g, w, ly.cout, ly.cin)   # ConvTranspose weight is (in, out, k..) == conv (Co, Ci)
+            if G.bwd_data_by_phases(g):
+                wph = pb.phases(g, w, ly.cout, ly.cin)          # this layer's FORWARD is a transposed pass
+            if want_grad and G.fwd_by_parity(g):
+                wq = pb.parity(g, w, ly.cout, ly.cin)           # its backward-data is the strided convolution
+            shape = (g.N, g.Ti, g.Hi, g.Wi, g.Ci)
+        geoms.append(g)
+        packed.append((wp, wt, wph, wq))
+    pb.launch()
     cur = x
     for i, (ly, (w, b)) in enumerate(zip(layers, params)):
-        g = _geom(ly, cur.shape)
-        wph = wq = None
-        if ly.kind == "conv":
-            wp = G.pack_weight(g, w, ly.cin, ly.cout)
-            if want_grad and i > 0 and G.bwd_data_by_phases(g):
-                wph = G.pack_weight_phases(g, w, ly.cin, ly.cout)          # for this layer's backward-data
-            if G.fwd_by_parity(g):
-                wq = G.pack_weight_parity(g, w, ly.cin, ly.cout)           # this layer's forward (4x4 / stride 2)
-        else:
-            wp = G.pack_weight(g, w, ly.cout, ly.cin)   # ConvTranspose weight is (in, out, k..) == conv (Co, Ci)
-            if G.bwd_data_by_phases(g):
-                wph = G.pack_weight_phases(g, w, ly.cout, ly.cin)          # this layer's FORWARD is a transposed pass
-            if want_grad and G.fwd_by_parity(g):
-                wq = G.pack_weight_parity(g, w, ly.cout, ly.cin)           # its backward-data is the strided convolution
+        g, (wp, wt, wph, wq) = geoms[i], packed[i]
+        seen = (g.N, g.Ti, g.Hi, g.Wi) if ly.kind == "conv" else (g.N, g.To, g.Ho, g.Wo)
+        assert seen == tuple(cur.shape[:4]), "geometry of the pre-pass does not match the activation"
         res = outs[ly.res_from] if ly.res_from >= 0 else None
         bias = _padded_bias(ly, b)
         if ly.kind == "conv":
@@ -97,10 +113,6 @@ def stack_forward(layers, x, params, want_grad=True):
         else:
             y = G.conv_bwd_data(g, cur, wp, bias=bias, res=res, flags=_act_flag(ly.act), wph=wph)
         outs.append(y)
-        geoms.append(g)
-        # backward-data of the 3x3 layers runs as a forward convolution over transposed weights (frame-resident kernel)
-        wt = G.pack_weight_t(g, w, ly.cin, ly.cout) if (want_grad and ly.kind == "conv" and G.bwd_data_as_conv(g)) else None
-        packed.append((wp, wt, wph, wq))
         cur = y
     return outs, (geoms, packed)
 

@@ -1,5 +1,6 @@
 """Thin typed wrappers over lvt_gemm_f32 / lvt_conv3d_* / lvt_colsum."""
 import ctypes as C
+import os
 
 import torch
 
@@ -164,6 +165,55 @@ def pack_weight_t(g, w, Ci_real, Co_real):
     L.check(L.lib().lvt_conv3d_pack_weight_t(C.byref(g), L.ptr(w), Ci_real, Co_real, L.ptr(wt), L.stream_ptr()),
             "lvt_conv3d_pack_weight_t")
     return _same_amax(wt, w)
+
+
+class PackBatch:
+    """The weight packs of a whole convolution stack as ONE launch (lvt_conv3d_pack_weights_multi): `plain`, `t`, `phases`,
+    `parity` allocate the destination and queue the pack (same layouts and bits as pack_weight*), `launch` issues them."""
+
+    SINGLE = bool(os.environ.get("LVT_NO_PACK_BATCH"))        # A/B switch: one launch per pack, as before round 4
+
+    def __init__(self):
+        self.entries, self.keep = [], []
+
+    def _add(self, kind, g, w, Ci_real, Co_real, shape, taps):
+        if self.SINGLE:
+            return (pack_weight, pack_weight_t, pack_weight_phases, pack_weight_parity)[kind](g, w, Ci_real, Co_real)
+        L.require(w)
+        dst = torch.empty(*shape, dtype=torch.float32, device=w.device)
+        e = L.PackEntry()
+        e.w, e.dst, e.kind, e.taps, e.Ci, e.Co, e.Ci_real, e.Co_real = w.data_ptr(), dst.data_ptr(), kind, taps, g.Ci, g.Co, Ci_real, Co_real
+        self.entries.append(e)
+        self.keep.append(w)
+        return _same_amax(dst, w)
+
+    def plain(self, g, w, Ci_real, Co_real):
+        taps = g.Kt * g.Kh * g.Kw
+        return self._add(0, g, w, Ci_real, Co_real, (taps, g.Ci, g.Co), taps)
+
+    def t(self, g, w, Ci_real, Co_real):
+        if (g.st, g.sh, g.sw) != (1, 1, 1):
+            raise L.LvtError("pack_weight_t: stride-1 convolutions only")
+        taps = g.Kt * g.Kh * g.Kw
+        return self._add(1, g, w, Ci_real, Co_real, (taps, g.Co, g.Ci), taps)
+
+    def phases(self, g, w, Ci_real, Co_real):
+        return self._add(2, g, w, Ci_real, Co_real, (4, 4, g.Co, g.Ci), self._taps16(g))
+
+    def parity(self, g, w, Ci_real, Co_real):
+        return self._add(3, g, w, Ci_real, Co_real, (4, 4, g.Ci, g.Co), self._taps16(g))
+
+    @staticmethod
+    def _taps16(g):
+        if (g.Kt, g.Kh, g.Kw) != (1, 4, 4):
+            raise L.LvtError("pack_weight_phases / _parity: 4x4 kernels only")
+        return 16
+
+    def launch(self):
+        if self.entries:
+            arr = (L.PackEntry * len(self.entries))(*self.entries)
+            L.check(L.lib().lvt_conv3d_pack_weights_multi(arr, len(self.entries), L.stream_ptr()), "lvt_conv3d_pack_weights_multi")
+        self.entries, self.keep = [], []
 
 
 def swapped_geom(g):

@@ -349,6 +349,26 @@ def test_image_side_strided_conv(N, H, W, real_ci, math_mode):
     assert torch.equal(y1, G.conv_fwd(g, xd, wp, bias=b.to(dev), flags=L.EPI_RELU))
 
 
+def test_weight_packs_in_one_launch_equal_the_single_packs():
+    """lvt_conv3d_pack_weights_multi (gemm.PackBatch): the four pack layouts of a stack's weights from one launch, bit for bit
+    the same tensors as lvt_conv3d_pack_weight / _t / _phases / _parity, channel padding included."""
+    from lvt_amd.hip import gemm as G
+    dev = _dev()
+    g3 = G.conv_geom(2, 1, 16, 16, 256, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    g4 = G.conv_geom(2, 1, 32, 32, 128, 256, (1, 4, 4), (1, 2, 2), (0, 1, 1))
+    gi = G.conv_geom(2, 1, 64, 64, 4, 128, (1, 4, 4), (1, 2, 2), (0, 1, 1))                       # 3 real input channels
+    w3, w4, wi = _rand(128, 256, 1, 3, 3).to(dev), _rand(256, 128, 1, 4, 4, seed=1).to(dev), _rand(128, 3, 1, 4, 4, seed=2).to(dev)
+    pb = G.PackBatch()
+    got = [pb.plain(g3, w3, 256, 128), pb.t(g3, w3, 256, 128), pb.plain(g4, w4, 128, 256), pb.phases(g4, w4, 128, 256),
+           pb.parity(g4, w4, 128, 256), pb.plain(gi, wi, 3, 128)]
+    pb.launch()
+    ref = [G.pack_weight(g3, w3, 256, 128), G.pack_weight_t(g3, w3, 256, 128), G.pack_weight(g4, w4, 128, 256),
+           G.pack_weight_phases(g4, w4, 128, 256), G.pack_weight_parity(g4, w4, 128, 256), G.pack_weight(gi, wi, 3, 128)]
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert float(got[-1][:, 3].abs().max()) == 0.0                                                # the padded channel is zero
+
+
 def test_conv3d_causal_geometry():
     """MaskedConv3d geometry (K16): kernel 3x3x3, front pads (2,2,1), T=2 to exercise the t taps."""
     from lvt_amd.hip import gemm as G
