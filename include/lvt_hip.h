@@ -427,7 +427,8 @@ int lvt_xent_fwd(const float *logits, const long long *target, long long tstride
                  float *loss, float *count, void *workspace, size_t workspace_bytes, void *stream);
 int lvt_xent_bwd(const float *logits, const long long *target, long long tstride_b, long long tstride_pos,
                  int P, long long rows, int V, long long ignore, const float *lse, const float *count,
-                 const float *gout, float scale, float *dlogits, void *stream);
+                 const float *gout, float scale, float *dlogits, float *dl_amax, void *stream);
+/* (dl_amax, nullable: receives |gout * scale / count|, an a-priori bound of max |dlogits| since |softmax - onehot| <= 1) */
 
 /* ---- fused multi-tensor optimizer steps (torch.optim.Adam / RMSprop as configured by
  * vidgen/solver/build.py:46-74; the reference's one-param-group-per-parameter layout costs hundreds of

@@ -535,9 +535,12 @@ __global__ void lvt_xent_finish_kernel(const float *__restrict__ psum, const flo
 __global__ void lvt_xent_bwd_kernel(const float *__restrict__ logits, const long long *__restrict__ target,
                                     long long tstride_b, long long tstride_pos, int P, long long rows, int V,
                                     long long ignore, const float *__restrict__ lse, const float *__restrict__ count,
-                                    const float *__restrict__ gout, float scale, float *__restrict__ dlogits) {
+                                    const float *__restrict__ gout, float scale, float *__restrict__ dlogits,
+                                    float *__restrict__ dl_amax) {
     const int lane = threadIdx.x & 63;
     const float c = (gout ? gout[0] : 1.f) * scale / count[0];
+    // |softmax - onehot| <= 1: |c| bounds every entry (an a-priori bound like LayerNorm's: one store, no reduction)
+    if (dl_amax && blockIdx.x == 0 && threadIdx.x == 0) *dl_amax = lvt_absf(c);
     for (long long r = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < rows;
          r += ((long long)gridDim.x * blockDim.x) >> 6) {
         const long long t = target[(r / P) * tstride_b + (r % P) * tstride_pos];
@@ -582,11 +585,11 @@ extern "C" int lvt_xent_fwd(const float *logits, const long long *target, long l
 }
 extern "C" int lvt_xent_bwd(const float *logits, const long long *target, long long tstride_b, long long tstride_pos,
                             int P, long long rows, int V, long long ignore, const float *lse, const float *count,
-                            const float *gout, float scale, float *dlogits, void *stream) {
+                            const float *gout, float scale, float *dlogits, float *dl_amax, void *stream) {
     LVT_REQUIRE(logits && target && lse && count && dlogits && rows > 0 && V % 4 == 0, "xent_bwd: bad args");
     const int blocks = (int)(lvt_cdiv(rows, 4) < 16384 ? lvt_cdiv(rows, 4) : 16384);
     hipLaunchKernelGGL(lvt_xent_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, target, tstride_b,
-                       tstride_pos, P, rows, V, ignore, lse, count, gout, scale, dlogits);
+                       tstride_pos, P, rows, V, ignore, lse, count, gout, scale, dlogits, dl_amax);
     LVT_CHECK_LAUNCH("lvt_xent_bwd_kernel");
     return LVT_OK;
 }

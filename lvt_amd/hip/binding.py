@@ -145,7 +145,7 @@ def _declare(lib):
         "lvt_slice_context": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci, cll, vp, vp, vp, vp, vp]),
         "lvt_xent_workspace_bytes": (sz, []),
         "lvt_xent_fwd": (ci, [vp, vp, cll, cll, ci, cll, ci, cll, cf, vp, vp, vp, vp, vp, sz, vp]),
-        "lvt_xent_bwd": (ci, [vp, vp, cll, cll, ci, cll, ci, cll, vp, vp, vp, cf, vp, vp]),
+        "lvt_xent_bwd": (ci, [vp, vp, cll, cll, ci, cll, ci, cll, vp, vp, vp, cf, vp, vp, vp]),
         "lvt_adam_step": (ci, [P(OptEntry), ci, cf, cf, cf, ci, vp]),
         "lvt_rmsprop_step": (ci, [P(OptEntry), ci, cf, cf, cf, vp]),
     }

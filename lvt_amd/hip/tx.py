@@ -186,7 +186,7 @@ def xent_bwd(logits, target, tstride_b, tstride_pos, P, ignore, lse, count, gout
     rows, V = logits.shape
     dl = torch.empty_like(logits)
     L.check(L.lib().lvt_xent_bwd(L.ptr(logits), C.c_void_p(target.data_ptr()), tstride_b, tstride_pos, P, rows, V,
-                                 ignore, L.ptr(lse), L.ptr(count), L.ptr(gout), scale, L.ptr(dl), L.stream_ptr()),
+                                 ignore, L.ptr(lse), L.ptr(count), L.ptr(gout), scale, L.ptr(dl), L.out_amax(dl), L.stream_ptr()),
             "lvt_xent_bwd")
     return dl
 

@@ -187,6 +187,8 @@ class _DecoderFrontFn(torch.autograd.Function):
         # data (DSFVT: t == 1 -> 9 of the 27 taps); the others multiply zero padding and are skipped exactly
         kt_eff = min(kt, t)
         w_eff = conv_w if kt_eff == kt else conv_w[:, :, kt - kt_eff:].contiguous()
+        if w_eff is not conv_w and L.f16x2():
+            L.set_amax(w_eff, L.amax_of(conv_w))         # (a part of the weight: the whole's max |.| bounds it, no scan)
         g = G.conv_geom(b, t, h, w, de, d, (kt_eff, kh, kw), (1, 1, 1), (kt_eff - 1, kh - 1, kw // 2), out=(t, h, w))
         wp = G.pack_weight(g, w_eff, de, d)
         x = G.conv_fwd(g, emb.view(b, t, h, w, de), wp, bias=conv_b).view(rows, d)

@@ -144,6 +144,12 @@ def test_xent_fwd_bwd():
     assert float(cnt) == b * P - 100
     dl = tx.xent_bwd(ld, td[0, 2], nc * P, 1, P, -100, lse, cnt, torch.ones(1, device=DEV), 0.25)
     assert rel_err(dl, logits.grad) < 1e-5
+    from lvt_amd.hip import binding as L
+    if L.f16x2():
+        # the launch stored its a-priori bound |gout * scale / count| >= max |dlogits| as the operand scale of the next product
+        bound = float(L._valid_amax(dl))
+        assert bound == float(torch.tensor(0.25, dtype=torch.float32) / torch.tensor(float(b * P - 100), dtype=torch.float32))
+        assert float(dl.abs().max()) <= bound <= 1.05 * float(dl.abs().max())
 
 
 # ---------------------------------------------------------------- golden / oracle parity ---------------
