@@ -33,7 +33,7 @@ extern "C" {
 #define LVT_ENODEVICE   (-4)   /* no gfx950 device visible                             */
 
 const char *lvt_last_error(void);
-int lvt_version(void);          /* 400 = round 4 (ABI changes are listed in INTEGRATION.md) */
+int lvt_version(void);          /* 500 = round 5 (ABI changes are listed in INTEGRATION.md) */
 /* Device probe: name, CU count, clock (kHz), HBM bytes.  Returns LVT_ENODEVICE without a GPU. */
 int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long long *hbm_bytes);
 
@@ -352,6 +352,28 @@ int lvt_attn_bwd_planes(const void *qkv_planes, long long plane_stride, long lon
                         const float *P, const float *o, int B, int H, int S, int da, float temper, int bt, int bh, int bw,
                         int masked, float *dq, float *dk, float *dv, float *ddt, float *ddh, float *ddw, float *d_amax,
                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- flash-style fused attention on fp32 operands, f16x2 arithmetic (csrc/attention_flash.hip; ABI 500) --------------
+ * Replaces bmm(q, k^T) / temper + B (+ masked_fill) -> softmax -> bmm(attn, v) of ScaledDotProductAttention
+ * (vt_attention.py:59-81, bias B of BlockLocalAttention.get_B, :169-174) and its autograd backward WITHOUT materialising
+ * the (B,H,S,S) attention matrix: q / k / v / d_o / o / dq / dk / dv are token-major fp32 (B*S rows, row stride `ld` floats,
+ * head h in columns h*da ..; q, k, v may be the three (B*S, H*da) slabs of the packed projection output).
+ * forward : o, and `stats` (2, B*H*S) fp32: row max m of the biased (masked) scores, then 1 / sum_j exp(score - m).
+ * backward: dq, dk, dv and the bank gradients ddt (H, 2bt-1), ddh (H, 2bh-1), ddw (H, 2bw-1); P and dS are recomputed from
+ *           q, k, v, d_o and `stats` in both backward launches (workspace: one float per row + the per-workgroup bank sums).
+ * Operands are split in-kernel into two fp16 terms under an exact power-of-two scale PER ROW (token x head, 128 values):
+ * 22 bits + sign for every element within 2^-16 of its row's max |.|, absolute error <= 2^-39 of the row max below that;
+ * three fp16 MFMAs per product, fp32 accumulation.  S == 256, da == 128, (bt,bh,bw) in {(1,16,16), (4,8,8)}, B*H % 8 == 0.
+ * o_amax / d_amax: nullable, as for lvt_attn_fwd_planes.                                                                 */
+int lvt_attn_flash_supported(int S, int da, int bt, int bh, int bw);
+int lvt_attn_fwd_flash(const float *q, const float *k, const float *v, long long ld, int B, int H, int S, int da,
+                       float temper, const float *dt, const float *dh, const float *dw, int bt, int bh, int bw,
+                       int masked, float fill, float *o, float *stats, float *o_amax, void *stream);
+size_t lvt_attn_bwd_flash_workspace_bytes(int B, int H, int S, int bt, int bh, int bw);
+int lvt_attn_bwd_flash(const float *q, const float *k, const float *v, const float *d_o, long long ld, const float *stats,
+                       int B, int H, int S, int da, float temper, const float *dt, const float *dh, const float *dw,
+                       int bt, int bh, int bw, int masked, float fill, float *dq, float *dk, float *dv, float *ddt,
+                       float *ddh, float *ddw, float *d_amax, void *workspace, size_t workspace_bytes, void *stream);
 
 /* single-query attention against a token-major K/V cache (incremental sampling: the reference re-runs the
  * whole causal decoder for every generated pixel, vt.py:121-131).  q (B rows of H*da, row stride ldq), o (B, H*da), caches (B, S, H*da);

@@ -1,0 +1,908 @@
+// Flash-style fused attention for one 256-token block, head dimension 128, on fp32 operands in the f16x2 arithmetic
+// (reference: ScaledDotProductAttention / BlockLocalAttention, vidgen/modeling/autoregressive/vt_attention.py:52-81,142-174).
+//
+// What this file replaces.  The pipelined kernels of attention_pipe.hip take q / k / v / dO as three bf16 planes (6 bytes per
+// element, six MFMAs per product), write the softmax P as 134 MB of fp32 per layer, read it back twice in the backward pass and
+// exchange dS the same way: 490-760 MB per launch against 268 / 536 MB of algorithmic traffic (profiles/r04_dsfvt_pmc_hbm_traffic.txt).
+// Here
+//   * operands arrive as plain fp32 (4 bytes per element, what the projection GEMMs write anyway) and are split into TWO fp16
+//     terms while they are staged into LDS: a s = hi + lo, hi = RN16(a s), lo = RN16(a s - hi), with an exact power-of-two
+//     scale s PER ROW (one token x one head: 128 values) taken from the row's own max |a| -- no max |.| plumbing from the
+//     producer, no a-priori bound.  A product is THREE v_mfma_f32_16x16x32_f16 (lo hi, hi lo, hi hi) into one fp32 accumulator;
+//     all fp16 x fp16 products are exact there, the dropped lo lo term is <= 2^-22 |a||b|.  Envelope: 22 bits + sign for every
+//     element within 2^-16 of ITS ROW's max, absolute error <= 2^-39 of the row max below that;
+//   * the forward pass keeps nothing but two floats per query row (running max m and sum l of the online softmax over 32-key
+//     chunks; O is rescaled when the max moves) -- P never leaves the registers;
+//   * the backward pass recomputes S = q k^T and dP = dO v^T from the operands in both of its kernels:
+//       A (one wave = 16 queries): pass 1 over the keys forms delta_i = sum_j P_ij dP_ij from THE dP values it will use
+//         (vt_attention.py:59-81 under autograd: the softmax backward cancels row sums the same way), pass 2 forms
+//         g = P o (dP - delta), the bias-bank gradients and dQ = g K / temper;
+//       B (one wave = 16 keys, K fragments in registers, V fragments resident in LDS): dV = P^T dO, dK = g^T Q / temper over
+//         32-query chunks, delta read from A's output;
+//     nine score-sized products instead of four, each at half the MFMA cost of attention_pipe.hip's, for 1/3 of its traffic.
+// Reductions over an index that carries per-row scales (keys in O = P V and dQ, queries in dV / dK) fold the row scale into
+// the other operand (P, g) and keep a running power-of-two scale of the accumulator ("online scale", exact).
+//
+// Staging: an ITEM is 64 LDS rows = 32 rows of one operand + 32 rows of a second one (K|V chunk for the query-stationary
+// kernels, Q|dO chunk for the key-stationary one), two fp16 planes with a 288-byte row pitch (conflict-free for the 16-row
+// ds_read_b128 fragment reads and the transposing ds_read_b64_tr_b16), in a two-slot ring with two register sets: while the
+// MFMAs of step t read slot t & 1, item t + 1 is split and stored into the other slot and the global loads of item t + 2 are
+// in flight; one barrier per step.  16 lanes own a row: its max |.| is four DPP steps, no LDS traffic.
+// Tiling as in attention_pipe.hip: 16-wide tiles, one wave = 16 queries (keys), eight waves per workgroup = two per SIMD.
+#include "attn_common.h"
+
+namespace {
+
+template <int I> struct IC { static constexpr int value = I; };
+template <int N, int I = 0, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) { f(IC<I>{}); static_for<N, I + 1>(f); }
+}
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define FA_LD 144                         // row pitch (fp16): 288 B
+#define FA_PL (64 * FA_LD)                // one plane of an item (fp16 elements)
+#define FA_SLOT (2 * FA_PL)               // hi plane, lo plane: 36864 B
+#define FA_EMIN 15                        // clamp of the biased exponent of a row max (keeps every derived scale a normal float)
+#define FA_EMAX 254
+
+__device__ __forceinline__ float fa_u2f(unsigned u) { return __uint_as_float(u); }
+// 2^d for an exponent difference d <= 0 (0 below the normal range)
+__device__ __forceinline__ float fa_pow2_neg(int d) { return d < -126 ? 0.f : fa_u2f((unsigned)(127 + d) << 23); }
+// float with biased exponent field e (0 when e <= 0)
+__device__ __forceinline__ float fa_exp_field(int e) { return e <= 0 ? 0.f : fa_u2f((unsigned)e << 23); }
+__device__ __forceinline__ int fa_ebits(float nonneg) {
+    const int e = (int)((__float_as_uint(nonneg) >> 23) & 0xffu);
+    return e < FA_EMIN ? FA_EMIN : (e > FA_EMAX ? FA_EMAX : e);
+}
+template <int CTRL> __device__ __forceinline__ float fa_dpp_max(float v) {
+    const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+    return fmaxf(v, __builtin_bit_cast(float, o));
+}
+// max over the 16 lanes of a DPP row: quad xor 1, quad xor 2, half-row mirror, row mirror
+__device__ __forceinline__ float fa_row16_max(float v) {
+    v = fa_dpp_max<0xB1>(v);
+    v = fa_dpp_max<0x4E>(v);
+    v = fa_dpp_max<0x141>(v);
+    v = fa_dpp_max<0x140>(v);
+    return v;
+}
+// sum / max over the four lanes (kg = lane >> 4) that share a 16-wide tile column
+__device__ __forceinline__ float fa_kg_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+__device__ __forceinline__ float fa_kg_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
+
+__device__ __forceinline__ float fa_mix_lo(unsigned h, float c) {        // c - half(h.lo), exact
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(-1.f), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float fa_mix_hi(unsigned h, float c) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(-1.f), "v"(c));
+    return r;
+}
+// (a, b) * s -> packed fp16 hi pair and lo pair (instruction choice: gemm_engine.hip, f16_split_pair)
+__device__ __forceinline__ void fa_split_pair(float a, float b, float s, unsigned &ph, unsigned &pl) {
+    const f32x2 t = f32x2{a, b} * s;
+    ph = __builtin_bit_cast(unsigned, __builtin_convertvector(t, f16x2v));
+    const f32x2 r = {fa_mix_lo(ph, t.x), fa_mix_hi(ph, t.y)};
+    pl = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2v));
+}
+// eight values (k slots 0..7 of a B operand) -> hi / lo fragments
+__device__ __forceinline__ void fa_split8(const float (&v)[8], float s, f16x8 &h, f16x8 &l) {
+    u32x4 uh, ul;
+    unsigned a, b;
+    fa_split_pair(v[0], v[1], s, a, b); uh[0] = a; ul[0] = b;
+    fa_split_pair(v[2], v[3], s, a, b); uh[1] = a; ul[1] = b;
+    fa_split_pair(v[4], v[5], s, a, b); uh[2] = a; ul[2] = b;
+    fa_split_pair(v[6], v[7], s, a, b); uh[3] = a; ul[3] = b;
+    h = __builtin_bit_cast(f16x8, uh);
+    l = __builtin_bit_cast(f16x8, ul);
+}
+// acc += a b with a = ah + al, b = bh + bl (smallest terms first)
+__device__ __forceinline__ f32x4v fa_mfma(const f16x8 a, const f16x8 b, const f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// staging
+// ---------------------------------------------------------------------------------------------------------------------------
+struct G4 { float4 v[4]; };              // row r of operand X: columns 4 c, 4 c + 64; row r of operand Y: the same
+__device__ __forceinline__ void fa_load(G4 &g, const float *__restrict__ x, const float *__restrict__ y, long long ld, int tid) {
+    const int r = tid >> 4, c = tid & 15;
+    const float *px = x + (long long)r * ld + 4 * c, *py = y + (long long)r * ld + 4 * c;
+    g.v[0] = *reinterpret_cast<const float4 *>(px);
+    g.v[1] = *reinterpret_cast<const float4 *>(px + 64);
+    g.v[2] = *reinterpret_cast<const float4 *>(py);
+    g.v[3] = *reinterpret_cast<const float4 *>(py + 64);
+}
+// split + store into `slot` (rows 0..31: X, 32..63: Y); rs_inv[row] = 2^(e - 14), the inverse of the row's scale; emax2
+// (optional): LDS words that collect the largest biased row exponent of the X / Y half (zeroed by the kernel prologue)
+__device__ __forceinline__ void fa_park(const G4 &g, unsigned short *slot, float *rs_inv, unsigned *emax2, int tid) {
+    const int r = tid >> 4, c = tid & 15;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const float4 a = g.v[2 * half], b = g.v[2 * half + 1];
+        float m = fmaxf(fmaxf(fmaxf(lvt_absf(a.x), lvt_absf(a.y)), fmaxf(lvt_absf(a.z), lvt_absf(a.w))),
+                        fmaxf(fmaxf(lvt_absf(b.x), lvt_absf(b.y)), fmaxf(lvt_absf(b.z), lvt_absf(b.w))));
+        m = fa_row16_max(m);
+        const int eb = fa_ebits(m);
+        const float s = fa_u2f((unsigned)(268 - eb) << 23);           // row max * s in [2^14, 2^15)
+        uint2 h0, l0, h1, l1;
+        fa_split_pair(a.x, a.y, s, h0.x, l0.x); fa_split_pair(a.z, a.w, s, h0.y, l0.y);
+        fa_split_pair(b.x, b.y, s, h1.x, l1.x); fa_split_pair(b.z, b.w, s, h1.y, l1.y);
+        unsigned short *d = slot + (32 * half + r) * FA_LD + 4 * c;
+        *reinterpret_cast<uint2 *>(d) = h0;
+        *reinterpret_cast<uint2 *>(d + 64) = h1;
+        *reinterpret_cast<uint2 *>(d + FA_PL) = l0;
+        *reinterpret_cast<uint2 *>(d + FA_PL + 64) = l1;
+        if (c == 0) {
+            rs_inv[32 * half + r] = fa_u2f((unsigned)(eb - 14) << 23);
+            if (emax2) atomicMax(emax2 + half, (unsigned)eb);
+        }
+    }
+}
+// fragment of LDS row `row` (A operand: the row is the tile row; B operand: the row is the tile column), k = 32 s + 8 kg .. + 7
+__device__ __forceinline__ f16x8 fa_rowfrag(const unsigned short *slot, int pl, int row, int s, int kg) {
+    return *reinterpret_cast<const f16x8 *>(slot + pl * FA_PL + row * FA_LD + 32 * s + 8 * kg);
+}
+// A fragment TRANSPOSED: tile row = column 16 dtile + c16 of the staged rows, k slots 0..3 = rows rb + 4 kg + 0..3, 4..7 = the
+// same rows + 16 (attention_pipe.hip, ap_tr)
+__device__ __forceinline__ f16x8 fa_trfrag(const unsigned short *slot, int pl, int rb, int dtile, int c16, int kg) {
+    const unsigned short *p = slot + pl * FA_PL + (rb + 4 * kg + (c16 >> 2)) * FA_LD + 16 * dtile + 4 * (c16 & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + 16 * FA_LD));
+    union { struct { s16x4 a, b; } s; f16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+}
+
+struct FaSmem {
+    unsigned short ring[2][FA_SLOT];
+    float rs_inv[2][64];
+    unsigned emax[24][2];
+    float dhs[32];                        // this head's dh bank (2 BH - 1 entries)
+};
+template <int NR> struct FaSmemA {
+    unsigned short ring[2][FA_SLOT];
+    float rs_inv[2][64];
+    unsigned emax[24][2];
+    float dhs[32];
+    float R[128 * 4 * NR];                // per-lane class sums of g (bias-bank gradient), [query][kg][NR]
+};
+struct FaSmemB {
+    unsigned short ring[2][FA_SLOT];
+    unsigned short vres[2][FA_SLOT];      // the workgroup's 128 V rows, resident
+    float rs_inv[2][64];
+    float vinv[2][64];
+    unsigned emax[16][2];
+    float dhs[32];
+};
+
+// workgroup -> (sample, head) pair and half: the two halves of a pair get block ids 8 apart (same XCD, back to back)
+__device__ __forceinline__ int fa_pair(unsigned x) { return (int)(((x >> 4) << 3) | (x & 7)); }
+__device__ __forceinline__ int fa_half(unsigned x) { return (int)((x >> 3) & 1); }
+__device__ __forceinline__ int fa_opaque(int x) { asm volatile("" : "+s"(x)); return x; }
+
+template <int BH, int BW> struct Geo16 {
+    static_assert(BW == 16 || BW == 8, "16-wide tiles: BW is 8 or 16");
+    static constexpr int HP = BW == 16 ? BH : BH / 2;
+    static __device__ __forceinline__ int hj(int hslot, int kg) { return BW == 16 ? hslot : 2 * hslot + (kg >> 1); }
+    static __device__ __forceinline__ int wj(int r, int kg) { return BW == 16 ? 4 * kg + r : 4 * (kg & 1) + r; }
+};
+template <int BT, int BH, int BW> struct BankIdx {
+    static constexpr int NT = 2 * BT - 1, NH = 2 * BH - 1, NW = 2 * BW - 1, NB = NT + NH + NW;
+};
+
+// stage 128 rows (the workgroup's stationary operand) into two slot-shaped regions; every wave then reads its 16 rows
+template <class SM = int>
+__device__ __forceinline__ void fa_stage128(const float *rows, long long ld, unsigned short *s0, unsigned short *s1, float *i0, float *i1,
+                                            int tid) {
+    G4 a, b;
+    fa_load(a, rows, rows + 32 * ld, ld, tid);
+    fa_load(b, rows + 64 * ld, rows + 96 * ld, ld, tid);
+    fa_park(a, s0, i0, nullptr, tid);
+    fa_park(b, s1, i1, nullptr, tid);
+}
+
+struct FaArgs {
+    const float *q, *k, *v, *d_o;        // token-major (B*S rows, ld floats per row), head h in columns h*128 ..
+    long long ld;
+    int H;
+    float inv_temper, fill;
+    const float *dt, *dh, *dw;
+    float *o, *m, *l;                    // forward outputs: o and the row statistics (B*H*S each): max m, 1 / sum l
+    float *dq, *dk, *dv, *delta, *bank_partial;
+};
+
+// ===========================================================================================================================
+// forward
+// ===========================================================================================================================
+template <int BT, int BH, int BW, int MASKED, int NCH>
+__device__ __forceinline__ float fa_fwd_body(const FaArgs &A, FaSmem &sm, int bh_, int qhalf) {
+    using GE = Geo16<BH, BW>;
+    constexpr int HP = GE::HP;
+    static_assert(BT * BH * BW == AT_S, "256 tokens");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, kg = lane >> 4;
+    const int b = bh_ / A.H, h = bh_ % A.H;
+    const long long row0 = (long long)b * AT_S;
+    const int il = wave * 16 + c16, i = qhalf * 128 + il;
+    const float *kbase = A.k + row0 * A.ld + h * AT_D, *vbase = A.v + row0 * A.ld + h * AT_D;
+    constexpr int NIT = NCH;
+
+    if (tid < 48) (&sm.emax[0][0])[tid] = 0u;
+    if (tid < 2 * BH - 1) sm.dhs[tid] = A.dh[h * (2 * BH - 1) + tid];
+    fa_stage128<FaSmem>(A.q + (row0 + qhalf * 128) * A.ld + h * AT_D, A.ld, sm.ring[0], sm.ring[1], sm.rs_inv[0], sm.rs_inv[1], tid);
+    G4 g0, g1;
+#define FA_G(t) ((((t) & 1) == 0) ? g0 : g1)
+    auto load_item = [&](int t, G4 &gg) { fa_load(gg, kbase + (long long)(32 * t) * A.ld, vbase + (long long)(32 * t) * A.ld, A.ld, tid); };
+    load_item(0, g0);
+    if (NIT > 1) load_item(1, g1);
+    __syncthreads();
+    f16x8 qb[4][2];
+    float qinv;
+    {
+        const unsigned short *qs = sm.ring[il >> 6];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) qb[s][pl] = fa_rowfrag(qs, pl, il & 63, s, kg);
+        qinv = sm.rs_inv[il >> 6][il & 63];
+    }
+    const int wi = i % BW, hi = (i / BW) % BH, ti = i / (BW * BH);
+    float bt_[BT], bw_[4];
+#pragma unroll
+    for (int x = 0; x < BT; ++x) bt_[x] = A.dt[h * (2 * BT - 1) + ti - x + BT - 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bw_[r] = A.dw[h * (2 * BW - 1) + wi - GE::wj(r, kg) + BW - 1];
+    // dh[hi - hj(x, kg) + BH - 1] of h slot x, read from LDS per tile (a 16-entry per-lane table would cost 16 registers)
+    const float *dhl = sm.dhs + (hi + BH - 1 - (BW == 16 ? 0 : (kg >> 1)));
+    constexpr int HSTEP = BW == 16 ? 1 : 2;
+    __syncthreads();
+    fa_park(g0, sm.ring[0], sm.rs_inv[0], sm.emax[0], tid);
+    __syncthreads();
+
+    f32x4v oacc[AT_D / 16];
+#pragma unroll
+    for (int d = 0; d < AT_D / 16; ++d) oacc[d] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    float m_run = -3.0e38f, lsum = 0.f;
+    int E_run = FA_EMIN;
+
+    static_for<NIT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const unsigned short *cur = sm.ring[t & 1];
+        const float *cinv = sm.rs_inv[t & 1];
+        if constexpr (t + 2 < NIT) load_item(t + 2, FA_G(t));
+        // ---- S^T = K Q^T for the 32 keys of this chunk (two 16-key tiles) ----
+        f32x4v st[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f16x8 a[2][2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) a[kt][pl] = fa_rowfrag(cur, pl, 16 * kt + c16, s, kg);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) st[kt] = fa_mfma(a[kt][1], qb[s][0], st[kt]);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) st[kt] = fa_mfma(a[kt][0], qb[s][1], st[kt]);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) st[kt] = fa_mfma(a[kt][0], qb[s][0], st[kt]);
+        }
+        if constexpr (t + 1 < NIT) fa_park(FA_G(t + 1), sm.ring[(t + 1) & 1], sm.rs_inv[(t + 1) & 1], sm.emax[t + 1], tid);
+        // ---- scores, online softmax ----
+        float x[8];
+        float cmax = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            constexpr int dummy = 0; (void)dummy;
+            const int T = 2 * t + kt;
+            const f32x4v kinv = *reinterpret_cast<const f32x4v *>(cinv + 16 * kt + 4 * kg);
+            const float bth = bt_[T / HP] + dhl[-HSTEP * (T % HP)];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = (st[kt][r] * (kinv[r] * qinv)) * A.inv_temper + (bth + bw_[r]);
+                if (MASKED && 16 * T + 4 * kg + r > i) v = A.fill;
+                x[4 * kt + r] = v;
+                cmax = fmaxf(cmax, v);
+            }
+        }
+        cmax = fa_kg_max(cmax);
+        const float m_new = fmaxf(m_run, cmax);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        const int E_c = (int)sm.emax[t][1];
+        const int E_new = E_c > E_run ? E_c : E_run;
+        const float fo = alpha * fa_pow2_neg(E_run - E_new);
+        E_run = E_new;
+        const float srun = fa_u2f((unsigned)(268 - E_new) << 23);
+        float psum = 0.f, pw[8];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const f32x4v vinv = *reinterpret_cast<const f32x4v *>(cinv + 32 + 16 * kt + 4 * kg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(x[4 * kt + r] - m_new);
+                psum += p;
+                pw[4 * kt + r] = p * (vinv[r] * srun);
+            }
+        }
+        lsum = lsum * alpha + psum;
+        f16x8 pbh, pbl;
+        fa_split8(pw, 32768.f, pbh, pbl);
+#pragma unroll
+        for (int d = 0; d < AT_D / 16; ++d) oacc[d] *= fo;
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int dp = 0; dp < AT_D / 32; ++dp) {
+            f16x8 a[2][2];
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) a[dd][pl] = fa_trfrag(cur, pl, 32, 2 * dp + dd, c16, kg);
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) oacc[2 * dp + dd] = fa_mfma(a[dd][1], pbh, oacc[2 * dp + dd]);
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) oacc[2 * dp + dd] = fa_mfma(a[dd][0], pbl, oacc[2 * dp + dd]);
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) oacc[2 * dp + dd] = fa_mfma(a[dd][0], pbh, oacc[2 * dp + dd]);
+        }
+        __syncthreads();
+    });
+#undef FA_G
+    const float linv = 1.f / fa_kg_sum(lsum);
+    const float osc = fa_exp_field(E_run - 29) * linv;
+    float am = 0.f;
+    {
+        float *orow = A.o + (row0 + i) * A.ld + h * AT_D + 4 * kg;
+#pragma unroll
+        for (int d = 0; d < AT_D / 16; ++d) {
+            const f32x4v ov = oacc[d] * osc;
+            *reinterpret_cast<f32x4v *>(orow + 16 * d) = ov;
+            am = fmaxf(am, fmaxf(fmaxf(lvt_absf(ov[0]), lvt_absf(ov[1])), fmaxf(lvt_absf(ov[2]), lvt_absf(ov[3]))));
+        }
+    }
+    if (kg == 0) {
+        const long long si = ((long long)b * A.H + h) * AT_S + i;
+        A.m[si] = m_run;
+        A.l[si] = linv;
+    }
+    return am;
+}
+
+template <int BT, int BH, int BW, int MASKED>
+__global__ __launch_bounds__(512, 1) void lvt_attn_fwd_flash_kernel(const FaArgs A, float *__restrict__ o_amax) {
+    __shared__ __attribute__((aligned(16))) FaSmem sm;
+    float am;
+    if (MASKED) {        // one workgroup = both query halves of a (sample, head): 8 + 4 key chunks
+        am = fa_fwd_body<BT, BH, BW, MASKED, 8>(A, sm, blockIdx.x, 1);
+        __syncthreads();
+        am = fmaxf(am, fa_fwd_body<BT, BH, BW, MASKED, 4>(A, sm, fa_opaque(blockIdx.x), 0));
+    } else {
+        am = fa_fwd_body<BT, BH, BW, MASKED, 8>(A, sm, fa_pair(blockIdx.x), fa_half(blockIdx.x));
+    }
+    if (o_amax) {
+        __syncthreads();
+        lvt_block_amax_commit(am, o_amax, reinterpret_cast<float *>(sm.ring[0]));
+    }
+}
+
+// ===========================================================================================================================
+// backward A: delta, dQ, bias-bank partial sums (query-stationary)
+// ===========================================================================================================================
+template <int BT, int BH, int BW, int MASKED, int NCH>
+__device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo16<BH, BW>::HP + 4> &sm, int bh_, int qhalf) {
+    using GE = Geo16<BH, BW>;
+    using BI = BankIdx<BT, BH, BW>;
+    constexpr int HP = GE::HP;
+    constexpr int NR = BT + HP + 4;
+    static_assert(BT * BH * BW == AT_S, "256 tokens");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, kg = lane >> 4;
+    const int b = bh_ / A.H, h = bh_ % A.H;
+    const long long row0 = (long long)b * AT_S;
+    const int il = wave * 16 + c16, i = qhalf * 128 + il;
+    const float *kbase = A.k + row0 * A.ld + h * AT_D, *vbase = A.v + row0 * A.ld + h * AT_D;
+    constexpr int NIT = 2 * NCH;                                     // pass 1: chunks 0 .. NCH-1, pass 2: the same again
+
+    if (tid < 48) (&sm.emax[0][0])[tid] = 0u;
+    if (tid < 2 * BH - 1) sm.dhs[tid] = A.dh[h * (2 * BH - 1) + tid];
+    float *mine = sm.R + (il * 4 + kg) * NR;                          // this lane's class sums: [t index | h slot | register]
+#pragma unroll
+    for (int x = 0; x < NR; ++x) mine[x] = 0.f;
+    G4 g0;                             // ONE register set here (two made the kernel spill): item t + 1 is loaded during step t
+    auto load_item = [&](int t, G4 &gg) {
+        const int c = t < NCH ? t : t - NCH;
+        fa_load(gg, kbase + (long long)(32 * c) * A.ld, vbase + (long long)(32 * c) * A.ld, A.ld, tid);
+    };
+    f16x8 qb[4][2], dob[4][2];
+    float qinv, doinv;
+    fa_stage128<int>(A.q + (row0 + qhalf * 128) * A.ld + h * AT_D, A.ld, sm.ring[0], sm.ring[1], sm.rs_inv[0], sm.rs_inv[1], tid);
+    __syncthreads();
+    {
+        const unsigned short *qs = sm.ring[il >> 6];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) qb[s][pl] = fa_rowfrag(qs, pl, il & 63, s, kg);
+        qinv = sm.rs_inv[il >> 6][il & 63];
+    }
+    __syncthreads();
+    fa_stage128<int>(A.d_o + (row0 + qhalf * 128) * A.ld + h * AT_D, A.ld, sm.ring[0], sm.ring[1], sm.rs_inv[0], sm.rs_inv[1], tid);
+    load_item(0, g0);
+    __syncthreads();
+    {
+        const unsigned short *qs = sm.ring[il >> 6];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) dob[s][pl] = fa_rowfrag(qs, pl, il & 63, s, kg);
+        doinv = sm.rs_inv[il >> 6][il & 63];
+    }
+    const long long si = ((long long)b * A.H + h) * AT_S + i;
+    const float m_i = A.m[si], linv = A.l[si];
+    const int wi = i % BW, hi = (i / BW) % BH, ti = i / (BW * BH);
+    float bt_[BT], bw_[4];
+#pragma unroll
+    for (int x = 0; x < BT; ++x) bt_[x] = A.dt[h * (2 * BT - 1) + ti - x + BT - 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bw_[r] = A.dw[h * (2 * BW - 1) + wi - GE::wj(r, kg) + BW - 1];
+    // dh[hi - hj(x, kg) + BH - 1] of h slot x, read from LDS per tile (a 16-entry per-lane table would cost 16 registers)
+    const float *dhl = sm.dhs + (hi + BH - 1 - (BW == 16 ? 0 : (kg >> 1)));
+    constexpr int HSTEP = BW == 16 ? 1 : 2;
+    __syncthreads();
+    fa_park(g0, sm.ring[0], sm.rs_inv[0], sm.emax[0], tid);
+    __syncthreads();
+
+    float delta = 0.f, gmax = 0.f;
+    int E_K = FA_EMIN;
+    float sgf = 0.f, skf = 0.f;                                       // pass 2: scale of g (from the bound G_i), 2^(141 - E_K)
+    int ebG = FA_EMIN;
+    f32x4v qacc[AT_D / 16];
+#pragma unroll
+    for (int d = 0; d < AT_D / 16; ++d) qacc[d] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    float rst[BT], rsw[4];                                            // class sums over the t index and the register; h slots: LDS
+#pragma unroll
+    for (int x = 0; x < BT; ++x) rst[x] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rsw[r] = 0.f;
+
+    static_for<NIT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int c = t < NCH ? t : t - NCH;
+        constexpr bool PASS2 = t >= NCH;
+        const unsigned short *cur = sm.ring[t & 1];
+        const float *cinv = sm.rs_inv[t & 1];
+        if constexpr (t + 1 < NIT) load_item(t + 1, g0);
+        if constexpr (t == NCH) {                                     // between the passes: delta and the scale bound of g
+            delta = fa_kg_sum(delta);
+            gmax = fa_kg_max(gmax);
+            ebG = fa_ebits(gmax + fabsf(delta));
+            sgf = fa_u2f((unsigned)(268 - ebG) << 23);
+            skf = fa_u2f((unsigned)(268 - E_K) << 23);
+        }
+        // ---- S^T = K Q^T, dP^T = V dO^T for the 32 keys of this chunk ----
+        f32x4v st[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+        f32x4v dp[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f16x8 a[2][2], av[2][2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    a[kt][pl] = fa_rowfrag(cur, pl, 16 * kt + c16, s, kg);
+                    av[kt][pl] = fa_rowfrag(cur, pl, 32 + 16 * kt + c16, s, kg);
+                }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) { st[kt] = fa_mfma(a[kt][1], qb[s][0], st[kt]); dp[kt] = fa_mfma(av[kt][1], dob[s][0], dp[kt]); }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) { st[kt] = fa_mfma(a[kt][0], qb[s][1], st[kt]); dp[kt] = fa_mfma(av[kt][0], dob[s][1], dp[kt]); }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) { st[kt] = fa_mfma(a[kt][0], qb[s][0], st[kt]); dp[kt] = fa_mfma(av[kt][0], dob[s][0], dp[kt]); }
+        }
+        if constexpr (!PASS2) { const int e = (int)sm.emax[t][0]; E_K = e > E_K ? e : E_K; }
+        float w[8];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int T = 2 * c + kt;
+            const f32x4v kinv = *reinterpret_cast<const f32x4v *>(cinv + 16 * kt + 4 * kg);
+            const f32x4v vinv = *reinterpret_cast<const f32x4v *>(cinv + 32 + 16 * kt + 4 * kg);
+            const float bth = bt_[T / HP] + dhl[-HSTEP * (T % HP)];
+            float gt = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = (st[kt][r] * (kinv[r] * qinv)) * A.inv_temper + (bth + bw_[r]);
+                if (MASKED && 16 * T + 4 * kg + r > i) x = A.fill;
+                const float p = __expf(x - m_i) * linv;
+                const float dpv = dp[kt][r] * (vinv[r] * doinv);
+                if constexpr (!PASS2) {
+                    delta = fmaf(p, dpv, delta);
+                    gmax = fmaxf(gmax, lvt_absf(dpv));
+                } else {
+                    const float g = p * (dpv - delta);
+                    gt += g;
+                    rsw[r] += g;
+                    w[4 * kt + r] = g * ((kinv[r] * skf) * sgf);
+                }
+            }
+            if constexpr (PASS2) { rst[T / HP] += gt; mine[BT + T % HP] += gt; }
+        }
+        if constexpr (PASS2) {
+            f16x8 wbh, wbl;
+            fa_split8(w, 1.f, wbh, wbl);
+            // ---- dQ^T += K^T g^T ----
+#pragma unroll
+            for (int dq_ = 0; dq_ < AT_D / 32; ++dq_) {
+                f16x8 a[2][2];
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) a[dd][pl] = fa_trfrag(cur, pl, 0, 2 * dq_ + dd, c16, kg);
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd) qacc[2 * dq_ + dd] = fa_mfma(a[dd][1], wbh, qacc[2 * dq_ + dd]);
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd) qacc[2 * dq_ + dd] = fa_mfma(a[dd][0], wbl, qacc[2 * dq_ + dd]);
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd) qacc[2 * dq_ + dd] = fa_mfma(a[dd][0], wbh, qacc[2 * dq_ + dd]);
+            }
+        }
+        if constexpr (t + 1 < NIT) fa_park(g0, sm.ring[(t + 1) & 1], sm.rs_inv[(t + 1) & 1], sm.emax[t + 1], tid);
+        __syncthreads();
+    });
+    // dq = acc * inv_temper * 2^(E_K - 141) * 2^(ebG - 141): two factors so that neither leaves the normal range
+    const float f1 = fa_exp_field(E_K - 14), f2 = fa_exp_field(ebG - 14) * A.inv_temper;
+    float am = 0.f;
+    {
+        float *qrow = A.dq + (row0 + i) * A.ld + h * AT_D + 4 * kg;
+#pragma unroll
+        for (int d = 0; d < AT_D / 16; ++d) {
+            const f32x4v ov = (qacc[d] * f1) * f2;
+            *reinterpret_cast<f32x4v *>(qrow + 16 * d) = ov;
+            am = fmaxf(am, fmaxf(fmaxf(lvt_absf(ov[0]), lvt_absf(ov[1])), fmaxf(lvt_absf(ov[2]), lvt_absf(ov[3]))));
+        }
+    }
+    if (kg == 0) A.delta[si] = delta;
+    // ---- bias-bank gradient of this (sample, head, query half): two fixed-order stages through LDS (attention_pipe.hip) ----
+    float *R = sm.R;                                                  // [128 queries][4 kg][NR]
+    float *R2 = reinterpret_cast<float *>(sm.ring[0]);                // [8 parts][NB]
+#pragma unroll
+    for (int x = 0; x < BT; ++x) mine[x] = rst[x];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mine[BT + HP + r] = rsw[r];
+    __syncthreads();
+    {
+        const int e = tid & 63, part = tid >> 6;
+        if (e < BI::NB) {
+            float acc = 0.f;
+            for (int q = 16 * part; q < 16 * part + 16; ++q) {
+                const int iq = qhalf * 128 + q;
+                const int wq = iq % BW, hq = (iq / BW) % BH, tq = iq / (BW * BH);
+                const float *r = R + (q * 4) * NR;
+                if (e < BI::NT) {
+                    const int tj = tq - e + BT - 1;
+                    if (tj >= 0 && tj < BT) acc += (r[tj] + r[NR + tj]) + (r[2 * NR + tj] + r[3 * NR + tj]);
+                } else if (e < BI::NT + BI::NH) {
+                    const int hj = hq - (e - BI::NT) + BH - 1;
+                    if (hj >= 0 && hj < BH) {
+                        if (BW == 16) acc += (r[BT + hj] + r[NR + BT + hj]) + (r[2 * NR + BT + hj] + r[3 * NR + BT + hj]);
+                        else acc += r[(2 * (hj & 1)) * NR + BT + (hj >> 1)] + r[(2 * (hj & 1) + 1) * NR + BT + (hj >> 1)];
+                    }
+                } else {
+                    const int wj = wq - (e - BI::NT - BI::NH) + BW - 1;
+                    if (wj >= 0 && wj < BW) {
+                        if (BW == 16) acc += r[(wj >> 2) * NR + BT + HP + (wj & 3)];
+                        else acc += r[(wj >> 2) * NR + BT + HP + (wj & 3)] + r[((wj >> 2) + 2) * NR + BT + HP + (wj & 3)];
+                    }
+                }
+            }
+            R2[part * BI::NB + e] = acc;
+        }
+    }
+    __syncthreads();
+    if (tid < BI::NB) {
+        float acc = 0.f;
+#pragma unroll
+        for (int part = 0; part < 8; ++part) acc += R2[part * BI::NB + tid];
+        A.bank_partial[((long long)bh_ * 2 + qhalf) * BI::NB + tid] = acc;
+    }
+    return am;
+}
+
+template <int BT, int BH, int BW, int MASKED>
+__global__ __launch_bounds__(512, 1) void lvt_attn_bwd_flash_a_kernel(const FaArgs A, float *__restrict__ d_amax) {
+    __shared__ __attribute__((aligned(16))) FaSmemA<BT + Geo16<BH, BW>::HP + 4> sm;
+    float am;
+    if (MASKED) {
+        am = fa_bwd_a_body<BT, BH, BW, MASKED, 8>(A, sm, blockIdx.x, 1);
+        __syncthreads();
+        am = fmaxf(am, fa_bwd_a_body<BT, BH, BW, MASKED, 4>(A, sm, fa_opaque(blockIdx.x), 0));
+    } else {
+        am = fa_bwd_a_body<BT, BH, BW, MASKED, 8>(A, sm, fa_pair(blockIdx.x), fa_half(blockIdx.x));
+    }
+    if (d_amax) {
+        __syncthreads();
+        lvt_block_amax_commit(am, d_amax, reinterpret_cast<float *>(sm.ring[0]));
+    }
+}
+
+// ===========================================================================================================================
+// backward B: dK, dV (key-stationary)
+// ===========================================================================================================================
+template <int BT, int BH, int BW, int MASKED, int C0, int NCH>
+__device__ __forceinline__ float fa_bwd_b_body(const FaArgs &A, FaSmemB &sm, int bh_, int khalf) {
+    using GE = Geo16<BH, BW>;
+    constexpr int HP = GE::HP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, kg = lane >> 4;
+    const int b = bh_ / A.H, h = bh_ % A.H;
+    const long long row0 = (long long)b * AT_S;
+    const int jl = wave * 16 + c16, j = khalf * 128 + jl;             // this lane's key (tile column)
+    const float *qbase = A.q + row0 * A.ld + h * AT_D, *dobase = A.d_o + row0 * A.ld + h * AT_D;
+    const long long sb = ((long long)b * A.H + h) * AT_S;
+    constexpr int NIT = NCH;
+
+    if (tid < 32) (&sm.emax[0][0])[tid] = 0u;
+    if (tid < 2 * BH - 1) sm.dhs[tid] = A.dh[h * (2 * BH - 1) + tid];
+    G4 g0;                             // one register set (see backward A)
+    auto load_item = [&](int t, G4 &gg) {
+        fa_load(gg, qbase + (long long)(32 * (C0 + t)) * A.ld, dobase + (long long)(32 * (C0 + t)) * A.ld, A.ld, tid);
+    };
+    fa_stage128<FaSmemB>(A.k + (row0 + khalf * 128) * A.ld + h * AT_D, A.ld, sm.ring[0], sm.ring[1], sm.rs_inv[0], sm.rs_inv[1], tid);
+    fa_stage128<FaSmemB>(A.v + (row0 + khalf * 128) * A.ld + h * AT_D, A.ld, sm.vres[0], sm.vres[1], sm.vinv[0], sm.vinv[1], tid);
+    load_item(0, g0);
+    __syncthreads();
+    f16x8 kb[4][2];
+    float kinv, vinv;
+    {
+        const unsigned short *ks = sm.ring[jl >> 6];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) kb[s][pl] = fa_rowfrag(ks, pl, jl & 63, s, kg);
+        kinv = sm.rs_inv[jl >> 6][jl & 63];
+        vinv = sm.vinv[jl >> 6][jl & 63];
+    }
+    const unsigned short *vs = sm.vres[jl >> 6];
+    const int wj = j % BW, hj = (j / BW) % BH, tj = j / (BW * BH);
+    float bt_[BT], bw_[4];                // indexed by the QUERY's t index and register (Geo16 of the varying token)
+#pragma unroll
+    for (int x = 0; x < BT; ++x) bt_[x] = A.dt[h * (2 * BT - 1) + x - tj + BT - 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bw_[r] = A.dw[h * (2 * BW - 1) + GE::wj(r, kg) - wj + BW - 1];
+    const float *dhl = sm.dhs + (BH - 1 - hj + (BW == 16 ? 0 : (kg >> 1)));      // dh[hj(x, kg) - hj + BH - 1] of the query's h slot x
+    constexpr int HSTEP = BW == 16 ? 1 : 2;
+    __syncthreads();
+    fa_park(g0, sm.ring[0], sm.rs_inv[0], sm.emax[0], tid);
+    __syncthreads();
+
+    f32x4v accv[AT_D / 16], acck[AT_D / 16];
+#pragma unroll
+    for (int d = 0; d < AT_D / 16; ++d) { accv[d] = f32x4v{0.f, 0.f, 0.f, 0.f}; acck[d] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+    int E_run = FA_EMIN, Z_run = FA_EMIN;
+
+    static_for<NIT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int c = C0 + t;                                     // 32-query chunk of the (sample, head)
+        const unsigned short *cur = sm.ring[t & 1];
+        const float *cinv = sm.rs_inv[t & 1];
+        if constexpr (t + 1 < NIT) load_item(t + 1, g0);
+        f32x4v m4[2], l4[2], d4[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const long long o = sb + 32 * c + 16 * qt + 4 * kg;
+            m4[qt] = *reinterpret_cast<const f32x4v *>(A.m + o);
+            l4[qt] = *reinterpret_cast<const f32x4v *>(A.l + o);
+            d4[qt] = *reinterpret_cast<const f32x4v *>(A.delta + o);
+        }
+        // ---- S = Q K^T, dP = dO V^T for the 32 queries of this chunk (rows) x the wave's 16 keys (columns) ----
+        f32x4v st[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+        f32x4v dp[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f16x8 aq[2][2], ad[2][2], vb[2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) vb[pl] = fa_rowfrag(vs, pl, jl & 63, s, kg);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    aq[qt][pl] = fa_rowfrag(cur, pl, 16 * qt + c16, s, kg);
+                    ad[qt][pl] = fa_rowfrag(cur, pl, 32 + 16 * qt + c16, s, kg);
+                }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) { st[qt] = fa_mfma(aq[qt][1], kb[s][0], st[qt]); dp[qt] = fa_mfma(ad[qt][1], vb[0], dp[qt]); }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) { st[qt] = fa_mfma(aq[qt][0], kb[s][1], st[qt]); dp[qt] = fa_mfma(ad[qt][0], vb[1], dp[qt]); }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) { st[qt] = fa_mfma(aq[qt][0], kb[s][0], st[qt]); dp[qt] = fa_mfma(ad[qt][0], vb[0], dp[qt]); }
+        }
+        float pw[8], u[8];
+        float umax = 0.f;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int T = 2 * c + qt;                                 // 16-query tile of the (sample, head)
+            const f32x4v qinv = *reinterpret_cast<const f32x4v *>(cinv + 16 * qt + 4 * kg);
+            const f32x4v doinv = *reinterpret_cast<const f32x4v *>(cinv + 32 + 16 * qt + 4 * kg);
+            const float bth = bt_[T / HP] + dhl[HSTEP * (T % HP)];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = (st[qt][r] * (qinv[r] * kinv)) * A.inv_temper + (bth + bw_[r]);
+                if (MASKED && j > 16 * T + 4 * kg + r) x = A.fill;
+                const float p = __expf(x - m4[qt][r]) * l4[qt][r];
+                const float dpv = dp[qt][r] * (doinv[r] * vinv);
+                const float g = p * (dpv - d4[qt][r]);
+                pw[4 * qt + r] = p * doinv[r];
+                u[4 * qt + r] = g * qinv[r];
+                umax = fmaxf(umax, lvt_absf(u[4 * qt + r]));
+            }
+        }
+        // online scales: P^T dO over queries whose rows carry 2^(14 - e_i) (chunk max exponent E), g^T Q likewise (column max Z)
+        const int E_c = (int)sm.emax[t][1];
+        const int E_new = E_c > E_run ? E_c : E_run;
+        const float fv = fa_pow2_neg(E_run - E_new);
+        E_run = E_new;
+        const float srun = fa_u2f((unsigned)(268 - E_new) << 23);
+        umax = fa_kg_max(umax);
+        const int zb = fa_ebits(umax);
+        const int Z_new = zb > Z_run ? zb : Z_run;
+        const float fk = fa_pow2_neg(Z_run - Z_new);
+        Z_run = Z_new;
+        const float zrun = fa_u2f((unsigned)(268 - Z_new) << 23);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { pw[e] *= srun; u[e] *= zrun; }
+        f16x8 pbh, pbl, ubh, ubl;
+        fa_split8(pw, 32768.f, pbh, pbl);
+        fa_split8(u, 1.f, ubh, ubl);
+#pragma unroll
+        for (int d = 0; d < AT_D / 16; ++d) { accv[d] *= fv; acck[d] *= fk; }
+        // ---- dV^T += dO^T P, dK^T += Q^T g ----
+#pragma unroll
+        for (int d = 0; d < AT_D / 16; ++d) {
+            f16x8 ao[2], aq[2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) { ao[pl] = fa_trfrag(cur, pl, 32, d, c16, kg); aq[pl] = fa_trfrag(cur, pl, 0, d, c16, kg); }
+            accv[d] = fa_mfma(ao[1], pbh, accv[d]); acck[d] = fa_mfma(aq[1], ubh, acck[d]);
+            accv[d] = fa_mfma(ao[0], pbl, accv[d]); acck[d] = fa_mfma(aq[0], ubl, acck[d]);
+            accv[d] = fa_mfma(ao[0], pbh, accv[d]); acck[d] = fa_mfma(aq[0], ubh, acck[d]);
+        }
+        if constexpr (t + 1 < NIT) fa_park(g0, sm.ring[(t + 1) & 1], sm.rs_inv[(t + 1) & 1], sm.emax[t + 1], tid);
+        __syncthreads();
+    });
+    const float fvs = fa_exp_field(E_run - 29), fks = fa_exp_field(Z_run - 14) * A.inv_temper;
+    float am = 0.f;
+    {
+        float *vrow = A.dv + (row0 + j) * A.ld + h * AT_D + 4 * kg, *krow = A.dk + (row0 + j) * A.ld + h * AT_D + 4 * kg;
+#pragma unroll
+        for (int d = 0; d < AT_D / 16; ++d) {
+            const f32x4v ov = accv[d] * fvs, ok = acck[d] * fks;
+            *reinterpret_cast<f32x4v *>(vrow + 16 * d) = ov;
+            *reinterpret_cast<f32x4v *>(krow + 16 * d) = ok;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) am = fmaxf(am, fmaxf(lvt_absf(ov[e]), lvt_absf(ok[e])));
+        }
+    }
+    return am;
+}
+
+template <int BT, int BH, int BW, int MASKED>
+__global__ __launch_bounds__(512, 1) void lvt_attn_bwd_flash_b_kernel(const FaArgs A, float *__restrict__ d_amax) {
+    __shared__ __attribute__((aligned(16))) FaSmemB sm;
+    float am;
+    if (MASKED) {        // key half 0 meets all eight query chunks, key half 1 the last four
+        am = fa_bwd_b_body<BT, BH, BW, MASKED, 0, 8>(A, sm, blockIdx.x, 0);
+        __syncthreads();
+        am = fmaxf(am, fa_bwd_b_body<BT, BH, BW, MASKED, 4, 4>(A, sm, fa_opaque(blockIdx.x), 1));
+    } else {
+        am = fa_bwd_b_body<BT, BH, BW, MASKED, 0, 8>(A, sm, fa_pair(blockIdx.x), fa_half(blockIdx.x));
+    }
+    if (d_amax) {
+        __syncthreads();
+        lvt_block_amax_commit(am, d_amax, reinterpret_cast<float *>(sm.ring[0]));
+    }
+}
+
+// bank gradients: out[h][e] = sum over (sample, query half) of the workgroup partials, fixed order (attention_pipe.hip)
+__global__ __launch_bounds__(256) void lvt_attn_flash_bank_reduce_kernel(const float *__restrict__ partial, int B, int H, int NB, int nt,
+                                                                         int nh, float *__restrict__ ddt, float *__restrict__ ddh,
+                                                                         float *__restrict__ ddw) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (idx >= H * NB) return;
+    const int h = idx / NB, e = idx % NB;
+    float s = 0.f;
+    for (int jj = lane; jj < 2 * B; jj += 64) s += partial[(((long long)(jj >> 1) * H + h) * 2 + (jj & 1)) * NB + e];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane) return;
+    if (e < nt) ddt[h * nt + e] = s;
+    else if (e < nt + nh) ddh[h * nh + e - nt] = s;
+    else ddw[h * (NB - nt - nh) + e - nt - nh] = s;
+}
+
+}  // namespace
+
+extern "C" int lvt_attn_flash_supported(int S, int da, int bt, int bh, int bw) {
+    return S == AT_S && da == AT_D && ((bt == 1 && bh == 16 && bw == 16) || (bt == 4 && bh == 8 && bw == 8)) ? 1 : 0;
+}
+
+#define LVT_FA_GEOMS(X) X(1, 16, 16) X(4, 8, 8)
+
+extern "C" int lvt_attn_fwd_flash(const float *q, const float *k, const float *v, long long ld, int B, int H, int S, int da,
+                                  float temper, const float *dt, const float *dh, const float *dw, int bt, int bh, int bw,
+                                  int masked, float fill, float *o, float *stats, float *o_amax, void *stream) {
+    LVT_REQUIRE(q && k && v && dt && dh && dw && o && stats && B > 0 && H > 0, "attn_fwd_flash: bad args");
+    LVT_REQUIRE((B * H) % 8 == 0, "attn_fwd_flash: B * H = %d must be a multiple of 8 (workgroup pairing per XCD)", B * H);
+    LVT_REQUIRE(lvt_attn_flash_supported(S, da, bt, bh, bw), "attn_fwd_flash: S=%d da=%d block (%d,%d,%d) has no instantiation", S, da, bt, bh, bw);
+    LVT_REQUIRE(lvt_aligned16(q) && lvt_aligned16(k) && lvt_aligned16(v) && lvt_aligned16(o) && lvt_aligned16(stats) && ld % 4 == 0 &&
+                ld >= (long long)H * da, "attn_fwd_flash: alignment / row stride");
+    FaArgs A = {};
+    A.q = q; A.k = k; A.v = v; A.ld = ld; A.H = H; A.inv_temper = 1.f / temper; A.fill = fill;
+    A.dt = dt; A.dh = dh; A.dw = dw; A.o = o; A.m = stats; A.l = stats + (size_t)B * H * S;
+    const dim3 grid((unsigned)(B * H * (masked ? 1 : 2))), blk(512);
+    hipStream_t s = (hipStream_t)stream;
+#define LVT_X(BT, BH, BW)                                                                                       \
+    if (bt == BT && bh == BH && bw == BW) {                                                                     \
+        if (masked) hipLaunchKernelGGL((lvt_attn_fwd_flash_kernel<BT, BH, BW, 1>), grid, blk, 0, s, A, o_amax); \
+        else hipLaunchKernelGGL((lvt_attn_fwd_flash_kernel<BT, BH, BW, 0>), grid, blk, 0, s, A, o_amax);        \
+    }
+    LVT_FA_GEOMS(LVT_X)
+#undef LVT_X
+    LVT_CHECK_LAUNCH("lvt_attn_fwd_flash_kernel");
+    return LVT_OK;
+}
+
+extern "C" size_t lvt_attn_bwd_flash_workspace_bytes(int B, int H, int S, int bt, int bh, int bw) {
+    const size_t nb = (size_t)(2 * bt - 1) + (2 * bh - 1) + (2 * bw - 1);
+    return (size_t)B * H * S * sizeof(float) + (size_t)B * H * 2 * nb * sizeof(float);
+}
+
+extern "C" int lvt_attn_bwd_flash(const float *q, const float *k, const float *v, const float *d_o, long long ld, const float *stats,
+                                  int B, int H, int S, int da, float temper, const float *dt, const float *dh, const float *dw,
+                                  int bt, int bh, int bw, int masked, float fill, float *dq, float *dk, float *dv, float *ddt,
+                                  float *ddh, float *ddw, float *d_amax, void *workspace, size_t workspace_bytes, void *stream) {
+    LVT_REQUIRE(q && k && v && d_o && stats && dt && dh && dw && dq && dk && dv && ddt && ddh && ddw && B > 0 && H > 0, "attn_bwd_flash: bad args");
+    LVT_REQUIRE((B * H) % 8 == 0, "attn_bwd_flash: B * H = %d must be a multiple of 8 (workgroup pairing per XCD)", B * H);
+    LVT_REQUIRE(lvt_attn_flash_supported(S, da, bt, bh, bw), "attn_bwd_flash: S=%d da=%d block (%d,%d,%d) has no instantiation", S, da, bt, bh, bw);
+    LVT_REQUIRE(lvt_aligned16(q) && lvt_aligned16(k) && lvt_aligned16(v) && lvt_aligned16(d_o) && lvt_aligned16(stats) && lvt_aligned16(dq) &&
+                lvt_aligned16(dk) && lvt_aligned16(dv) && ld % 4 == 0 && ld >= (long long)H * da, "attn_bwd_flash: alignment / row stride");
+    if (!workspace || workspace_bytes < lvt_attn_bwd_flash_workspace_bytes(B, H, S, bt, bh, bw) || !lvt_aligned16(workspace)) {
+        lvt_set_error("attn_bwd_flash: workspace too small or misaligned");
+        return LVT_EWORKSPACE;
+    }
+    FaArgs A = {};
+    A.q = q; A.k = k; A.v = v; A.d_o = d_o; A.ld = ld; A.H = H; A.inv_temper = 1.f / temper; A.fill = fill;
+    A.dt = dt; A.dh = dh; A.dw = dw; A.m = const_cast<float *>(stats); A.l = const_cast<float *>(stats) + (size_t)B * H * S;
+    A.dq = dq; A.dk = dk; A.dv = dv;
+    A.delta = (float *)workspace;
+    A.bank_partial = A.delta + (size_t)B * H * S;
+    const int nt = 2 * bt - 1, nh = 2 * bh - 1, nw = 2 * bw - 1, nb = nt + nh + nw;
+    const dim3 grid((unsigned)(B * H * (masked ? 1 : 2))), blk(512);
+    hipStream_t s = (hipStream_t)stream;
+#define LVT_X(BT, BH, BW)                                                                                         \
+    if (bt == BT && bh == BH && bw == BW) {                                                                       \
+        if (masked) hipLaunchKernelGGL((lvt_attn_bwd_flash_a_kernel<BT, BH, BW, 1>), grid, blk, 0, s, A, d_amax); \
+        else hipLaunchKernelGGL((lvt_attn_bwd_flash_a_kernel<BT, BH, BW, 0>), grid, blk, 0, s, A, d_amax);        \
+    }
+    LVT_FA_GEOMS(LVT_X)
+#undef LVT_X
+    LVT_CHECK_LAUNCH("lvt_attn_bwd_flash_a_kernel");
+#define LVT_X(BT, BH, BW)                                                                                         \
+    if (bt == BT && bh == BH && bw == BW) {                                                                       \
+        if (masked) hipLaunchKernelGGL((lvt_attn_bwd_flash_b_kernel<BT, BH, BW, 1>), grid, blk, 0, s, A, d_amax); \
+        else hipLaunchKernelGGL((lvt_attn_bwd_flash_b_kernel<BT, BH, BW, 0>), grid, blk, 0, s, A, d_amax);        \
+    }
+    LVT_FA_GEOMS(LVT_X)
+#undef LVT_X
+    LVT_CHECK_LAUNCH("lvt_attn_bwd_flash_b_kernel");
+    hipLaunchKernelGGL(lvt_attn_flash_bank_reduce_kernel, dim3((unsigned)lvt_cdiv((long long)H * nb, 4)), dim3(256), 0, s,
+                       A.bank_partial, B, H, nb, nt, nh, ddt, ddh, ddw);
+    LVT_CHECK_LAUNCH("lvt_attn_flash_bank_reduce_kernel");
+    return LVT_OK;
+}

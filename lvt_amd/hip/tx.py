@@ -17,6 +17,7 @@ def attn_softmax_fwd_(scores, temper, dt, dh, dw, block, masked, fill=-1e4):
     L.check(L.lib().lvt_attn_softmax_fwd(L.ptr(scores), B, H, S, temper, L.ptr(dt), L.ptr(dh), L.ptr(dw),
                                          block[0], block[1], block[2], 1 if masked else 0, fill, L.stream_ptr()),
             "lvt_attn_softmax_fwd")
+    L.drop_amax(scores)         # rewritten in place through a raw pointer: the record of max |q k^T| no longer bounds it
     return scores
 
 
@@ -82,6 +83,51 @@ def attn_bwd_planes(qkvp, dop, P, o, B, H, S, da, temper, block, masked):
     return dqkv, ddt, ddh, ddw
 
 
+def attn_flash_supported(S, da, block, bh_pairs=8):
+    """The flash kernels (csrc/attention_flash.hip) serve 256-token x 128-dim blocks of an instantiated geometry in the f16x2
+    arithmetic; bh_pairs = batch x heads must be a multiple of 8 (workgroup pairing per XCD)."""
+    return (bh_pairs % 8 == 0 and L.get_math_mode() == "f16x2" and
+            bool(L.lib().lvt_attn_flash_supported(S, da, block[0], block[1], block[2])))
+
+
+def attn_fwd_flash(qkv, B, H, S, da, temper, dt, dh, dw, block, masked, fill=-1e4):
+    """qkv (3, B*S, H*da) fp32 (the packed projection output) -> (o (B*S, H*da), stats (2, B*H*S): row max, 1 / row sum).
+    No attention matrix is written (vt_attention.py:59-81)."""
+    L.require(qkv, dt, dh, dw)
+    M, hd = B * S, H * da
+    o = torch.empty(M, hd, dtype=torch.float32, device=qkv.device)
+    stats = torch.empty(2, B * H * S, dtype=torch.float32, device=qkv.device)
+    t0 = L.TIMER.begin() if L.TIMER is not None else None
+    L.check(L.lib().lvt_attn_fwd_flash(L.ptr(qkv[0]), L.ptr(qkv[1]), L.ptr(qkv[2]), hd, B, H, S, da, temper, L.ptr(dt), L.ptr(dh),
+                                       L.ptr(dw), block[0], block[1], block[2], 1 if masked else 0, fill, L.ptr(o), L.ptr(stats),
+                                       L.out_amax(o), L.stream_ptr()), "lvt_attn_fwd_flash")
+    if t0 is not None:
+        L.TIMER.end("attn_fwd", 4.0 * B * H * S * S * da, t0)
+    return o, stats
+
+
+def attn_bwd_flash(qkv, do, stats, B, H, S, da, temper, dt, dh, dw, block, masked, fill=-1e4):
+    """-> (dqkv (3, B*S, H*da) fp32, ddt, ddh, ddw); do (B*S, H*da) fp32."""
+    L.require(qkv, do, stats, dt, dh, dw)
+    M, hd = B * S, H * da
+    dev = qkv.device
+    dqkv = torch.empty(3, M, hd, dtype=torch.float32, device=dev)
+    ddt = torch.empty(H, 2 * block[0] - 1, dtype=torch.float32, device=dev)
+    ddh = torch.empty(H, 2 * block[1] - 1, dtype=torch.float32, device=dev)
+    ddw = torch.empty(H, 2 * block[2] - 1, dtype=torch.float32, device=dev)
+    lib = L.lib()
+    nws = lib.lvt_attn_bwd_flash_workspace_bytes(B, H, S, block[0], block[1], block[2])
+    ws = L.workspace(nws, dev, "attn_bwd")
+    t0 = L.TIMER.begin() if L.TIMER is not None else None
+    L.check(lib.lvt_attn_bwd_flash(L.ptr(qkv[0]), L.ptr(qkv[1]), L.ptr(qkv[2]), L.ptr(do), hd, L.ptr(stats), B, H, S, da, temper,
+                                   L.ptr(dt), L.ptr(dh), L.ptr(dw), block[0], block[1], block[2], 1 if masked else 0, fill,
+                                   L.ptr(dqkv[0]), L.ptr(dqkv[1]), L.ptr(dqkv[2]), L.ptr(ddt), L.ptr(ddh), L.ptr(ddw),
+                                   L.out_amax(dqkv), L.ptr(ws), nws, L.stream_ptr()), "lvt_attn_bwd_flash")
+    if t0 is not None:
+        L.TIMER.end("attn_bwd", 10.0 * B * H * S * S * da, t0)     # S and dP recomputed once: 5 score-sized products (algorithmic)
+    return dqkv, ddt, ddh, ddw
+
+
 def attn_softmax_bwd_(P, dP, temper, block):
     """dP is overwritten with dS.  Returns (ddt, ddh, ddw)."""
     L.require(P, dP)
@@ -92,6 +138,7 @@ def attn_softmax_bwd_(P, dP, temper, block):
     ddw = torch.empty(H, 2 * block[2] - 1, dtype=torch.float32, device=P.device)
     L.check(L.lib().lvt_attn_softmax_bwd(L.ptr(P), L.ptr(dP), B, H, S, temper, block[0], block[1], block[2], L.ptr(G),
                                          L.ptr(ddt), L.ptr(ddh), L.ptr(ddw), L.stream_ptr()), "lvt_attn_softmax_bwd")
+    L.drop_amax(dP)             # dP now holds dS
     return ddt, ddh, ddw
 
 

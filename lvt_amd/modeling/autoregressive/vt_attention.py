@@ -157,7 +157,17 @@ FUSED_ATTENTION = True      # scores + bias + mask + softmax + P.V in one launch
 # DSTSVT), 256 tokens x 128 head dims, bf16x3 arithmetic and batch x heads % 8 == 0.  LVT_NO_PLANE_ATTENTION=1 (or
 # PLANE_ATTENTION = False) keeps the round-2 path; tests force either side.
 PLANE_ATTENTION = None
+# Round 5: in the f16x2 arithmetic the attention core runs on the flash kernels (csrc/attention_flash.hip): fp32 q / k / v / dO
+# straight from the projection GEMMs (no planes), no attention matrix in HBM (two floats per row are saved instead of 256),
+# P and dS recomputed in the backward pass.  LVT_NO_FLASH_ATTENTION=1 (or FLASH_ATTENTION = False) keeps the plane kernels.
+FLASH_ATTENTION = None
 PAIR_FFN_WGRAD = not os.environ.get("LVT_NO_PAIR_WGRAD")     # the two FFN weight gradients of a layer as one 2-batch launch
+
+
+def _use_flash(S, da, block, pairs):
+    if os.environ.get("LVT_NO_FLASH_ATTENTION") or FLASH_ATTENTION is False:
+        return False
+    return tx.attn_flash_supported(S, da, block, pairs)
 
 
 def _use_planes(S, da, block, pairs):
@@ -179,7 +189,8 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         temper = math.sqrt(da)
         dev = x.device
         xn, mean1, rstd1 = ew.layernorm_fwd(x, ln_w, ln_b)
-        planes = FUSED_ATTENTION and _use_planes(S, da, block, b * na)
+        flash = FUSED_ATTENTION and _use_flash(S, da, block, b * na)
+        planes = FUSED_ATTENTION and not flash and _use_planes(S, da, block, b * na)
         if planes:
             # q, k, v of all heads in ONE launch whose epilogue writes them as their exact 3-way bf16 split (3 operands x
             # 3 planes x (M, hd)): the operand format of the pipelined attention kernels, which then stage by copying
@@ -195,6 +206,8 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
             q, k, v = qkv[0], qkv[1], qkv[2]
         if planes:
             pass
+        elif flash:
+            o, P = tx.attn_fwd_flash(qkv, b, na, S, da, temper, dt, dh, dw, block, masked)     # "P": the (2, b*na*S) row statistics
         elif FUSED_ATTENTION and tx.attn_fwd_supported(S, da):
             P, o = tx.attn_fwd(q, k, v, b, na, S, da, temper, dt, dh, dw, block, masked)
         else:
@@ -215,14 +228,14 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         y2 = torch.empty(M, d, dtype=torch.float32, device=dev)
         G.gemm(h1, f3w, y2, M, d, f3w.shape[1], flags=L.EPI_BIAS | L.EPI_RESIDUAL, bias=f3b, res=y1)
         ctx.save_for_backward(x, mean1, rstd1, xn, qkv, P, o, y1, mean2, rstd2, fn, h1,
-                              ln_w, wqkv, proj_w, f0w, f1w, f3w)
-        ctx.block, ctx.dims, ctx.masked, ctx.planes = block, (M, d, S, b, na, da), bool(masked), bool(planes)
+                              ln_w, wqkv, proj_w, f0w, f1w, f3w, dt, dh, dw)
+        ctx.block, ctx.dims, ctx.masked, ctx.planes, ctx.flash = block, (M, d, S, b, na, da), bool(masked), bool(planes), bool(flash)
         return y2
 
     @staticmethod
     def backward(ctx, dy2):
         (x, mean1, rstd1, xn, qkv, P, o, y1, mean2, rstd2, fn, h1,
-         ln_w, wqkv, proj_w, f0w, f1w, f3w) = ctx.saved_tensors
+         ln_w, wqkv, proj_w, f0w, f1w, f3w, dt, dh, dw) = ctx.saved_tensors
         M, d, S, b, na, da = ctx.dims
         hd = na * da
         temper = math.sqrt(da)
@@ -254,6 +267,11 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         do = torch.empty(M, hd, dtype=torch.float32, device=dev)
         G.gemm(dy1, proj_w, do, M, hd, d, ta=0, tb=1, ldb=hd)
         dproj = linear_wgrad(dy1, o, d, hd, M)
+        if ctx.flash:
+            # the whole attention core backward on fp32 operands: P and dS are recomputed from q, k, v, dO and the row statistics
+            dqkv, ddt, ddh, ddw = tx.attn_bwd_flash(qkv, do, P, b, na, S, da, temper, dt, dh, dw, ctx.block, ctx.masked)
+            return _BlockLocalAttentionFn._finish_backward(ctx, dqkv, ddt, ddh, ddw, dy1, dproj, df0w, df0b, df1w, df1b,
+                                                            df3w, df3b)
         # attention core
         q, k, v = qkv[0], qkv[1], qkv[2]
         bh = dict(batch_outer=b, batch_inner=na)
