@@ -51,16 +51,15 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define FA_SLOT (2 * FA_PL)               // hi plane, lo plane: 36864 B
 #define FA_EMIN 15                        // clamp of the biased exponent of a row max (keeps every derived scale a normal float)
 #define FA_EMAX 254
+#define FA_LOG2E 1.4426950408889634f      // scores are kept in log2 units: p = 2^(x - m) is one v_exp_f32
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float fa_u2f(unsigned u) { return __uint_as_float(u); }
-// 2^d for an exponent difference d <= 0 (0 below the normal range)
-__device__ __forceinline__ float fa_pow2_neg(int d) { return d < -126 ? 0.f : fa_u2f((unsigned)(127 + d) << 23); }
 // float with biased exponent field e (0 when e <= 0)
 __device__ __forceinline__ float fa_exp_field(int e) { return e <= 0 ? 0.f : fa_u2f((unsigned)e << 23); }
-__device__ __forceinline__ int fa_ebits(float nonneg) {
-    const int e = (int)((__float_as_uint(nonneg) >> 23) & 0xffu);
-    return e < FA_EMIN ? FA_EMIN : (e > FA_EMAX ? FA_EMAX : e);
-}
+__device__ __forceinline__ int fa_clamp_e(int e) { return e < FA_EMIN ? FA_EMIN : (e > FA_EMAX ? FA_EMAX : e); }
+__device__ __forceinline__ int fa_ebits(float nonneg) { return fa_clamp_e((int)((__float_as_uint(nonneg) >> 23) & 0xffu)); }
 template <int CTRL> __device__ __forceinline__ float fa_dpp_max(float v) {
     const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
     return fmaxf(v, __builtin_bit_cast(float, o));
@@ -73,9 +72,24 @@ __device__ __forceinline__ float fa_row16_max(float v) {
     v = fa_dpp_max<0x140>(v);
     return v;
 }
-// sum / max over the four lanes (kg = lane >> 4) that share a 16-wide tile column
-__device__ __forceinline__ float fa_kg_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
-__device__ __forceinline__ float fa_kg_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
+// sum / max over the four lanes (kg = lane >> 4) that share a 16-wide tile column: the gfx950 row swaps (VALU; a
+// ds_bpermute shuffle goes through the LDS crossbar and waits on lgkmcnt).  v_permlane16_swap exchanges rows 1 <-> 0 and
+// 3 <-> 2 of its two operands, v_permlane32_swap the upper half of one with the lower half of the other: with both operands =
+// v the two results hold v of (row, row ^ 1) resp. (half, half ^ 1) side by side.
+__device__ __forceinline__ float fa_kg_max(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(fa_u2f(r[0]), fa_u2f(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(fa_u2f(r[0]), fa_u2f(r[1]));
+}
+__device__ __forceinline__ float fa_kg_sum(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fa_u2f(r[0]) + fa_u2f(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fa_u2f(r[0]) + fa_u2f(r[1]);
+}
+__device__ __forceinline__ float fa_max4(const f32x4v a) { return fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])); }
+__device__ __forceinline__ float fa_absmax4(const float4 a) { return fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))); }
 
 __device__ __forceinline__ float fa_mix_lo(unsigned h, float c) {        // c - half(h.lo), exact
     float r;
@@ -94,18 +108,29 @@ __device__ __forceinline__ void fa_split_pair(float a, float b, float s, unsigne
     const f32x2 r = {fa_mix_lo(ph, t.x), fa_mix_hi(ph, t.y)};
     pl = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2v));
 }
-// eight values (k slots 0..7 of a B operand) -> hi / lo fragments
-__device__ __forceinline__ void fa_split8(const float (&v)[8], float s, f16x8 &h, f16x8 &l) {
+// the same for values that are already scaled
+__device__ __forceinline__ void fa_split_pair1(float a, float b, unsigned &ph, unsigned &pl) {
+    const f32x2 t = {a, b};
+    ph = __builtin_bit_cast(unsigned, __builtin_convertvector(t, f16x2v));
+    const f32x2 r = {fa_mix_lo(ph, a), fa_mix_hi(ph, b)};
+    pl = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2v));
+}
+// eight scaled values (k slots 0..7 of a B operand) -> hi / lo fragments
+__device__ __forceinline__ void fa_split8(const float (&v)[8], f16x8 &h, f16x8 &l) {
     u32x4 uh, ul;
     unsigned a, b;
-    fa_split_pair(v[0], v[1], s, a, b); uh[0] = a; ul[0] = b;
-    fa_split_pair(v[2], v[3], s, a, b); uh[1] = a; ul[1] = b;
-    fa_split_pair(v[4], v[5], s, a, b); uh[2] = a; ul[2] = b;
-    fa_split_pair(v[6], v[7], s, a, b); uh[3] = a; ul[3] = b;
+    fa_split_pair1(v[0], v[1], a, b); uh[0] = a; ul[0] = b;
+    fa_split_pair1(v[2], v[3], a, b); uh[1] = a; ul[1] = b;
+    fa_split_pair1(v[4], v[5], a, b); uh[2] = a; ul[2] = b;
+    fa_split_pair1(v[6], v[7], a, b); uh[3] = a; ul[3] = b;
     h = __builtin_bit_cast(f16x8, uh);
     l = __builtin_bit_cast(f16x8, ul);
 }
-// acc += a b with a = ah + al, b = bh + bl (smallest terms first)
+// The biased score of one (query, key) pair in log2 units, from the accumulator of the scaled operands.  ONE expression for the
+// forward and both backward kernels: the backward recomputes p = 2^(x - m) / l against the forward's m and l, and only a
+// bit-identical x makes the row maximum cancel exactly and the recomputed P equal the forward's (folding m into the bias
+// instead tripled the error of dq / dv on heavy-tailed operands).
+__device__ __forceinline__ float fa_score(float acc, float kq, float bias) { return fmaf(acc, kq, bias); }
 __device__ __forceinline__ f32x4v fa_mfma(const f16x8 a, const f16x8 b, const f32x4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
@@ -113,7 +138,27 @@ __device__ __forceinline__ f32x4v fa_mfma(const f16x8 a, const f16x8 b, const f3
 // ---------------------------------------------------------------------------------------------------------------------------
 // staging
 // ---------------------------------------------------------------------------------------------------------------------------
-struct G4 { float4 v[4]; };              // row r of operand X: columns 4 c, 4 c + 64; row r of operand Y: the same
+// One row of 128 fp32 values held by 16 lanes (lane c: columns 4 c .. + 3 and 4 c + 64 .. + 3) -> its scale, then the two
+// fp16 planes of LDS row `row` of `slot` and rs_inv[row] = 2^(e - 14), the inverse of the scale.  (An inf / nan element takes
+// part in max |.| like any other -- v_max ignores a nan, an inf clamps the scale: such a row is lost either way.)  Two pieces,
+// so that a kernel can spread the work between its MFMA groups.
+__device__ __forceinline__ int fa_row_scale(const float4 a, const float4 b) {     // -> biased exponent of the row max
+    return fa_ebits(fa_row16_max(fmaxf(fa_absmax4(a), fa_absmax4(b))));
+}
+__device__ __forceinline__ void fa_row_store(const float4 a, const float4 b, int eb, unsigned short *slot, float *rs_inv, int row, int c) {
+    const float s = fa_u2f((unsigned)(268 - eb) << 23);               // row max * s in [2^14, 2^15)
+    uint2 h0, l0, h1, l1;
+    fa_split_pair(a.x, a.y, s, h0.x, l0.x); fa_split_pair(a.z, a.w, s, h0.y, l0.y);
+    fa_split_pair(b.x, b.y, s, h1.x, l1.x); fa_split_pair(b.z, b.w, s, h1.y, l1.y);
+    unsigned short *d = slot + row * FA_LD + 4 * c;
+    *reinterpret_cast<uint2 *>(d) = h0;
+    *reinterpret_cast<uint2 *>(d + 64) = h1;
+    *reinterpret_cast<uint2 *>(d + FA_PL) = l0;
+    *reinterpret_cast<uint2 *>(d + FA_PL + 64) = l1;
+    rs_inv[c == 0 ? row : 64 + c] = fa_u2f((unsigned)(eb - 14) << 23);      // (entries 64..79: scratch, keeps the piece branch-free)
+}
+// 512-thread workgroups: a thread holds row r = tid >> 4 of operand X and row r of operand Y of a 32 + 32-row item
+struct G4 { float4 v[4]; };
 __device__ __forceinline__ void fa_load(G4 &g, const float *__restrict__ x, const float *__restrict__ y, long long ld, int tid) {
     const int r = tid >> 4, c = tid & 15;
     const float *px = x + (long long)r * ld + 4 * c, *py = y + (long long)r * ld + 4 * c;
@@ -122,30 +167,59 @@ __device__ __forceinline__ void fa_load(G4 &g, const float *__restrict__ x, cons
     g.v[2] = *reinterpret_cast<const float4 *>(py);
     g.v[3] = *reinterpret_cast<const float4 *>(py + 64);
 }
-// split + store into `slot` (rows 0..31: X, 32..63: Y); rs_inv[row] = 2^(e - 14), the inverse of the row's scale; emax2
-// (optional): LDS words that collect the largest biased row exponent of the X / Y half (zeroed by the kernel prologue)
-__device__ __forceinline__ void fa_park(const G4 &g, unsigned short *slot, float *rs_inv, unsigned *emax2, int tid) {
+__device__ __forceinline__ void fa_park(const G4 &g, unsigned short *slot, float *rs_inv, int tid) {
     const int r = tid >> 4, c = tid & 15;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const float4 a = g.v[2 * half], b = g.v[2 * half + 1];
-        float m = fmaxf(fmaxf(fmaxf(lvt_absf(a.x), lvt_absf(a.y)), fmaxf(lvt_absf(a.z), lvt_absf(a.w))),
-                        fmaxf(fmaxf(lvt_absf(b.x), lvt_absf(b.y)), fmaxf(lvt_absf(b.z), lvt_absf(b.w))));
-        m = fa_row16_max(m);
-        const int eb = fa_ebits(m);
-        const float s = fa_u2f((unsigned)(268 - eb) << 23);           // row max * s in [2^14, 2^15)
-        uint2 h0, l0, h1, l1;
-        fa_split_pair(a.x, a.y, s, h0.x, l0.x); fa_split_pair(a.z, a.w, s, h0.y, l0.y);
-        fa_split_pair(b.x, b.y, s, h1.x, l1.x); fa_split_pair(b.z, b.w, s, h1.y, l1.y);
-        unsigned short *d = slot + (32 * half + r) * FA_LD + 4 * c;
-        *reinterpret_cast<uint2 *>(d) = h0;
-        *reinterpret_cast<uint2 *>(d + 64) = h1;
-        *reinterpret_cast<uint2 *>(d + FA_PL) = l0;
-        *reinterpret_cast<uint2 *>(d + FA_PL + 64) = l1;
-        if (c == 0) {
-            rs_inv[32 * half + r] = fa_u2f((unsigned)(eb - 14) << 23);
-            if (emax2) atomicMax(emax2 + half, (unsigned)eb);
-        }
+    for (int half = 0; half < 2; ++half)
+        fa_row_store(g.v[2 * half], g.v[2 * half + 1], fa_row_scale(g.v[2 * half], g.v[2 * half + 1]), slot, rs_inv, 32 * half + r, c);
+}
+// 256-thread workgroups: rows r = tid >> 4 and r + 16 of X, then of Y (piece p = 0..3: LDS row 16 p + r)
+struct G8 { float4 v[8]; };
+__device__ __forceinline__ void fa_load8(G8 &g, const float *__restrict__ x, const float *__restrict__ y, long long ld, int tid) {
+    const int r = tid >> 4, c = tid & 15;
+    const float *px = x + (long long)r * ld + 4 * c, *py = y + (long long)r * ld + 4 * c;
+    g.v[0] = *reinterpret_cast<const float4 *>(px);
+    g.v[1] = *reinterpret_cast<const float4 *>(px + 64);
+    g.v[2] = *reinterpret_cast<const float4 *>(px + 16 * ld);
+    g.v[3] = *reinterpret_cast<const float4 *>(px + 16 * ld + 64);
+    g.v[4] = *reinterpret_cast<const float4 *>(py);
+    g.v[5] = *reinterpret_cast<const float4 *>(py + 64);
+    g.v[6] = *reinterpret_cast<const float4 *>(py + 16 * ld);
+    g.v[7] = *reinterpret_cast<const float4 *>(py + 16 * ld + 64);
+}
+__device__ __forceinline__ void fa_park8(const G8 &g, unsigned short *slot, float *rs_inv, int tid) {
+    const int r = tid >> 4, c = tid & 15;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        fa_row_store(g.v[2 * p], g.v[2 * p + 1], fa_row_scale(g.v[2 * p], g.v[2 * p + 1]), slot, rs_inv, 16 * p + r, c);
+}
+// The wave's stationary operand straight from global memory in B-fragment layout: lane (tile column c16 = row `row` of the
+// operand, k block kg) holds k = 32 s + 8 kg .. + 7 of each of the four k steps; the row's scale from the 32 values of the lane
+// and the three other lanes of the column.  inv = 2^(e - 14).
+__device__ __forceinline__ void fa_load_bfrags(const float *__restrict__ row, int kg, f16x8 (&fr)[4][2], float &inv) {
+    float4 v[8];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        v[2 * s] = *reinterpret_cast<const float4 *>(row + 32 * s + 8 * kg);
+        v[2 * s + 1] = *reinterpret_cast<const float4 *>(row + 32 * s + 8 * kg + 4);
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fa_absmax4(v[e]));
+    m = fa_kg_max(m);
+    const int eb = fa_ebits(m);
+    const float sc = fa_u2f((unsigned)(268 - eb) << 23);
+    inv = fa_u2f((unsigned)(eb - 14) << 23);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        u32x4 uh, ul;
+        unsigned a, b;
+        fa_split_pair(v[2 * s].x, v[2 * s].y, sc, a, b); uh[0] = a; ul[0] = b;
+        fa_split_pair(v[2 * s].z, v[2 * s].w, sc, a, b); uh[1] = a; ul[1] = b;
+        fa_split_pair(v[2 * s + 1].x, v[2 * s + 1].y, sc, a, b); uh[2] = a; ul[2] = b;
+        fa_split_pair(v[2 * s + 1].z, v[2 * s + 1].w, sc, a, b); uh[3] = a; ul[3] = b;
+        fr[s][0] = __builtin_bit_cast(f16x8, uh);
+        fr[s][1] = __builtin_bit_cast(f16x8, ul);
     }
 }
 // fragment of LDS row `row` (A operand: the row is the tile row; B operand: the row is the tile column), k = 32 s + 8 kg .. + 7
@@ -165,29 +239,28 @@ __device__ __forceinline__ f16x8 fa_trfrag(const unsigned short *slot, int pl, i
 
 struct FaSmem {
     unsigned short ring[2][FA_SLOT];
-    float rs_inv[2][64];
-    unsigned emax[24][2];
-    float dhs[32];                        // this head's dh bank (2 BH - 1 entries)
+    float rs_inv[2][80];
+    float dhs[32];                        // this head's dh bank (2 BH - 1 entries), in log2 units
 };
 template <int NR> struct FaSmemA {
     unsigned short ring[2][FA_SLOT];
-    float rs_inv[2][64];
-    unsigned emax[24][2];
+    float rs_inv[2][80];
     float dhs[32];
+    float red[16];
     float R[128 * 4 * NR];                // per-lane class sums of g (bias-bank gradient), [query][kg][NR]
 };
-struct FaSmemB {
-    unsigned short ring[2][FA_SLOT];
-    unsigned short vres[2][FA_SLOT];      // the workgroup's 128 V rows, resident
-    float rs_inv[2][64];
-    float vinv[2][64];
-    unsigned emax[16][2];
+struct FaSmem3 {                          // 256-thread workgroups: three-slot ring
+    unsigned short ring[3][FA_SLOT];
+    float rs_inv[3][80];
     float dhs[32];
 };
 
 // workgroup -> (sample, head) pair and half: the two halves of a pair get block ids 8 apart (same XCD, back to back)
 __device__ __forceinline__ int fa_pair(unsigned x) { return (int)(((x >> 4) << 3) | (x & 7)); }
 __device__ __forceinline__ int fa_half(unsigned x) { return (int)((x >> 3) & 1); }
+// the same for four quarters per pair
+__device__ __forceinline__ int fa_pair4(unsigned x) { return (int)(((x >> 5) << 3) | (x & 7)); }
+__device__ __forceinline__ int fa_quarter(unsigned x) { return (int)((x >> 3) & 3); }
 __device__ __forceinline__ int fa_opaque(int x) { asm volatile("" : "+s"(x)); return x; }
 
 template <int BH, int BW> struct Geo16 {
@@ -200,25 +273,15 @@ template <int BT, int BH, int BW> struct BankIdx {
     static constexpr int NT = 2 * BT - 1, NH = 2 * BH - 1, NW = 2 * BW - 1, NB = NT + NH + NW;
 };
 
-// stage 128 rows (the workgroup's stationary operand) into two slot-shaped regions; every wave then reads its 16 rows
-template <class SM = int>
-__device__ __forceinline__ void fa_stage128(const float *rows, long long ld, unsigned short *s0, unsigned short *s1, float *i0, float *i1,
-                                            int tid) {
-    G4 a, b;
-    fa_load(a, rows, rows + 32 * ld, ld, tid);
-    fa_load(b, rows + 64 * ld, rows + 96 * ld, ld, tid);
-    fa_park(a, s0, i0, nullptr, tid);
-    fa_park(b, s1, i1, nullptr, tid);
-}
-
 struct FaArgs {
     const float *q, *k, *v, *d_o;        // token-major (B*S rows, ld floats per row), head h in columns h*128 ..
     long long ld;
     int H;
-    float inv_temper, fill;
+    float c1, fill2;                     // log2(e) / temper; the causal fill in log2 units
+    float inv_temper;
     const float *dt, *dh, *dw;
-    float *o, *m, *l;                    // forward outputs: o and the row statistics (B*H*S each): max m, 1 / sum l
-    float *dq, *dk, *dv, *delta, *bank_partial;
+    float *o, *m, *l;                    // forward outputs: o and the row statistics (B*H*S each): max m (log2 units), 1 / sum l
+    float *dq, *dk, *dv, *delta, *scal, *bank_partial;
 };
 
 // ===========================================================================================================================
@@ -237,43 +300,33 @@ __device__ __forceinline__ float fa_fwd_body(const FaArgs &A, FaSmem &sm, int bh
     const float *kbase = A.k + row0 * A.ld + h * AT_D, *vbase = A.v + row0 * A.ld + h * AT_D;
     constexpr int NIT = NCH;
 
-    if (tid < 48) (&sm.emax[0][0])[tid] = 0u;
-    if (tid < 2 * BH - 1) sm.dhs[tid] = A.dh[h * (2 * BH - 1) + tid];
-    fa_stage128<FaSmem>(A.q + (row0 + qhalf * 128) * A.ld + h * AT_D, A.ld, sm.ring[0], sm.ring[1], sm.rs_inv[0], sm.rs_inv[1], tid);
+    if (tid < 2 * BH - 1) sm.dhs[tid] = A.dh[h * (2 * BH - 1) + tid] * FA_LOG2E;
     G4 g0, g1;
 #define FA_G(t) ((((t) & 1) == 0) ? g0 : g1)
     auto load_item = [&](int t, G4 &gg) { fa_load(gg, kbase + (long long)(32 * t) * A.ld, vbase + (long long)(32 * t) * A.ld, A.ld, tid); };
     load_item(0, g0);
     if (NIT > 1) load_item(1, g1);
-    __syncthreads();
     f16x8 qb[4][2];
     float qinv;
-    {
-        const unsigned short *qs = sm.ring[il >> 6];
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) qb[s][pl] = fa_rowfrag(qs, pl, il & 63, s, kg);
-        qinv = sm.rs_inv[il >> 6][il & 63];
-    }
+    fa_load_bfrags(A.q + (row0 + i) * A.ld + h * AT_D, kg, qb, qinv);
     const int wi = i % BW, hi = (i / BW) % BH, ti = i / (BW * BH);
     float bt_[BT], bw_[4];
 #pragma unroll
-    for (int x = 0; x < BT; ++x) bt_[x] = A.dt[h * (2 * BT - 1) + ti - x + BT - 1];
+    for (int x = 0; x < BT; ++x) bt_[x] = A.dt[h * (2 * BT - 1) + ti - x + BT - 1] * FA_LOG2E;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bw_[r] = A.dw[h * (2 * BW - 1) + wi - GE::wj(r, kg) + BW - 1];
+    for (int r = 0; r < 4; ++r) bw_[r] = A.dw[h * (2 * BW - 1) + wi - GE::wj(r, kg) + BW - 1] * FA_LOG2E;
     // dh[hi - hj(x, kg) + BH - 1] of h slot x, read from LDS per tile (a 16-entry per-lane table would cost 16 registers)
     const float *dhl = sm.dhs + (hi + BH - 1 - (BW == 16 ? 0 : (kg >> 1)));
     constexpr int HSTEP = BW == 16 ? 1 : 2;
-    __syncthreads();
-    fa_park(g0, sm.ring[0], sm.rs_inv[0], sm.emax[0], tid);
+    const float qc = qinv * A.c1;
+    fa_park(g0, sm.ring[0], sm.rs_inv[0], tid);
     __syncthreads();
 
     f32x4v oacc[AT_D / 16];
 #pragma unroll
     for (int d = 0; d < AT_D / 16; ++d) oacc[d] = f32x4v{0.f, 0.f, 0.f, 0.f};
     float m_run = -3.0e38f, lsum = 0.f;
-    int E_run = FA_EMIN;
+    float vmax_run = fa_u2f((unsigned)(FA_EMIN - 14) << 23);         // largest 2^(e - 14) over the V rows met so far
 
     static_for<NIT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
@@ -296,47 +349,46 @@ __device__ __forceinline__ float fa_fwd_body(const FaArgs &A, FaSmem &sm, int bh
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) st[kt] = fa_mfma(a[kt][0], qb[s][0], st[kt]);
         }
-        if constexpr (t + 1 < NIT) fa_park(FA_G(t + 1), sm.ring[(t + 1) & 1], sm.rs_inv[(t + 1) & 1], sm.emax[t + 1], tid);
-        // ---- scores, online softmax ----
+        if constexpr (t + 1 < NIT) fa_park(FA_G(t + 1), sm.ring[(t + 1) & 1], sm.rs_inv[(t + 1) & 1], tid);
+        // ---- scores (log2 units), online softmax ----
         float x[8];
-        float cmax = -3.0e38f;
+        f32x4v vinv[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            constexpr int dummy = 0; (void)dummy;
             const int T = 2 * t + kt;
             const f32x4v kinv = *reinterpret_cast<const f32x4v *>(cinv + 16 * kt + 4 * kg);
+            vinv[kt] = *reinterpret_cast<const f32x4v *>(cinv + 32 + 16 * kt + 4 * kg);
             const float bth = bt_[T / HP] + dhl[-HSTEP * (T % HP)];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = (st[kt][r] * (kinv[r] * qinv)) * A.inv_temper + (bth + bw_[r]);
-                if (MASKED && 16 * T + 4 * kg + r > i) v = A.fill;
+                float v = fa_score(st[kt][r], kinv[r] * qc, bth + bw_[r]);
+                if (MASKED && 16 * T + 4 * kg + r > i) v = A.fill2;
                 x[4 * kt + r] = v;
-                cmax = fmaxf(cmax, v);
             }
         }
+        float cmax = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
         cmax = fa_kg_max(cmax);
+        const float vmax_c = fa_kg_max(fmaxf(fa_max4(vinv[0]), fa_max4(vinv[1])));   // = 2^(E_c - 141)
         const float m_new = fmaxf(m_run, cmax);
-        const float alpha = __expf(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
-        const int E_c = (int)sm.emax[t][1];
-        const int E_new = E_c > E_run ? E_c : E_run;
-        const float fo = alpha * fa_pow2_neg(E_run - E_new);
-        E_run = E_new;
-        const float srun = fa_u2f((unsigned)(268 - E_new) << 23);
+        const float vmax_new = fmaxf(vmax_run, vmax_c);
+        // accumulated so far at weight 2^(141 - E_run): bring it to the new chunk scale (exact) and to the new row max
+        const float fo = alpha * (vmax_run * __builtin_amdgcn_rcpf(vmax_new));
+        vmax_run = vmax_new;
+        const float srun = 32768.f * __builtin_amdgcn_rcpf(vmax_new);                 // 2^15 * 2^(141 - E_run), exact (powers of two)
         float psum = 0.f, pw[8];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            const f32x4v vinv = *reinterpret_cast<const f32x4v *>(cinv + 32 + 16 * kt + 4 * kg);
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(x[4 * kt + r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(x[4 * kt + r] - m_new);
                 psum += p;
-                pw[4 * kt + r] = p * (vinv[r] * srun);
+                pw[4 * kt + r] = p * (vinv[kt][r] * srun);
             }
-        }
         lsum = lsum * alpha + psum;
         f16x8 pbh, pbl;
-        fa_split8(pw, 32768.f, pbh, pbl);
+        fa_split8(pw, pbh, pbl);
 #pragma unroll
         for (int d = 0; d < AT_D / 16; ++d) oacc[d] *= fo;
         // ---- O^T += V^T P^T ----
@@ -358,7 +410,8 @@ __device__ __forceinline__ float fa_fwd_body(const FaArgs &A, FaSmem &sm, int bh
     });
 #undef FA_G
     const float linv = 1.f / fa_kg_sum(lsum);
-    const float osc = fa_exp_field(E_run - 29) * linv;
+    // sum_j p V = acc 2^(E_run - 156) = acc vmax_run 2^-15 (vmax_run = 2^(E_run - 141))
+    const float osc = (vmax_run * (1.f / 32768.f)) * linv;
     float am = 0.f;
     {
         float *orow = A.o + (row0 + i) * A.ld + h * AT_D + 4 * kg;
@@ -366,7 +419,7 @@ __device__ __forceinline__ float fa_fwd_body(const FaArgs &A, FaSmem &sm, int bh
         for (int d = 0; d < AT_D / 16; ++d) {
             const f32x4v ov = oacc[d] * osc;
             *reinterpret_cast<f32x4v *>(orow + 16 * d) = ov;
-            am = fmaxf(am, fmaxf(fmaxf(lvt_absf(ov[0]), lvt_absf(ov[1])), fmaxf(lvt_absf(ov[2]), lvt_absf(ov[3]))));
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(ov[0]), fabsf(ov[1])), fmaxf(fabsf(ov[2]), fabsf(ov[3]))));
         }
     }
     if (kg == 0) {
@@ -380,6 +433,9 @@ __device__ __forceinline__ float fa_fwd_body(const FaArgs &A, FaSmem &sm, int bh
 template <int BT, int BH, int BW, int MASKED>
 __global__ __launch_bounds__(512, 1) void lvt_attn_fwd_flash_kernel(const FaArgs A, float *__restrict__ o_amax) {
     __shared__ __attribute__((aligned(16))) FaSmem sm;
+    // the two waves of a SIMD (w, w + 4) run the same MFMA -> VALU -> MFMA sequence between the same barriers: a static
+    // priority for one of them staggers the pair, so that one wave's softmax / staging VALU runs beside the other's MFMAs
+    if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);
     float am;
     if (MASKED) {        // one workgroup = both query halves of a (sample, head): 8 + 4 key chunks
         am = fa_fwd_body<BT, BH, BW, MASKED, 8>(A, sm, blockIdx.x, 1);
@@ -412,58 +468,39 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
     const float *kbase = A.k + row0 * A.ld + h * AT_D, *vbase = A.v + row0 * A.ld + h * AT_D;
     constexpr int NIT = 2 * NCH;                                     // pass 1: chunks 0 .. NCH-1, pass 2: the same again
 
-    if (tid < 48) (&sm.emax[0][0])[tid] = 0u;
-    if (tid < 2 * BH - 1) sm.dhs[tid] = A.dh[h * (2 * BH - 1) + tid];
+    if (tid < 2 * BH - 1) sm.dhs[tid] = A.dh[h * (2 * BH - 1) + tid] * FA_LOG2E;
     float *mine = sm.R + (il * 4 + kg) * NR;                          // this lane's class sums: [t index | h slot | register]
 #pragma unroll
     for (int x = 0; x < NR; ++x) mine[x] = 0.f;
-    G4 g0;                             // ONE register set here (two made the kernel spill): item t + 1 is loaded during step t
+    G4 g0;                             // one register set: item t + 1 is split + stored during step t, item t + 2 loaded right after
     auto load_item = [&](int t, G4 &gg) {
         const int c = t < NCH ? t : t - NCH;
         fa_load(gg, kbase + (long long)(32 * c) * A.ld, vbase + (long long)(32 * c) * A.ld, A.ld, tid);
     };
+    load_item(0, g0);
     f16x8 qb[4][2], dob[4][2];
     float qinv, doinv;
-    fa_stage128<int>(A.q + (row0 + qhalf * 128) * A.ld + h * AT_D, A.ld, sm.ring[0], sm.ring[1], sm.rs_inv[0], sm.rs_inv[1], tid);
-    __syncthreads();
-    {
-        const unsigned short *qs = sm.ring[il >> 6];
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) qb[s][pl] = fa_rowfrag(qs, pl, il & 63, s, kg);
-        qinv = sm.rs_inv[il >> 6][il & 63];
-    }
-    __syncthreads();
-    fa_stage128<int>(A.d_o + (row0 + qhalf * 128) * A.ld + h * AT_D, A.ld, sm.ring[0], sm.ring[1], sm.rs_inv[0], sm.rs_inv[1], tid);
-    load_item(0, g0);
-    __syncthreads();
-    {
-        const unsigned short *qs = sm.ring[il >> 6];
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) dob[s][pl] = fa_rowfrag(qs, pl, il & 63, s, kg);
-        doinv = sm.rs_inv[il >> 6][il & 63];
-    }
+    fa_load_bfrags(A.q + (row0 + i) * A.ld + h * AT_D, kg, qb, qinv);
+    fa_load_bfrags(A.d_o + (row0 + i) * A.ld + h * AT_D, kg, dob, doinv);
     const long long si = ((long long)b * A.H + h) * AT_S + i;
     const float m_i = A.m[si], linv = A.l[si];
     const int wi = i % BW, hi = (i / BW) % BH, ti = i / (BW * BH);
-    float bt_[BT], bw_[4];
+    float bt_[BT];
+    f32x4v bw4;
 #pragma unroll
-    for (int x = 0; x < BT; ++x) bt_[x] = A.dt[h * (2 * BT - 1) + ti - x + BT - 1];
+    for (int x = 0; x < BT; ++x) bt_[x] = A.dt[h * (2 * BT - 1) + ti - x + BT - 1] * FA_LOG2E;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bw_[r] = A.dw[h * (2 * BW - 1) + wi - GE::wj(r, kg) + BW - 1];
-    // dh[hi - hj(x, kg) + BH - 1] of h slot x, read from LDS per tile (a 16-entry per-lane table would cost 16 registers)
+    for (int r = 0; r < 4; ++r) bw4[r] = A.dw[h * (2 * BW - 1) + wi - GE::wj(r, kg) + BW - 1] * FA_LOG2E;
     const float *dhl = sm.dhs + (hi + BH - 1 - (BW == 16 ? 0 : (kg >> 1)));
     constexpr int HSTEP = BW == 16 ? 1 : 2;
-    __syncthreads();
-    fa_park(g0, sm.ring[0], sm.rs_inv[0], sm.emax[0], tid);
+    const float qc = qinv * A.c1;
+    fa_park(g0, sm.ring[0], sm.rs_inv[0], tid);
+    load_item(1, g0);
     __syncthreads();
 
     float delta = 0.f, gmax = 0.f;
-    int E_K = FA_EMIN;
-    float sgf = 0.f, skf = 0.f;                                       // pass 2: scale of g (from the bound G_i), 2^(141 - E_K)
+    float kmax = fa_u2f((unsigned)(FA_EMIN - 14) << 23);             // largest 2^(e - 14) over the K rows (pass 1)
+    float wsc = 0.f, dl = 0.f;                                        // pass 2: (scale of g from its bound) / kmax; delta / l
     int ebG = FA_EMIN;
     f32x4v qacc[AT_D / 16];
 #pragma unroll
@@ -480,19 +517,30 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
         constexpr bool PASS2 = t >= NCH;
         const unsigned short *cur = sm.ring[t & 1];
         const float *cinv = sm.rs_inv[t & 1];
-        if constexpr (t + 1 < NIT) load_item(t + 1, g0);
-        if constexpr (t == NCH) {                                     // between the passes: delta and the scale bound of g
-            delta = fa_kg_sum(delta);
+        constexpr bool PARK = t + 1 < NIT;
+        unsigned short *nslot = sm.ring[(t + 1) & 1];
+        float *ninv = sm.rs_inv[(t + 1) & 1];
+        if constexpr (t == NCH) {                                     // between the passes: delta, the scale bound of g, the bounds for B
+            delta = fa_kg_sum(delta) * linv;
             gmax = fa_kg_max(gmax);
-            ebG = fa_ebits(gmax + fabsf(delta));
-            sgf = fa_u2f((unsigned)(268 - ebG) << 23);
-            skf = fa_u2f((unsigned)(268 - E_K) << 23);
+            kmax = fa_kg_max(kmax);
+            const float G = gmax + fabsf(delta);                      // >= |p (dP - delta)|: p <= 1
+            ebG = fa_ebits(G);
+            wsc = fa_u2f((unsigned)(268 - ebG) << 23) * __builtin_amdgcn_rcpf(kmax);
+            dl = delta * linv;
+            // per-workgroup bounds for kernel B: max 2^(e - 14) over the dO rows, max of G_i 2^(e_i - 14) over the q rows
+            float r0 = doinv, r1 = G * qinv;
+#pragma unroll
+            for (int dd = 32; dd > 0; dd >>= 1) { r0 = fmaxf(r0, __shfl_xor(r0, dd, 64)); r1 = fmaxf(r1, __shfl_xor(r1, dd, 64)); }
+            if (lane == 0) { sm.red[wave] = r0; sm.red[8 + wave] = r1; }
         }
-        // ---- S^T = K Q^T, dP^T = V dO^T for the 32 keys of this chunk ----
+        // ---- S^T = K Q^T, dP^T = V dO^T for the 32 keys of this chunk; the split + store of item t + 1 in four pieces between
+        // the MFMAs of the four k steps ----
         f32x4v st[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
         f32x4v dp[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        int eb0 = 0, eb1 = 0;
+        static_for<4>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
             f16x8 a[2][2], av[2][2];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -507,8 +555,21 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
             for (int kt = 0; kt < 2; ++kt) { st[kt] = fa_mfma(a[kt][0], qb[s][1], st[kt]); dp[kt] = fa_mfma(av[kt][0], dob[s][1], dp[kt]); }
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) { st[kt] = fa_mfma(a[kt][0], qb[s][0], st[kt]); dp[kt] = fa_mfma(av[kt][0], dob[s][0], dp[kt]); }
-        }
-        if constexpr (!PASS2) { const int e = (int)sm.emax[t][0]; E_K = e > E_K ? e : E_K; }
+            if constexpr (PARK) {
+                if constexpr (s == 0) eb0 = fa_row_scale(g0.v[0], g0.v[1]);
+                if constexpr (s == 1) fa_row_store(g0.v[0], g0.v[1], eb0, nslot, ninv, tid >> 4, tid & 15);
+                if constexpr (s == 2) eb1 = fa_row_scale(g0.v[2], g0.v[3]);
+                if constexpr (s == 3) fa_row_store(g0.v[2], g0.v[3], eb1, nslot, ninv, 32 + (tid >> 4), tid & 15);
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+                for (int e = 0; e < 12; ++e) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (s & 1) ? 3 : 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        if constexpr (t + 2 < NIT) load_item(t + 2, g0);
         float w[8];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -516,28 +577,33 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
             const f32x4v kinv = *reinterpret_cast<const f32x4v *>(cinv + 16 * kt + 4 * kg);
             const f32x4v vinv = *reinterpret_cast<const f32x4v *>(cinv + 32 + 16 * kt + 4 * kg);
             const float bth = bt_[T / HP] + dhl[-HSTEP * (T % HP)];
+            if constexpr (!PASS2) kmax = fmaxf(kmax, fa_max4(kinv));
+            const f32x4v qk = kinv * qc, bm = bw4 + bth;
+            const f32x4v dv = vinv * (PASS2 ? doinv * linv : doinv), kw = kinv * wsc;
             float gt = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float x = (st[kt][r] * (kinv[r] * qinv)) * A.inv_temper + (bth + bw_[r]);
-                if (MASKED && 16 * T + 4 * kg + r > i) x = A.fill;
-                const float p = __expf(x - m_i) * linv;
-                const float dpv = dp[kt][r] * (vinv[r] * doinv);
+                float x = fa_score(st[kt][r], qk[r], bm[r]);
+                if (MASKED && 16 * T + 4 * kg + r > i) x = A.fill2;
+                // (x - m as its own operation: folding m into the bias rounds every score at the size of m before the
+                // subtraction -- dq of the heavy-tailed accuracy class went from 1.0x to 3.4x the fp32 evaluation's error)
+                const float ex = __builtin_amdgcn_exp2f(x - m_i);     // p = ex linv
                 if constexpr (!PASS2) {
-                    delta = fmaf(p, dpv, delta);
-                    gmax = fmaxf(gmax, lvt_absf(dpv));
+                    const float dpv = dp[kt][r] * dv[r];
+                    delta = fmaf(ex, dpv, delta);
+                    gmax = fmaxf(gmax, fabsf(dpv));
                 } else {
-                    const float g = p * (dpv - delta);
+                    const float g = ex * fmaf(dp[kt][r], dv[r], -dl);  // p (dP - delta)
                     gt += g;
                     rsw[r] += g;
-                    w[4 * kt + r] = g * ((kinv[r] * skf) * sgf);
+                    w[4 * kt + r] = g * kw[r];
                 }
             }
             if constexpr (PASS2) { rst[T / HP] += gt; mine[BT + T % HP] += gt; }
         }
         if constexpr (PASS2) {
             f16x8 wbh, wbl;
-            fa_split8(w, 1.f, wbh, wbl);
+            fa_split8(w, wbh, wbl);
             // ---- dQ^T += K^T g^T ----
 #pragma unroll
             for (int dq_ = 0; dq_ < AT_D / 32; ++dq_) {
@@ -554,11 +620,10 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
                 for (int dd = 0; dd < 2; ++dd) qacc[2 * dq_ + dd] = fa_mfma(a[dd][0], wbh, qacc[2 * dq_ + dd]);
             }
         }
-        if constexpr (t + 1 < NIT) fa_park(g0, sm.ring[(t + 1) & 1], sm.rs_inv[(t + 1) & 1], sm.emax[t + 1], tid);
         __syncthreads();
     });
-    // dq = acc * inv_temper * 2^(E_K - 141) * 2^(ebG - 141): two factors so that neither leaves the normal range
-    const float f1 = fa_exp_field(E_K - 14), f2 = fa_exp_field(ebG - 14) * A.inv_temper;
+    // acc = sum_j g K 2^(14 - E_K) 2^(141 - ebG): dq = acc inv_temper kmax 2^(ebG - 141)   (kmax = 2^(E_K - 14), E_K unbiased)
+    const float f1 = kmax, f2 = fa_exp_field(ebG - 14) * A.inv_temper;
     float am = 0.f;
     {
         float *qrow = A.dq + (row0 + i) * A.ld + h * AT_D + 4 * kg;
@@ -566,10 +631,17 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
         for (int d = 0; d < AT_D / 16; ++d) {
             const f32x4v ov = (qacc[d] * f1) * f2;
             *reinterpret_cast<f32x4v *>(qrow + 16 * d) = ov;
-            am = fmaxf(am, fmaxf(fmaxf(lvt_absf(ov[0]), lvt_absf(ov[1])), fmaxf(lvt_absf(ov[2]), lvt_absf(ov[3]))));
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(ov[0]), fabsf(ov[1])), fmaxf(fabsf(ov[2]), fabsf(ov[3]))));
         }
     }
     if (kg == 0) A.delta[si] = delta;
+    if (tid == 0) {
+        float r0 = sm.red[0], r1 = sm.red[8];
+#pragma unroll
+        for (int x = 1; x < 8; ++x) { r0 = fmaxf(r0, sm.red[x]); r1 = fmaxf(r1, sm.red[8 + x]); }
+        A.scal[(bh_ * 2 + qhalf) * 2] = r0;
+        A.scal[(bh_ * 2 + qhalf) * 2 + 1] = r1;
+    }
     // ---- bias-bank gradient of this (sample, head, query half): two fixed-order stages through LDS (attention_pipe.hip) ----
     float *R = sm.R;                                                  // [128 queries][4 kg][NR]
     float *R2 = reinterpret_cast<float *>(sm.ring[0]);                // [8 parts][NB]
@@ -619,8 +691,9 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
 template <int BT, int BH, int BW, int MASKED>
 __global__ __launch_bounds__(512, 1) void lvt_attn_bwd_flash_a_kernel(const FaArgs A, float *__restrict__ d_amax) {
     __shared__ __attribute__((aligned(16))) FaSmemA<BT + Geo16<BH, BW>::HP + 4> sm;
+    if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);           // (see the forward kernel)
     float am;
-    if (MASKED) {
+    if (MASKED) {        // one workgroup = both query halves of a (sample, head): 8 + 4 key chunks (as separate workgroups: 219 us against 182)
         am = fa_bwd_a_body<BT, BH, BW, MASKED, 8>(A, sm, blockIdx.x, 1);
         __syncthreads();
         am = fmaxf(am, fa_bwd_a_body<BT, BH, BW, MASKED, 4>(A, sm, fa_opaque(blockIdx.x), 0));
@@ -634,8 +707,24 @@ __global__ __launch_bounds__(512, 1) void lvt_attn_bwd_flash_a_kernel(const FaAr
 }
 
 // ===========================================================================================================================
-// backward B: dK, dV (key-stationary)
+// backward B: dK, dV (key-stationary): one wave = 16 keys (K fragments in registers, the workgroup's 128 V rows resident in
+// LDS), 32-query chunks of Q | dO through the two-slot ring.  Per step: S = Q K^T and dP = dO V^T (48 MFMAs, the split +
+// store of the next item spread between them), the element-wise work (scores, p, g, the two B operands), then dV^T += dO^T P
+// and dK^T += Q^T g (48 MFMAs on transposed fragments).
+// (A four-wave form -- one wave per SIMD with 512 registers, K and V fragments in registers, three slots, chunk t + 1's score
+// products software-pipelined beside chunk t's element-wise work -- was built and measured: 241 us against 178 for this form.
+// With one workgroup per CU its eight rounds of prologues are exposed, and a single in-order wave overlaps its own VALU and
+// MFMA work far less than the instruction mix suggests: timing builds put the element-wise work at 91 us, the staging
+// arithmetic at 51, all MFMAs at 59 and the bare loads / fragment reads / barriers at 72; profiles/r05_attn_flash_b4_ablation.txt.)
 // ===========================================================================================================================
+struct FaSmemB {
+    unsigned short ring[2][FA_SLOT];
+    unsigned short vres[2][FA_SLOT];      // the workgroup's 128 V rows, resident
+    float rs_inv[2][80];
+    float vinv[2][80];
+    float dhs[32];
+};
+
 template <int BT, int BH, int BW, int MASKED, int C0, int NCH>
 __device__ __forceinline__ float fa_bwd_b_body(const FaArgs &A, FaSmemB &sm, int bh_, int khalf) {
     using GE = Geo16<BH, BW>;
@@ -649,51 +738,57 @@ __device__ __forceinline__ float fa_bwd_b_body(const FaArgs &A, FaSmemB &sm, int
     const long long sb = ((long long)b * A.H + h) * AT_S;
     constexpr int NIT = NCH;
 
-    if (tid < 32) (&sm.emax[0][0])[tid] = 0u;
-    if (tid < 2 * BH - 1) sm.dhs[tid] = A.dh[h * (2 * BH - 1) + tid];
-    G4 g0;                             // one register set (see backward A)
+    if (tid < 2 * BH - 1) sm.dhs[tid] = A.dh[h * (2 * BH - 1) + tid] * FA_LOG2E;
+    G4 g0;                             // one register set: item t + 1 is split + stored during step t, item t + 2 loaded right after
     auto load_item = [&](int t, G4 &gg) {
         fa_load(gg, qbase + (long long)(32 * (C0 + t)) * A.ld, dobase + (long long)(32 * (C0 + t)) * A.ld, A.ld, tid);
     };
-    fa_stage128<FaSmemB>(A.k + (row0 + khalf * 128) * A.ld + h * AT_D, A.ld, sm.ring[0], sm.ring[1], sm.rs_inv[0], sm.rs_inv[1], tid);
-    fa_stage128<FaSmemB>(A.v + (row0 + khalf * 128) * A.ld + h * AT_D, A.ld, sm.vres[0], sm.vres[1], sm.vinv[0], sm.vinv[1], tid);
-    load_item(0, g0);
-    __syncthreads();
-    f16x8 kb[4][2];
-    float kinv, vinv;
-    {
-        const unsigned short *ks = sm.ring[jl >> 6];
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) kb[s][pl] = fa_rowfrag(ks, pl, jl & 63, s, kg);
-        kinv = sm.rs_inv[jl >> 6][jl & 63];
-        vinv = sm.vinv[jl >> 6][jl & 63];
+    {                                   // the workgroup's 128 V rows -> LDS, resident
+        const float *rows = A.v + (row0 + khalf * 128) * A.ld + h * AT_D;
+        G4 a, bq;
+        fa_load(a, rows, rows + 32 * A.ld, A.ld, tid);
+        fa_load(bq, rows + 64 * A.ld, rows + 96 * A.ld, A.ld, tid);
+        fa_park(a, sm.vres[0], sm.vinv[0], tid);
+        fa_park(bq, sm.vres[1], sm.vinv[1], tid);
     }
+    load_item(0, g0);
+    f16x8 kb[4][2];
+    float kinv;
+    fa_load_bfrags(A.k + (row0 + j) * A.ld + h * AT_D, kg, kb, kinv);
+    // bounds from kernel A (both query halves): exponent of the dO rows, bound of g 2^(e_q - 14)
+    const float *sc = A.scal + (long long)bh_ * 4;
+    const float domax = fmaxf(sc[0], sc[2]), umax = fmaxf(sc[1], sc[3]);
+    const float srun = 32768.f * __builtin_amdgcn_rcpf(domax);        // 2^15 2^(141 - E)
+    const int zb = fa_ebits(umax);
+    const float zrun = fa_u2f((unsigned)(268 - zb) << 23);
     const unsigned short *vs = sm.vres[jl >> 6];
     const int wj = j % BW, hj = (j / BW) % BH, tj = j / (BW * BH);
-    float bt_[BT], bw_[4];                // indexed by the QUERY's t index and register (Geo16 of the varying token)
+    float bt_[BT];                        // indexed by the QUERY's t index (Geo16 of the varying token)
+    f32x4v bw4;
 #pragma unroll
-    for (int x = 0; x < BT; ++x) bt_[x] = A.dt[h * (2 * BT - 1) + x - tj + BT - 1];
+    for (int x = 0; x < BT; ++x) bt_[x] = A.dt[h * (2 * BT - 1) + x - tj + BT - 1] * FA_LOG2E;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bw_[r] = A.dw[h * (2 * BW - 1) + GE::wj(r, kg) - wj + BW - 1];
+    for (int r = 0; r < 4; ++r) bw4[r] = A.dw[h * (2 * BW - 1) + GE::wj(r, kg) - wj + BW - 1] * FA_LOG2E;
     const float *dhl = sm.dhs + (BH - 1 - hj + (BW == 16 ? 0 : (kg >> 1)));      // dh[hj(x, kg) - hj + BH - 1] of the query's h slot x
     constexpr int HSTEP = BW == 16 ? 1 : 2;
+    const float kc = kinv * A.c1;
+    fa_park(g0, sm.ring[0], sm.rs_inv[0], tid);
+    if (NIT > 1) load_item(1, g0);
     __syncthreads();
-    fa_park(g0, sm.ring[0], sm.rs_inv[0], sm.emax[0], tid);
-    __syncthreads();
+    const float vinv = sm.vinv[jl >> 6][jl & 63];
 
     f32x4v accv[AT_D / 16], acck[AT_D / 16];
 #pragma unroll
     for (int d = 0; d < AT_D / 16; ++d) { accv[d] = f32x4v{0.f, 0.f, 0.f, 0.f}; acck[d] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
-    int E_run = FA_EMIN, Z_run = FA_EMIN;
 
     static_for<NIT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         constexpr int c = C0 + t;                                     // 32-query chunk of the (sample, head)
+        constexpr bool PARK = t + 1 < NIT;
         const unsigned short *cur = sm.ring[t & 1];
         const float *cinv = sm.rs_inv[t & 1];
-        if constexpr (t + 1 < NIT) load_item(t + 1, g0);
+        unsigned short *nslot = sm.ring[(t + 1) & 1];
+        float *ninv = sm.rs_inv[(t + 1) & 1];
         f32x4v m4[2], l4[2], d4[2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
@@ -702,11 +797,13 @@ __device__ __forceinline__ float fa_bwd_b_body(const FaArgs &A, FaSmemB &sm, int
             l4[qt] = *reinterpret_cast<const f32x4v *>(A.l + o);
             d4[qt] = *reinterpret_cast<const f32x4v *>(A.delta + o);
         }
-        // ---- S = Q K^T, dP = dO V^T for the 32 queries of this chunk (rows) x the wave's 16 keys (columns) ----
+        // ---- S = Q K^T, dP = dO V^T for the 32 queries of this chunk (rows) x the wave's 16 keys (columns); the split + store
+        // of item t + 1 in four pieces between the MFMAs of the four k steps ----
         f32x4v st[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
         f32x4v dp[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        int eb0 = 0, eb1 = 0;
+        static_for<4>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
             f16x8 aq[2][2], ad[2][2], vb[2];
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) vb[pl] = fa_rowfrag(vs, pl, jl & 63, s, kg);
@@ -723,46 +820,46 @@ __device__ __forceinline__ float fa_bwd_b_body(const FaArgs &A, FaSmemB &sm, int
             for (int qt = 0; qt < 2; ++qt) { st[qt] = fa_mfma(aq[qt][0], kb[s][1], st[qt]); dp[qt] = fa_mfma(ad[qt][0], vb[1], dp[qt]); }
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) { st[qt] = fa_mfma(aq[qt][0], kb[s][0], st[qt]); dp[qt] = fa_mfma(ad[qt][0], vb[0], dp[qt]); }
-        }
+            if constexpr (PARK) {
+                if constexpr (s == 0) eb0 = fa_row_scale(g0.v[0], g0.v[1]);
+                if constexpr (s == 1) fa_row_store(g0.v[0], g0.v[1], eb0, nslot, ninv, tid >> 4, tid & 15);
+                if constexpr (s == 2) eb1 = fa_row_scale(g0.v[2], g0.v[3]);
+                if constexpr (s == 3) fa_row_store(g0.v[2], g0.v[3], eb1, nslot, ninv, 32 + (tid >> 4), tid & 15);
+                // pin: this step's fragment reads, then the MFMAs with the staging arithmetic between them
+                __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+#pragma unroll
+                for (int e = 0; e < 12; ++e) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (s & 1) ? 3 : 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        if constexpr (t + 2 < NIT) load_item(t + 2, g0);
+        // ---- element-wise: per tile the products of the row / column factors, per element five operations + the mask ----
         float pw[8], u[8];
-        float umax = 0.f;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const int T = 2 * c + qt;                                 // 16-query tile of the (sample, head)
             const f32x4v qinv = *reinterpret_cast<const f32x4v *>(cinv + 16 * qt + 4 * kg);
             const f32x4v doinv = *reinterpret_cast<const f32x4v *>(cinv + 32 + 16 * qt + 4 * kg);
             const float bth = bt_[T / HP] + dhl[HSTEP * (T % HP)];
+            const f32x4v qk = qinv * kc, bm = bw4 + bth;
+            const f32x4v lds = l4[qt] * (doinv * srun);               // P^T dO operand: p 2^(e_i - 14) 2^15 2^(141 - E) = exp lds
+            const f32x4v qzl = l4[qt] * (qinv * zrun);                // g^T Q operand: g 2^(e_i - 14) 2^(141 - zb) = exp (dp dvq - dq)
+            const f32x4v dvq = (doinv * vinv) * qzl, dq_ = d4[qt] * qzl;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float x = (st[qt][r] * (qinv[r] * kinv)) * A.inv_temper + (bth + bw_[r]);
-                if (MASKED && j > 16 * T + 4 * kg + r) x = A.fill;
-                const float p = __expf(x - m4[qt][r]) * l4[qt][r];
-                const float dpv = dp[qt][r] * (doinv[r] * vinv);
-                const float g = p * (dpv - d4[qt][r]);
-                pw[4 * qt + r] = p * doinv[r];
-                u[4 * qt + r] = g * qinv[r];
-                umax = fmaxf(umax, lvt_absf(u[4 * qt + r]));
+                float x = fa_score(st[qt][r], qk[r], bm[r]);
+                if (MASKED && j > 16 * T + 4 * kg + r) x = A.fill2;
+                const float ex = __builtin_amdgcn_exp2f(x - m4[qt][r]);
+                pw[4 * qt + r] = ex * lds[r];
+                u[4 * qt + r] = ex * fmaf(dp[qt][r], dvq[r], -dq_[r]);
             }
         }
-        // online scales: P^T dO over queries whose rows carry 2^(14 - e_i) (chunk max exponent E), g^T Q likewise (column max Z)
-        const int E_c = (int)sm.emax[t][1];
-        const int E_new = E_c > E_run ? E_c : E_run;
-        const float fv = fa_pow2_neg(E_run - E_new);
-        E_run = E_new;
-        const float srun = fa_u2f((unsigned)(268 - E_new) << 23);
-        umax = fa_kg_max(umax);
-        const int zb = fa_ebits(umax);
-        const int Z_new = zb > Z_run ? zb : Z_run;
-        const float fk = fa_pow2_neg(Z_run - Z_new);
-        Z_run = Z_new;
-        const float zrun = fa_u2f((unsigned)(268 - Z_new) << 23);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { pw[e] *= srun; u[e] *= zrun; }
         f16x8 pbh, pbl, ubh, ubl;
-        fa_split8(pw, 32768.f, pbh, pbl);
-        fa_split8(u, 1.f, ubh, ubl);
-#pragma unroll
-        for (int d = 0; d < AT_D / 16; ++d) { accv[d] *= fv; acck[d] *= fk; }
+        fa_split8(pw, pbh, pbl);
+        fa_split8(u, ubh, ubl);
         // ---- dV^T += dO^T P, dK^T += Q^T g ----
 #pragma unroll
         for (int d = 0; d < AT_D / 16; ++d) {
@@ -773,10 +870,10 @@ __device__ __forceinline__ float fa_bwd_b_body(const FaArgs &A, FaSmemB &sm, int
             accv[d] = fa_mfma(ao[0], pbl, accv[d]); acck[d] = fa_mfma(aq[0], ubl, acck[d]);
             accv[d] = fa_mfma(ao[0], pbh, accv[d]); acck[d] = fa_mfma(aq[0], ubh, acck[d]);
         }
-        if constexpr (t + 1 < NIT) fa_park(g0, sm.ring[(t + 1) & 1], sm.rs_inv[(t + 1) & 1], sm.emax[t + 1], tid);
         __syncthreads();
     });
-    const float fvs = fa_exp_field(E_run - 29), fks = fa_exp_field(Z_run - 14) * A.inv_temper;
+    // accv = sum_i p dO 2^15 2^(141 - E) = sum / (srun): dv = accv domax / 2^15;  acck = sum_i g Q 2^(141 - zb): dk = acck inv_temper 2^(zb - 141)
+    const float fvs = domax * (1.f / 32768.f), fks = fa_exp_field(zb - 14) * A.inv_temper;
     float am = 0.f;
     {
         float *vrow = A.dv + (row0 + j) * A.ld + h * AT_D + 4 * kg, *krow = A.dk + (row0 + j) * A.ld + h * AT_D + 4 * kg;
@@ -786,7 +883,7 @@ __device__ __forceinline__ float fa_bwd_b_body(const FaArgs &A, FaSmemB &sm, int
             *reinterpret_cast<f32x4v *>(vrow + 16 * d) = ov;
             *reinterpret_cast<f32x4v *>(krow + 16 * d) = ok;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) am = fmaxf(am, fmaxf(lvt_absf(ov[e]), lvt_absf(ok[e])));
+            for (int e = 0; e < 4; ++e) am = fmaxf(am, fmaxf(fabsf(ov[e]), fabsf(ok[e])));
         }
     }
     return am;
@@ -795,11 +892,12 @@ __device__ __forceinline__ float fa_bwd_b_body(const FaArgs &A, FaSmemB &sm, int
 template <int BT, int BH, int BW, int MASKED>
 __global__ __launch_bounds__(512, 1) void lvt_attn_bwd_flash_b_kernel(const FaArgs A, float *__restrict__ d_amax) {
     __shared__ __attribute__((aligned(16))) FaSmemB sm;
+    if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);           // (see the forward kernel)
     float am;
-    if (MASKED) {        // key half 0 meets all eight query chunks, key half 1 the last four
-        am = fa_bwd_b_body<BT, BH, BW, MASKED, 0, 8>(A, sm, blockIdx.x, 0);
-        __syncthreads();
-        am = fmaxf(am, fa_bwd_b_body<BT, BH, BW, MASKED, 4, 4>(A, sm, fa_opaque(blockIdx.x), 1));
+    if (MASKED) {        // key half 0 meets all eight query chunks, key half 1 the last four: separate workgroups (one workgroup
+                         // running both halves back to back spilled ~95 registers inside its step loops)
+        if (fa_half(blockIdx.x) == 0) am = fa_bwd_b_body<BT, BH, BW, MASKED, 0, 8>(A, sm, fa_pair(blockIdx.x), 0);
+        else am = fa_bwd_b_body<BT, BH, BW, MASKED, 4, 4>(A, sm, fa_pair(blockIdx.x), 1);
     } else {
         am = fa_bwd_b_body<BT, BH, BW, MASKED, 0, 8>(A, sm, fa_pair(blockIdx.x), fa_half(blockIdx.x));
     }
@@ -843,7 +941,7 @@ extern "C" int lvt_attn_fwd_flash(const float *q, const float *k, const float *v
     LVT_REQUIRE(lvt_aligned16(q) && lvt_aligned16(k) && lvt_aligned16(v) && lvt_aligned16(o) && lvt_aligned16(stats) && ld % 4 == 0 &&
                 ld >= (long long)H * da, "attn_fwd_flash: alignment / row stride");
     FaArgs A = {};
-    A.q = q; A.k = k; A.v = v; A.ld = ld; A.H = H; A.inv_temper = 1.f / temper; A.fill = fill;
+    A.q = q; A.k = k; A.v = v; A.ld = ld; A.H = H; A.inv_temper = 1.f / temper; A.c1 = FA_LOG2E / temper; A.fill2 = fill * FA_LOG2E;
     A.dt = dt; A.dh = dh; A.dw = dw; A.o = o; A.m = stats; A.l = stats + (size_t)B * H * S;
     const dim3 grid((unsigned)(B * H * (masked ? 1 : 2))), blk(512);
     hipStream_t s = (hipStream_t)stream;
@@ -860,7 +958,7 @@ extern "C" int lvt_attn_fwd_flash(const float *q, const float *k, const float *v
 
 extern "C" size_t lvt_attn_bwd_flash_workspace_bytes(int B, int H, int S, int bt, int bh, int bw) {
     const size_t nb = (size_t)(2 * bt - 1) + (2 * bh - 1) + (2 * bw - 1);
-    return (size_t)B * H * S * sizeof(float) + (size_t)B * H * 2 * nb * sizeof(float);
+    return (size_t)B * H * S * sizeof(float) + (size_t)B * H * 4 * sizeof(float) + (size_t)B * H * 2 * nb * sizeof(float);
 }
 
 extern "C" int lvt_attn_bwd_flash(const float *q, const float *k, const float *v, const float *d_o, long long ld, const float *stats,
@@ -877,13 +975,15 @@ extern "C" int lvt_attn_bwd_flash(const float *q, const float *k, const float *v
         return LVT_EWORKSPACE;
     }
     FaArgs A = {};
-    A.q = q; A.k = k; A.v = v; A.d_o = d_o; A.ld = ld; A.H = H; A.inv_temper = 1.f / temper; A.fill = fill;
+    A.q = q; A.k = k; A.v = v; A.d_o = d_o; A.ld = ld; A.H = H; A.inv_temper = 1.f / temper; A.c1 = FA_LOG2E / temper; A.fill2 = fill * FA_LOG2E;
     A.dt = dt; A.dh = dh; A.dw = dw; A.m = const_cast<float *>(stats); A.l = const_cast<float *>(stats) + (size_t)B * H * S;
     A.dq = dq; A.dk = dk; A.dv = dv;
     A.delta = (float *)workspace;
-    A.bank_partial = A.delta + (size_t)B * H * S;
+    A.scal = A.delta + (size_t)B * H * S;
+    A.bank_partial = A.scal + (size_t)B * H * 4;
     const int nt = 2 * bt - 1, nh = 2 * bh - 1, nw = 2 * bw - 1, nb = nt + nh + nw;
     const dim3 grid((unsigned)(B * H * (masked ? 1 : 2))), blk(512);
+    const dim3 gridb((unsigned)(B * H * 2));                              // kernel B: the two key halves are separate workgroups
     hipStream_t s = (hipStream_t)stream;
 #define LVT_X(BT, BH, BW)                                                                                         \
     if (bt == BT && bh == BH && bw == BW) {                                                                       \
@@ -895,7 +995,7 @@ extern "C" int lvt_attn_bwd_flash(const float *q, const float *k, const float *v
     LVT_CHECK_LAUNCH("lvt_attn_bwd_flash_a_kernel");
 #define LVT_X(BT, BH, BW)                                                                                         \
     if (bt == BT && bh == BH && bw == BW) {                                                                       \
-        if (masked) hipLaunchKernelGGL((lvt_attn_bwd_flash_b_kernel<BT, BH, BW, 1>), grid, blk, 0, s, A, d_amax); \
+        if (masked) hipLaunchKernelGGL((lvt_attn_bwd_flash_b_kernel<BT, BH, BW, 1>), gridb, blk, 0, s, A, d_amax); \
         else hipLaunchKernelGGL((lvt_attn_bwd_flash_b_kernel<BT, BH, BW, 0>), grid, blk, 0, s, A, d_amax);        \
     }
     LVT_FA_GEOMS(LVT_X)

@@ -35,8 +35,8 @@ def _reference(q, k, v, go, banks, blk, masked, dtype=torch.float64):
     P = torch.softmax(sc, -1)
     o = (P @ vh).permute(0, 2, 1, 3).reshape(B * S, H * DA)
     o.backward(go.to(dtype))
-    m = sc.max(-1).values
-    linv = 1.0 / torch.exp(sc - m[..., None]).sum(-1)
+    m = sc.max(-1).values * math.log2(math.e)          # the kernels keep the row max in log2 units
+    linv = 1.0 / torch.exp(sc - sc.max(-1, keepdim=True).values).sum(-1)
     return [o.detach(), m.detach().reshape(-1), linv.detach().reshape(-1)] + [t.grad for t in leaves] + [t.grad for t in bl]
 
 
