@@ -328,18 +328,26 @@ def _permute_cols(uw, d, ncols):
 class ChannelPredictor(nn.Module):
     def __init__(self, d, nc, nv, de, share_p=True, share_embeddings=False):
         super().__init__()
-        if share_p or share_embeddings:
-            raise NotImplementedError("SHARE_P / SHARE_EMBEDDINGS variants are not used by the shipped configs")
+        if share_embeddings:
+            raise NotImplementedError("the SHARE_EMBEDDINGS variant (videotransformer.py:124-125) is not used by the shipped configs")
         self.nc, self.nv, self.share_p, self.share_embeddings = nc, nv, share_p, share_embeddings
         self.layer_norm = nn.LayerNorm(d)
         self.U = nn.ModuleList([nn.Linear(d + k * nv, d, bias=True) for k in range(nc)])
         self.relu = nn.ReLU(inplace=True)
-        self.P = nn.ModuleList([nn.Linear(d, nv, bias=True) for _ in range(nc)])
+        if share_p:         # the reference's config default (defaults.py:50; videotransformer.py:121-123): ONE output layer for all channels
+            self.P = nn.Linear(d, nv, bias=True)
+        else:
+            self.P = nn.ModuleList([nn.Linear(d, nv, bias=True) for _ in range(nc)])
+
+    def _P(self, k):
+        return self.P if self.share_p else self.P[k]
 
     def _flat_params(self):
+        """(U_k.weight, U_k.bias, P_k.weight, P_k.bias) per channel; with a shared P the same two tensors appear nc times and
+        autograd adds up the nc gradients _ChannelPredictorFn returns for them."""
         flat = []
         for k in range(self.nc):
-            flat += [self.U[k].weight, self.U[k].bias, self.P[k].weight, self.P[k].bias]
+            flat += [self.U[k].weight, self.U[k].bias, self._P(k).weight, self._P(k).bias]
         return flat
 
     def logits_tokens(self, sl, yl_tok):
@@ -380,7 +388,7 @@ class ChannelPredictor(nn.Module):
         if forced_codes is None and uniforms is None:
             u = torch.rand(self.nc, b, device=rows.device)
         for k in range(self.nc):
-            uw, pw = self.U[k].weight, self.P[k].weight
+            uw, pw = self.U[k].weight, self._P(k).weight
             res = None
             if k > 0:
                 ut = cached[k] if cached is not None else _permute_cols(uw, d, k * self.nv)
@@ -391,7 +399,7 @@ class ChannelPredictor(nn.Module):
             G.gemm_small(y, uw, u_, b, d, d, ldb=uw.shape[1], flags=L.EPI_BIAS | L.EPI_RELU | (L.EPI_RESIDUAL if k else 0),
                          bias=self.U[k].bias, res=res, split_ws=split_ws)
             o = torch.empty(b, self.nv, dtype=torch.float32, device=y.device)
-            G.gemm_small(u_, pw, o, b, self.nv, d, flags=L.EPI_BIAS, bias=self.P[k].bias, split_ws=split_ws)
+            G.gemm_small(u_, pw, o, b, self.nv, d, flags=L.EPI_BIAS, bias=self._P(k).bias, split_ws=split_ws)
             if forced_codes is None:
                 # writes codes[:, k, 0] (element stride nc between samples)
                 if uniforms is not None:

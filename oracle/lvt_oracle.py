@@ -511,7 +511,8 @@ def vt_decoder(p, sl, zl, blocks):
 
 
 def channel_predictor_logits(p, sl, yl, nv=512):
-    """ChannelPredictor 'logits', SHARE_P False (videotransformer.py:139-160).
+    """ChannelPredictor 'logits' (videotransformer.py:139-160): per-channel output layers P.k (SHARE_P False) or, when the
+    parameter dict holds `ch_predictor.P.weight`, the ONE shared layer of SHARE_P True (:121-123,150-151).
     Returns list of nc tensors (b, nv, t, h, w)."""
     pre = "ch_predictor."
     b, d, t, h, w = yl.shape
@@ -523,7 +524,8 @@ def channel_predictor_logits(p, sl, yl, nv=512):
     for k in range(nc):
         inp = y if k == 0 else torch.cat((y, oh[:, :, :k * nv]), dim=2)
         u = F.linear(inp, p[pre + "U.%d.weight" % k], p[pre + "U.%d.bias" % k])
-        o = F.linear(torch.relu(u), p[pre + "P.%d.weight" % k], p[pre + "P.%d.bias" % k])
+        pk = "P." if (pre + "P.weight") in p else "P.%d." % k
+        o = F.linear(torch.relu(u), p[pre + pk + "weight"], p[pre + pk + "bias"])
         out.append(o.transpose(1, 2).contiguous().view(b, nv, t, h, w))
     return out
 

@@ -542,8 +542,36 @@ def golden_pins():
     save("g20_latent_paths", **g20)
 
 
+def golden_share_p():
+    """G21: ChannelPredictor with ONE shared output layer P (SHARE_P = True, the reference's config default:
+    vidgen/config/defaults.py:50, videotransformer.py:121-123,150-151): logits of all channels and the gradients of the
+    shared P (the sum over the channels), of U_2 and of the input, at reduced width (d = 128, nv = 64, nc = 3)."""
+    from vidgen.modeling.autoregressive.videotransformer import ChannelPredictor
+    SEED = 2121
+    d, nc, nv, de = 128, 3, 64, 32
+    cp = ChannelPredictor(d, nc, nv, de, share_p=True, share_embeddings=False)
+    shapes = {"layer_norm.weight": (d,), "layer_norm.bias": (d,), "P.weight": (nv, d), "P.bias": (nv,)}
+    for k in range(nc):
+        shapes["U.%d.weight" % k] = (d, d + k * nv)
+        shapes["U.%d.bias" % k] = (d,)
+    assert set(shapes) == set(cp.state_dict().keys())
+    params = seeded.seeded_params(shapes, SEED, "g21.")
+    load_into(cp, params)
+    sl = seeded.seeded_codes("g21.slice", (2, nc, 2, 8, 8), SEED, nv=nv)
+    yl = seeded.seeded_input("g21.yl", (2, d, 2, 8, 8), SEED, -2.0, 2.0).requires_grad_(True)
+    gys = [seeded.seeded_input("g21.gy%d" % k, (2, nv, 2, 8, 8), SEED, -1.0, 1.0) for k in range(nc)]
+    pred = cp(sl, yl, mode="logits")
+    sum((o * g).sum() for o, g in zip(pred, gys)).backward()
+    save("g21_share_p", seed=SEED, dims=np.array([d, nc, nv, de]), slice=sl, yl=yl,
+         **{"logits_%d" % k: pred[k] for k in range(nc)}, **{"gy_%d" % k: gys[k] for k in range(nc)},
+         grad_P_weight=cp.P.weight.grad, grad_P_bias=cp.P.bias.grad, grad_U2_weight=cp.U[2].weight.grad,
+         grad_U0_bias=cp.U[0].bias.grad, grad_yl=yl.grad, grad_ln_w=cp.layer_norm.weight.grad)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["vqvae", "vt", "variants", "pins"]
+    which = sys.argv[1:] or ["vqvae", "vt", "variants", "pins", "share_p"]
+    if "share_p" in which:
+        golden_share_p()
     if "pins" in which:
         golden_pins()
     if "vqvae" in which:

@@ -183,3 +183,34 @@ def test_kdvqvae_loss_grads_and_indices(golden):
     assert rel_err(z_e[:, ::8, ::2, ::2], g["z_e_slice"]) < 2e-5
     for i in range(4):
         assert rel_err(model.codebook.state_dict()["ve.%d.running_size" % i], g["new_ve.%d.running_size" % i]) < 1e-5
+
+
+def test_g21_share_p_channel_predictor(golden):
+    """SHARE_P = True -- the reference's CONFIG DEFAULT (vidgen/config/defaults.py:50): one output layer P for all channels
+    (videotransformer.py:121-123,150-151).  Logits of every channel and the gradients (the shared P's is the sum over the
+    channels) against the reference's own ChannelPredictor(share_p=True), fixture G21; state_dict keys as the reference's."""
+    import seeded
+    from lvt_amd.modeling.autoregressive.videotransformer import ChannelPredictor
+    g = golden("g21_share_p")
+    d, nc, nv, de = [int(x) for x in g["dims"]]
+    cp = ChannelPredictor(d, nc, nv, de, share_p=True, share_embeddings=False)
+    shapes = {k: tuple(v.shape) for k, v in cp.state_dict().items()}
+    assert "P.weight" in shapes and "P.bias" in shapes and not any(k.startswith("P.0") for k in shapes)
+    cp.load_state_dict(seeded.seeded_params(shapes, int(g["seed"]), "g21."))
+    cp = cp.to(DEV)
+    yl = g["yl"].to(DEV).requires_grad_(True)
+    pred = cp(g["slice"].to(DEV), yl, mode="logits")
+    sum((o * g["gy_%d" % k].to(DEV)).sum() for k, o in enumerate(pred)).backward()
+    for k in range(nc):
+        assert rel_err(pred[k], g["logits_%d" % k]) < 2e-5
+    assert rel_err(cp.P.weight.grad, g["grad_P_weight"]) < 1e-4
+    assert rel_err(cp.P.bias.grad, g["grad_P_bias"]) < 1e-4
+    assert rel_err(cp.U[2].weight.grad, g["grad_U2_weight"]) < 1e-4
+    assert rel_err(cp.U[0].bias.grad, g["grad_U0_bias"]) < 1e-4
+    assert rel_err(cp.layer_norm.weight.grad, g["grad_ln_w"]) < 1e-4
+    assert rel_err(yl.grad, g["grad_yl"]) < 1e-4
+    # incremental sampling goes through the same shared layer
+    with torch.no_grad():
+        codes, probs = cp.sample_from_rows(torch.randn(4, d, device=DEV), forced_codes=torch.zeros(4, nc, dtype=torch.int64),
+                                           return_probs=True)
+    assert tuple(probs.shape) == (4, nc, nv) and torch.isfinite(probs).all()

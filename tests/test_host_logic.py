@@ -316,3 +316,19 @@ def test_relu_decision_matching_helper_on_a_toy_network():
         assert_grads_match(wrong, run, ["w1", "w2"])
     with pytest.raises(AssertionError):
         assert_grads_match_decisions(wrong, masks, run, ["w1", "w2"])
+
+
+def test_channel_predictor_share_p_is_the_config_default_and_constructs():
+    """SHARE_P defaults to True in the reference's config (vidgen/config/defaults.py:50): a config that does not set it must
+    build, with ONE output layer whose state_dict keys are the reference's (`P.weight`, `P.bias`); SHARE_EMBEDDINGS stays a
+    documented error."""
+    from lvt_amd.config import get_cfg
+    from lvt_amd.modeling.autoregressive.videotransformer import ChannelPredictor
+    assert get_cfg().MODEL.AUTOREGRESSIVE.VT.SHARE_P is True
+    cp = ChannelPredictor(64, 3, 16, 8, share_p=True)
+    keys = set(cp.state_dict().keys())
+    assert {"P.weight", "P.bias", "U.2.weight", "layer_norm.bias"} <= keys and not any(k.startswith("P.0") for k in keys)
+    assert tuple(cp.P.weight.shape) == (16, 64)
+    assert len(ChannelPredictor(64, 3, 16, 8, share_p=False).P) == 3
+    with pytest.raises(NotImplementedError):
+        ChannelPredictor(64, 3, 16, 8, share_p=False, share_embeddings=True)

@@ -189,6 +189,27 @@ def test_g11_channel_predictor(golden, vtp):
     assert rel_err(pred[3][0], g["logits_3_full_b0"]) < FTOL
 
 
+def test_g21_share_p_channel_predictor(golden):
+    """SHARE_P = True (the reference's config default): one output layer for all channels; logits and gradients of the
+    oracle against the reference's own ChannelPredictor(share_p=True) (fixture G21)."""
+    g = golden("g21_share_p")
+    d, nc, nv, de = [int(x) for x in g["dims"]]
+    shapes = {"layer_norm.weight": (d,), "layer_norm.bias": (d,), "P.weight": (nv, d), "P.bias": (nv,)}
+    for k in range(nc):
+        shapes["U.%d.weight" % k] = (d, d + k * nv)
+        shapes["U.%d.bias" % k] = (d,)
+    params = {"ch_predictor." + k: v.clone().requires_grad_(True) for k, v in seeded.seeded_params(shapes, int(g["seed"]), "g21.").items()}
+    yl = g["yl"].clone().requires_grad_(True)
+    pred = O.channel_predictor_logits(params, g["slice"], yl, nv=nv)
+    sum((o * g["gy_%d" % k]).sum() for k, o in enumerate(pred)).backward()
+    for k in range(nc):
+        assert rel_err(pred[k], g["logits_%d" % k]) < FTOL
+    assert rel_err(params["ch_predictor.P.weight"].grad, g["grad_P_weight"]) < 1e-4
+    assert rel_err(params["ch_predictor.P.bias"].grad, g["grad_P_bias"]) < 1e-4
+    assert rel_err(params["ch_predictor.U.2.weight"].grad, g["grad_U2_weight"]) < 1e-4
+    assert rel_err(yl.grad, g["grad_yl"]) < 1e-4
+
+
 def test_g12_full_dsfvt_loss(golden, vtp):
     g = golden("g12_dsfvt_loss")
     p = {k: v.clone().requires_grad_(True) for k, v in vtp.items()}
