@@ -49,11 +49,11 @@ SEED = 29871897                    # configs/*/Base: SEED
 def engine_peak(mode, kind=""):
     """Ceiling of an engine launch in ALGORITHMIC fp32 FLOP/s: the fp32 MFMA peak in 'f32' mode; in 'bf16x3' mode every
     algorithmic product is six bf16 MFMA products (a1b1 a1b2 a2b1 a1b3 a3b1 a2b2), so the ceiling is bf16 peak / 6; in
-    'f16x2' mode three fp16 MFMA products (hi hi, hi lo, lo hi; fp16 rate = bf16 rate), so peak / 3 -- except for the
-    launches that have no f16x2 path and run bf16x3 in that mode too (`kind` attn_*: the fused attention kernels)."""
+    'f16x2' mode three fp16 MFMA products (hi hi, hi lo, lo hi; fp16 rate = bf16 rate), so peak / 3 -- the attention launches
+    too since round 5 (csrc/attention_flash.hip; with LVT_NO_FLASH_ATTENTION they fall back to the bf16x3 plane kernels)."""
     if mode == "f32":
         return FP32_MFMA_PEAK_TFLOPS
-    if mode == "f16x2" and not kind.startswith("attn_"):
+    if mode == "f16x2" and not (kind.startswith("attn_") and os.environ.get("LVT_NO_FLASH_ATTENTION")):
         return BF16_MFMA_PEAK_TFLOPS / 3.0
     return BF16_MFMA_PEAK_TFLOPS / 6.0
 
@@ -69,7 +69,8 @@ MATH_NOTE = {
              "v_mfma_f32_32x32x16_f16 (hi hi | hi lo + lo hi in a second accumulator; dropped lo lo <= 2^-22 |a||b|, "
              "2^-24.6 rms); measured error against fp64 is not larger than the plain fp32 MFMA path's on seven operand "
              "classes (tests/test_gpu_engine.py::test_math_modes_accuracy) and every parity test runs in this mode at "
-             "unchanged tolerances; the fused attention kernels and the VQ search keep the bf16x3 arithmetic",
+             "unchanged tolerances; the flash attention kernels split per ROW (token x head) instead of per tensor, the VQ search "
+             "keeps the bf16x3 arithmetic",
 }
 PEAK_NOTE = {
     "f32": "dense fp32 MFMA peak (MI355X_MICROARCH.md)",
@@ -79,15 +80,18 @@ PEAK_NOTE = {
               "profiles/r01_ubench_engine_bounds.txt), i.e. ~300 TFLOP/s in these units; the shader clock measured inside "
               "lvt_gemm_kernel on random operands is 1.58-1.69 GHz of the nominal 2.4 (2.25 GHz on zeros), "
               "profiles/r03_gemm_shape_and_power_probes.txt",
-    "f16x2": "dense bf16/fp16 MFMA peak 2516.6 TFLOP/s / 3 MFMA products per algorithmic fp32 product (/ 6 for the attention "
-             "launches, which stay on bf16x3); `peak` is the flop-weighted harmonic ceiling of the launches of the step, "
-             "`achieved` counts ALGORITHMIC fp32 FLOPs only",
+    "f16x2": "dense bf16/fp16 MFMA peak 2516.6 TFLOP/s / 3 MFMA products per algorithmic fp32 product; `achieved` counts "
+             "ALGORITHMIC fp32 FLOPs only (the attention backward is counted with the reference's four products, 8 B H S^2 d_a, "
+             "although the flash kernels recompute the scores and dP in both of their launches)",
 }
 
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dp-single-rank", action="store_true",
+                    help="with --gpus 1: join a ONE-rank RCCL group and keep the gradient reducers active (all-reduces are "
+                         "identities there), so that `comm` reports the exposed communication of the data-parallel path")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batches", type=int, default=4, help="distinct synthetic batches rotated through the steps")
@@ -179,7 +183,7 @@ def timed_steps(step, steps, first_iter, world, device):
 
 def traffic_from_profile(name, launches_per_step=None):
     """HBM bytes per engine launch from this round's committed PMC passes (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in
-    separate runs of scratch/bench_leg.py, summarised by scratch/pmc_summary.py / scratch/profile_r04.sh): counters cannot be
+    separate runs of scratch/bench_leg.py, summarised by scratch/pmc_summary.py / scratch/profile_r05.sh): counters cannot be
     read inside the run.  -> (bytes per launch or None, file name, stale?): the figure is STALE when the profiled code issued
     another number of engine launches per step than the run that quotes it (the kernels changed since the pass)."""
     try:
@@ -243,7 +247,7 @@ def roofline_block(es, mode, traffic_file, kernel_note):
 class VqvaeLeg:
     """PR-DVQVAE2 train step: fwd + bwd + Adam on `batch` clips x 16 frames (encoder, 4x512 EMA codebooks, decoder)."""
 
-    def __init__(self, device, world, rank, local_rank, batch, nbatches):
+    def __init__(self, device, world, rank, local_rank, batch, nbatches, dp=None):
         from lvt_amd.config import get_cfg
         from lvt_amd.modeling import build_model
         cfg = get_cfg()
@@ -254,7 +258,7 @@ class VqvaeLeg:
         self.cfg, self.model = cfg, build_model(cfg)
         self.model.train()
         self.optimizers, _ = self.model.configure_optimizers_and_checkpointers()
-        if world > 1:
+        if world > 1 if dp is None else dp:
             self.model.wrap_parallel(device_ids=[local_rank], broadcast_buffers=False)
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
         self.clips, self.batches = [], []
@@ -280,7 +284,7 @@ class DsfvtLeg:
     """DSFVT train step: fwd + bwd + RMSprop on `batch` samples = one random subscale slice (256 tokens x 4 code channels)
     of one 16-frame code clip each."""
 
-    def __init__(self, device, world, rank, local_rank, batch, nbatches):
+    def __init__(self, device, world, rank, local_rank, batch, nbatches, dp=None):
         from lvt_amd.config import get_cfg
         from lvt_amd.data.dataset_mapper import prepare_slices_batch
         from lvt_amd.modeling import build_model
@@ -292,7 +296,7 @@ class DsfvtLeg:
         self.cfg, self.model = cfg, build_model(cfg)
         self.model.train()
         self.optimizers, _ = self.model.configure_optimizers_and_checkpointers()
-        if world > 1:
+        if world > 1 if dp is None else dp:
             self.model.wrap_parallel(device_ids=[local_rank], broadcast_buffers=False)
         v = cfg.MODEL.AUTOREGRESSIVE.VT
         g = torch.Generator(device="cpu").manual_seed(4321 + rank)
@@ -676,13 +680,18 @@ def run(args):
             out["cpu_baseline"] = cpu_baseline_generate(args.cpu_seconds * 0.5)
         print(json.dumps(out), flush=True)
         return
-    if world > 1:
+    single = bool(args.dp_single_rank) and world == 1
+    if single:
+        os.environ["LVT_DP_SINGLE_RANK"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+    if world > 1 or single:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     from lvt_amd.hip import binding as L
-    vq = VqvaeLeg(device, world, rank, local_rank, args.batch_clips, args.batches)
-    ds = DsfvtLeg(device, world, rank, local_rank, args.dsfvt_batch, args.batches)
+    vq = VqvaeLeg(device, world, rank, local_rank, args.batch_clips, args.batches, dp=world > 1 or single)
+    ds = DsfvtLeg(device, world, rank, local_rank, args.dsfvt_batch, args.batches, dp=world > 1 or single)
     vq_per_step = max(1, args.dsfvt_batch // args.batch_clips)        # VQ-VAE train steps per DSFVT train step (2)
     clips_per_step = args.dsfvt_batch                                 # every one of them passes through both models
 
@@ -708,12 +717,18 @@ def run(args):
 
     # communication: what RCCL sees, and what the step costs with the reducers switched off (gradients stay local)
     reducers = list(getattr(vq.model, "_reducers", [])) + list(getattr(ds.model, "_reducers", []))
-    comm = {"world_size": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,
+    grouped = world > 1 or single
+    if grouped:     # what RCCL itself reports after a collective of this process group has run
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+    comm = {"world_size": dist.get_world_size() if grouped else 1, "backend": dist.get_backend() if grouped else None,
+            "ranks_seen_by_allreduce": int(probe.item()) if grouped else 1, "single_rank_group": single,
             "allreduce_bytes_per_step": int(sum(r.bytes_per_backward for r in reducers if r in vq.model._reducers) * vq_per_step
                                             + sum(r.bytes_per_backward for r in reducers if r in ds.model._reducers))
             if reducers else 0,
             "ema_allreduce_bytes_per_step": (4 * 512 * (64 + 1) * 4) * vq_per_step if world > 1 else 0}
-    if world > 1:
+    if grouped:
         for r in reducers:
             r.enabled = False
         n3 = max(5, args.steps // 2)
@@ -728,17 +743,24 @@ def run(args):
     extra = {}
     if not args.no_legs:
         nl = max(10, args.steps)
-        extra["vqvae"] = leg_alone("vqvae", vq, nl, 3, world, device, "clips", "r04_vqvae_pmc_hbm_traffic.json",
+        extra["vqvae"] = leg_alone("vqvae", vq, nl, 3, world, device, "clips", "r05_vqvae_pmc_hbm_traffic.json",
                                    "lvt_conv_patch_kernel<0,1,2> / lvt_conv_wgrad_frames_kernel<0,1> (frame-resident 3x3 and "
                                    "4x4/stride-2 layers) + lvt_gemm_kernel<*> (1x1 and image-side layers)",
                                    not args.no_strict_f32)
         extra["dsfvt"] = leg_alone("dsfvt", ds, max(10, args.steps // 2), 2, world, device, "samples",
-                                   "r04_dsfvt_pmc_hbm_traffic.json",
+                                   "r05_dsfvt_pmc_hbm_traffic.json",
                                    "lvt_gemm_wide_kernel<*> (QKV / proj / FFN products, their data and weight gradients; f16x2) + "
-                                   "lvt_attn_fwd16_planes_kernel / lvt_attn_bwd_a16 / _b16 (fused attention, bf16x3)", not args.no_strict_f32)
+                                   "lvt_attn_fwd_flash_kernel / lvt_attn_bwd_flash_a / _b (flash attention on fp32 operands, per-row f16x2)", not args.no_strict_f32)
         v1, v2 = extra["vqvae"]["clips_per_s"], extra["dsfvt"]["samples_per_s"]
         extra["legs_combined_harmonic"] = {"clips_per_s": round(1.0 / (1.0 / v1 + 1.0 / v2), 3),
                                            "note": "1/(1/vqvae + 1/dsfvt) of the two legs timed alone: cross-check of `value`"}
+    # the same job with every product on the plain fp32 MFMA instruction (LVT_MATH=f32), from the two legs timed alone in that mode
+    strict_f32 = None
+    if "vqvae" in extra and "strict_f32_mfma" in extra["vqvae"] and "strict_f32_mfma" in extra["dsfvt"]:
+        f1, f2 = extra["vqvae"]["strict_f32_mfma"]["clips_per_s"], extra["dsfvt"]["strict_f32_mfma"]["samples_per_s"]
+        strict_f32 = {"clips_per_s": round(1.0 / (1.0 / f1 + 1.0 / f2), 3), "ratio_to_value": None,
+                      "note": "LVT_MATH=f32 (v_mfma_f32_32x32x2_f32 everywhere): 1/(1/vqvae + 1/dsfvt) of the two legs timed alone "
+                              "in that mode (extra.*.strict_f32_mfma); `value` is measured in `math_mode`"}
     gate_state = None
     parity = None
     if not args.no_parity and rank == 0:
@@ -746,7 +768,7 @@ def run(args):
         extra["vq_encode"] = vq_enc
         parity["dsfvt_loss"] = round(float(ds_loss.detach()), 6)
         parity["vqvae_loss"] = {k: round(float(v.detach()), 6) for k, v in losses.items()}
-    if world > 1:
+    if grouped:
         dist.barrier()
 
     if rank == 0:
@@ -758,11 +780,14 @@ def run(args):
             extra["generate"] = generate_in_child(args)
         ms = elapsed / args.steps * 1e3
         value = clips_per_step * world * args.steps / elapsed
+        if strict_f32 is not None:
+            strict_f32["ratio_to_value"] = round(value / strict_f32["clips_per_s"], 3)
         out = {
             "metric": "video-clips/sec/node (VQVAE+DSFVT train step, BAIR 64x64x16)",
             "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "math": MATH_NOTE[math_mode],
+            "vs_baseline": None, "dtype": "f32", "math_mode": math_mode, "strict_f32": strict_f32, "data": "synthetic",
+            "math": MATH_NOTE[math_mode],
             "step_ms": stats,
             "config": {"workload": "VQVAE+DSFVT train step: %d clips per GPU per step through both models -- %d x PR-DVQVAE2 "
                                    "train step (fwd+bwd+Adam, %d clips x 16 frames x 3x64x64, 4x512 EMA codebooks) + 1 x DSFVT "
@@ -771,7 +796,7 @@ def run(args):
                                    % (clips_per_step, vq_per_step, args.batch_clips, args.dsfvt_batch, args.batches),
                        "global_batch_clips": clips_per_step * world, "parallelism": "dp%d" % world},
             "roofline": roofline_block(
-                es, math_mode, "r04_combined_pmc_hbm_traffic.json",
+                es, math_mode, "r05_combined_pmc_hbm_traffic.json",
                 "the matrix-core engine launches of the step: lvt_gemm_wide_kernel<*>, lvt_gemm_kernel<*>, lvt_conv_patch_kernel<*>, "
                 "lvt_conv_wgrad_frames_kernel<*>, lvt_attn_fwd/bwd kernels; %d launches per step, event-timed in a second "
                 "pass of the same %d steps: %.2f ms of engine time in a %.2f ms instrumented step (unperturbed: %.2f ms)"
@@ -784,7 +809,7 @@ def run(args):
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, gate_state)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

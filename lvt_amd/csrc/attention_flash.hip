@@ -49,7 +49,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define FA_LD 144                         // row pitch (fp16): 288 B
 #define FA_PL (64 * FA_LD)                // one plane of an item (fp16 elements)
 #define FA_SLOT (2 * FA_PL)               // hi plane, lo plane: 36864 B
-#define FA_EMIN 15                        // clamp of the biased exponent of a row max (keeps every derived scale a normal float)
+#define FA_EMIN 30                        // clamp of the biased exponent of a row max: rows below 2^-97 share that scale, and every
+                                          // derived factor (2^15 / 2^(e - 141), products of a scale and an inverse scale) stays finite
 #define FA_EMAX 254
 #define FA_LOG2E 1.4426950408889634f      // scores are kept in log2 units: p = 2^(x - m) is one v_exp_f32
 
@@ -500,7 +501,8 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
 
     float delta = 0.f, gmax = 0.f;
     float kmax = fa_u2f((unsigned)(FA_EMIN - 14) << 23);             // largest 2^(e - 14) over the K rows (pass 1)
-    float wsc = 0.f, dl = 0.f;                                        // pass 2: (scale of g from its bound) / kmax; delta / l
+    float sgf = 0.f, kmr = 0.f, dl = 0.f;                             // pass 2: scale of g from its bound, 1 / kmax (applied one
+                                                                      // after the other: their product can leave the float range), delta / l
     int ebG = FA_EMIN;
     f32x4v qacc[AT_D / 16];
 #pragma unroll
@@ -526,7 +528,8 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
             kmax = fa_kg_max(kmax);
             const float G = gmax + fabsf(delta);                      // >= |p (dP - delta)|: p <= 1
             ebG = fa_ebits(G);
-            wsc = fa_u2f((unsigned)(268 - ebG) << 23) * __builtin_amdgcn_rcpf(kmax);
+            sgf = fa_u2f((unsigned)(268 - ebG) << 23);
+            kmr = __builtin_amdgcn_rcpf(kmax);
             dl = delta * linv;
             // per-workgroup bounds for kernel B: max 2^(e - 14) over the dO rows, max of G_i 2^(e_i - 14) over the q rows
             float r0 = doinv, r1 = G * qinv;
@@ -579,7 +582,7 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
             const float bth = bt_[T / HP] + dhl[-HSTEP * (T % HP)];
             if constexpr (!PASS2) kmax = fmaxf(kmax, fa_max4(kinv));
             const f32x4v qk = kinv * qc, bm = bw4 + bth;
-            const f32x4v dv = vinv * (PASS2 ? doinv * linv : doinv), kw = kinv * wsc;
+            const f32x4v dv = vinv * (PASS2 ? doinv * linv : doinv), kw = kinv * kmr;         // kw <= 1
             float gt = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -596,7 +599,7 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
                     const float g = ex * fmaf(dp[kt][r], dv[r], -dl);  // p (dP - delta)
                     gt += g;
                     rsw[r] += g;
-                    w[4 * kt + r] = g * kw[r];
+                    w[4 * kt + r] = (g * sgf) * kw[r];
                 }
             }
             if constexpr (PASS2) { rst[T / HP] += gt; mine[BT + T % HP] += gt; }
@@ -846,7 +849,7 @@ __device__ __forceinline__ float fa_bwd_b_body(const FaArgs &A, FaSmemB &sm, int
             const float bth = bt_[T / HP] + dhl[HSTEP * (T % HP)];
             const f32x4v qk = qinv * kc, bm = bw4 + bth;
             const f32x4v lds = l4[qt] * (doinv * srun);               // P^T dO operand: p 2^(e_i - 14) 2^15 2^(141 - E) = exp lds
-            const f32x4v qzl = l4[qt] * (qinv * zrun);                // g^T Q operand: g 2^(e_i - 14) 2^(141 - zb) = exp (dp dvq - dq)
+            const f32x4v qzl = l4[qt] * qinv;                         // g^T Q operand: g 2^(e_i - 14) 2^(141 - zb) = (exp (dp dvq - dq)) zrun
             const f32x4v dvq = (doinv * vinv) * qzl, dq_ = d4[qt] * qzl;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -854,7 +857,7 @@ __device__ __forceinline__ float fa_bwd_b_body(const FaArgs &A, FaSmemB &sm, int
                 if (MASKED && j > 16 * T + 4 * kg + r) x = A.fill2;
                 const float ex = __builtin_amdgcn_exp2f(x - m4[qt][r]);
                 pw[4 * qt + r] = ex * lds[r];
-                u[4 * qt + r] = ex * fmaf(dp[qt][r], dvq[r], -dq_[r]);
+                u[4 * qt + r] = (ex * fmaf(dp[qt][r], dvq[r], -dq_[r])) * zrun;     // (zrun last: |g 2^(e_i - 14)| <= the bound it comes from)
             }
         }
         f16x8 pbh, pbl, ubh, ubl;

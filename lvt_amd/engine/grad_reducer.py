@@ -27,13 +27,20 @@ gloo has no AVG.
 """
 import weakref
 
+import os
+
 import torch
 import torch.distributed as dist
 from torch.optim.optimizer import register_optimizer_step_pre_hook
 
 
+# LVT_DP_SINGLE_RANK=1: every reducer is active in a process group of ONE rank too (bench.py --dp-single-rank, the overlap
+# trace of scripts / profiles): the RCCL launches, the side stream and the joins of the 8-GPU run on a single-GPU box.
+FORCE_SINGLE_RANK = bool(os.environ.get("LVT_DP_SINGLE_RANK"))
+
+
 class BucketedGradReducer:
-    def __init__(self, params, bucket_bytes=16 << 20, group=None, broadcast_params=True, reduce_single_rank=False):
+    def __init__(self, params, bucket_bytes=16 << 20, group=None, broadcast_params=True, reduce_single_rank=None):
         """reduce_single_rank: run the collectives also in a process group of ONE rank (they are identities there);
         tests use it to drive the RCCL code path -- AVG reduction, asynchronous work on the side stream, the joins -- on
         a single-GPU box."""
@@ -41,6 +48,8 @@ class BucketedGradReducer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._div = self.world
+        if reduce_single_rank is None:
+            reduce_single_rank = FORCE_SINGLE_RANK or bool(os.environ.get("LVT_DP_SINGLE_RANK"))
         if reduce_single_rank and self.world == 1 and dist.is_available() and dist.is_initialized():
             self.world = 2          # "active"; the divisor of the SUM path stays the true group size
         if broadcast_params and self.world > 1:

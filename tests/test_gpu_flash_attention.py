@@ -111,6 +111,29 @@ def test_flash_attention_accuracy_envelope(kind):
         assert err <= max(1.5 * err32, 2e-6 * scale), (kind, n, err, err32, scale)
 
 
+@pytest.mark.parametrize("blk", [(1, 16, 16), (4, 8, 8)])
+def test_flash_attention_zero_rows_and_zero_gradients(blk):
+    """Operands with all-zero rows, a (sample, head) whose dO is entirely zero (a block that does not reach the loss: the DSSVT
+    encoder has them) and one whose V is zero: every scale derived from a row maximum stays finite -- no inf * 0."""
+    B, H = 2, 8
+    hd = H * DA
+    q, k, v, go = (_rand(B * S, hd, seed=s) for s in (11, 12, 13, 14))
+    go[:S] = 0                                  # sample 0: no gradient at all
+    go[S:, :DA] = 0                             # sample 1, head 0 alike
+    v[S:, DA:2 * DA] = 0                        # sample 1, head 1: V == 0
+    q[5] = 0; k[7] = 0; k[S + 9] = 0
+    banks = [_rand(H, 2 * n - 1, seed=5 + i) * 0.5 for i, n in enumerate(blk)]
+    for masked in (False, True):
+        ref = _reference(q, k, v, go, banks, blk, masked)
+        got = _flash(q, k, v, go, banks, blk, masked)
+        bank_scale = max(float(ref[i].abs().max()) for i in (6, 7, 8))
+        for n, a, r in zip(NAMES, got, ref):
+            assert torch.isfinite(a).all(), n
+            scale = bank_scale if n.startswith("dd") else float(r.abs().max())
+            assert float((a.double().cpu() - r).abs().max()) < 2e-5 * scale, (n, masked)
+        assert float(got[3][:S].abs().max()) == 0.0 and float(got[5][:S].abs().max()) == 0.0     # sample 0: dq == dv == 0
+
+
 @pytest.mark.parametrize("block,masked", [((1, 16, 16), False), ((1, 16, 16), True), ((4, 8, 8), True), ((4, 8, 8), False)])
 def test_flash_layer_equals_plane_layer(block, masked):
     """One BlockLocalAttention layer through the flash kernels against the same layer through the plane kernels of
