@@ -6,7 +6,11 @@ against the CPU oracle stepped by torch.optim with the same hyperparameters on t
   * the loss of every step within 1e-4 (relative) of an fp64 oracle trajectory;
   * the weights after the last step as close to the fp64 trajectory as the CPU fp32 oracle's trajectory is (x 4; floor 1e-5 of
     the tensor's max), per tensor in the l2 norm -- an Adam / RMSprop update is ~lr * sign(g) wherever |g| is at the rounding
-    level, so single entries of ANY two fp32 trajectories differ by up to 2 lr there and a max-norm bound would test luck;
+    level, so single entries of ANY two fp32 trajectories differ by up to 2 lr there and a max-norm bound would test luck.
+    The DSFVT oracle runs (fp32 and fp64) take their ReLU decisions from the device (binding.RELU_TRACE, tests/util_relu.py):
+    among the 4 M units of a forward pass one or two sit within round-off of zero, and a unit resolved differently moves whole
+    gradient tensors by 1e-4 .. 1e-3 (scratch/grad_accuracy_dsfvt.py: 300 x the CPU fp32 oracle's distance from fp64 at step 0,
+    with the plane and the flash attention kernels alike) -- a fork of the trajectories that says nothing about the arithmetic;
   * code indices: no flip against the oracle's own search on rows with a clear margin, at every step (the oracle trajectory is
     run with the device's indices forced, so that a sub-margin row cannot fork the two trajectories)."""
 import pytest
@@ -48,6 +52,7 @@ def test_vqvae_train_trajectory_vs_oracle():
     sides = {dt: oracle_side(dt) for dt in (torch.float32, torch.float64)}
     flips_clear = 0
     for i in range(STEPS):
+        cpu32 = {}
         with EventStorage(i):
             losses = model([{"image": xs[i][j].numpy()} for j in range(4)], mode="supervised")
         sum(losses.values()).backward()
@@ -71,10 +76,14 @@ def test_vqvae_train_trajectory_vs_oracle():
             for o in opt:
                 o.step()
             sides[dt] = (pe, pd, {k: v.detach() for k, v in new_state.items()}, opt)
+            if dt == torch.float32:
+                cpu32 = {k: float(v.detach()) for k, v in ref.items()}
             if dt == torch.float64:
                 for k in ("loss_reconstruction", "loss_commitment"):
                     a, b = float(losses[k].detach()), float(ref[k].detach())
-                    assert abs(a - b) < 1e-4 * abs(b), (i, k, a, b)
+                    # (the commitment loss is a mean of squared differences of nearly equal tensors, ~1e-4 after a few steps: its
+                    # fp32 evaluations scatter by more than 1e-4 of it, so the CPU fp32 trajectory's own distance is the yardstick)
+                    assert abs(a - b) < max(1e-4 * abs(b), 4 * abs(cpu32[k] - b)), (i, k, a, b, cpu32[k])
         for o in opts:
             o["optimizer"].step()
         for o in opts:
@@ -87,9 +96,9 @@ def test_vqvae_train_trajectory_vs_oracle():
     for k in r64:
         e_mine, e_cpu = _l2(mine[k].cpu(), r64[k].detach()), _l2(r32[k].detach(), r64[k].detach())
         assert e_mine < max(4 * e_cpu, 1e-5), (k, e_mine, e_cpu)
-    cb, cb64 = model.codebook.state_dict(), sides[torch.float64][2]
+    cb, cb64, cb32 = model.codebook.state_dict(), sides[torch.float64][2], sides[torch.float32][2]
     for k in cb64:
-        assert _l2(cb[k].cpu(), cb64[k]) < 1e-4, k
+        assert _l2(cb[k].cpu(), cb64[k]) < max(4 * _l2(cb32[k], cb64[k]), 1e-4), k
 
 
 def test_dsfvt_train_trajectory_vs_oracle():
@@ -119,19 +128,32 @@ def test_dsfvt_train_trajectory_vs_oracle():
                                   alpha=s.RMSPROP.ALPHA_G, momentum=s.RMSPROP.MOMENTUM_G)
         return p, opt
 
+    from util_relu import ReluFollow, relu_probe
     sides = {dt: oracle_side(dt) for dt in (torch.float32, torch.float64)}
+    forks = 0
     for i, data in enumerate(batches):
-        with EventStorage(i):
-            loss = model(data, mode="supervised")["loss_cross_entropy"]
+        trace = L.RELU_TRACE = []
+        try:
+            with EventStorage(i):
+                loss = model(data, mode="supervised")["loss_cross_entropy"]
+        finally:
+            L.RELU_TRACE = None
         loss.backward()
         ctx = torch.stack([d["context"] for d in data]); sl = torch.stack([d["slice"] for d in data])
         si = torch.stack([d["slice_idx"] for d in data]); ig = torch.stack([d["ignore_mask"] for d in data])
         for dt, (p, opt) in sides.items():
             opt.zero_grad()
-            lo, _ = O.vt_supervised_loss(p, ctx, sl, si, ig, **ds)
+            with torch.no_grad():       # MaskedConv3d.forward zeroes the causal taps in weight.data (vt_utils.py:197-199): the
+                w = p["decoder.conv.conv.weight"]       # optimizer's update of those taps lives until the next forward only
+                w[:, :, -1, -1, w.shape[-1] // 2:] = 0
+            with relu_probe(ReluFollow(trace)) as follow:
+                lo, _ = O.vt_supervised_loss(p, ctx, sl, si, ig, **ds)
+            assert follow.calls == len(trace)
             lo.backward()
             opt.step()
             if dt == torch.float64:
+                forks += follow.differ
+                assert follow.differ <= 16, follow.differ      # units on their threshold, not a different network
                 a, b = float(loss.detach()), float(lo.detach())
                 assert abs(a - b) < 1e-4 * abs(b), (i, a, b)
         for o in opts:

@@ -52,6 +52,22 @@ class ReluProbe:
         return y
 
 
+class ReluFollow:
+    """Stand-in for torch.relu that takes EVERY decision from recorded masks (`masks`: one bool tensor per ReLU call in the
+    oracle's call order and element order -- lvt_amd.hip.binding.RELU_TRACE): y = x where the mask passes, 0 elsewhere.
+    An oracle run under it makes exactly the decisions of the path under test (used step by step along a training trajectory,
+    where a unit on its threshold would otherwise fork the two trajectories)."""
+
+    def __init__(self, masks):
+        self.masks, self.calls, self.differ = masks, 0, 0
+
+    def __call__(self, x):
+        m = self.masks[self.calls].detach().to(x.device).reshape(x.shape)
+        self.calls += 1
+        self.differ += int((m != (x.detach() > 0)).sum())
+        return torch.where(m, x, torch.zeros_like(x))
+
+
 @contextlib.contextmanager
 def relu_probe(probe):
     torch.relu = probe
