@@ -69,6 +69,8 @@ class BucketedGradReducer:
         if cur:
             self._make_bucket(cur)
         self._comm_stream = None
+        self.trace = None          # a list: every bucket launch / join appends (kind, bucket index, bytes, event) -- a HIP event on the
+                                   # stream the collective / the join was issued on (scratch/dp_overlap_trace.py)
         self.enabled = True        # False: gradients stay local (bench.py times a step without communication)
         # gloo (CPU unit tests, and the 2-ranks-on-one-GPU tests) has no AVG: SUM + one division there
         self._avg = self.world > 1 and dist.get_backend(group) == "nccl"
@@ -96,7 +98,7 @@ class BucketedGradReducer:
         dev, dt = plist[0].device, plist[0].dtype
         total = sum(p.numel() for p in plist)
         flat = torch.zeros(total, dtype=dt, device=dev)
-        b = {"flat": flat, "params": list(plist), "views": [], "pending": len(plist), "work": None}
+        b = {"flat": flat, "params": list(plist), "views": [], "pending": len(plist), "work": None, "index": len(self.buckets)}
         off = 0
         for p in plist:
             v = flat[off:off + p.numel()].view_as(p)
@@ -167,12 +169,20 @@ class BucketedGradReducer:
                 b["work"] = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
         else:
             b["work"] = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
+        if self.trace is not None and cs is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(cs)               # completes when the collective of this bucket has
+            self.trace.append(("allreduce_done", b["index"], flat.numel() * flat.element_size(), ev))
 
     def _join(self, b):
         b["work"].wait()
         cs = self._comm_stream
         if cs is not None:
             torch.cuda.current_stream(cs.device).wait_stream(cs)
+            if self.trace is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(cs.device))
+                self.trace.append(("joined", b["index"], 0, ev))
         if not self._avg:
             b["flat"].div_(self._div)
         b["work"] = None
