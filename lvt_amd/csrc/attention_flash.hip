@@ -805,42 +805,91 @@ __device__ __forceinline__ float fa_bwd_b_body(const FaArgs &A, FaSmemB &sm, int
         f32x4v st[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
         f32x4v dp[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
         int eb0 = 0, eb1 = 0;
-        static_for<4>([&](auto sc_) {
-            constexpr int s = decltype(sc_)::value;
-            f16x8 aq[2][2], ad[2][2], vb[2];
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) vb[pl] = fa_rowfrag(vs, pl, jl & 63, s, kg);
+        // Fragment reads are software-pipelined by HALF k steps: while the six S MFMAs of step s issue, the dO / V fragments of
+        // step s are in flight; while the six dP MFMAs issue, the Q fragments of step s + 1.  (Reading all ten fragments of a k
+        // step and then multiplying made the LDS and the matrix pipe take turns: all eight waves read at once -- 320 LDS
+        // cycles -- then multiply -- 2 x 192 cycles per SIMD.)
+        f16x8 aq[2][2][2], ad[2][2], vb[2];
+        auto load_s = [&](int s_, int bf) {
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    aq[qt][pl] = fa_rowfrag(cur, pl, 16 * qt + c16, s, kg);
-                    ad[qt][pl] = fa_rowfrag(cur, pl, 32 + 16 * qt + c16, s, kg);
-                }
+                for (int pl = 0; pl < 2; ++pl) aq[bf][qt][pl] = fa_rowfrag(cur, pl, 16 * qt + c16, s_, kg);
+#ifdef FB_X_NOFRAG1
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) { st[qt] = fa_mfma(aq[qt][1], kb[s][0], st[qt]); dp[qt] = fa_mfma(ad[qt][1], vb[0], dp[qt]); }
+            for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) { st[qt] = fa_mfma(aq[qt][0], kb[s][1], st[qt]); dp[qt] = fa_mfma(ad[qt][0], vb[1], dp[qt]); }
+                for (int pl = 0; pl < 2; ++pl) aq[bf][qt][pl] = kb[s_ & 3][pl];
+#endif
+        };
+        auto load_p = [&](int s_) {
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) { st[qt] = fa_mfma(aq[qt][0], kb[s][0], st[qt]); dp[qt] = fa_mfma(ad[qt][0], vb[0], dp[qt]); }
+            for (int pl = 0; pl < 2; ++pl) vb[pl] = fa_rowfrag(vs, pl, jl & 63, s_, kg);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) ad[qt][pl] = fa_rowfrag(cur, pl, 32 + 16 * qt + c16, s_, kg);
+#ifdef FB_X_NOFRAG1
+            vb[0] = kb[s_ & 3][1]; vb[1] = kb[s_ & 3][0];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) ad[qt][pl] = kb[(s_ + 1) & 3][pl];
+#endif
+        };
+        load_s(0, 0);
+        static_for<4>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value, bf = s & 1;
+            load_p(s);
+#ifdef FB_X_NOMFMA1
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) { st[qt] += __builtin_bit_cast(f32x4v, aq[bf][qt][1]) + __builtin_bit_cast(f32x4v, aq[bf][qt][0]); dp[qt] += __builtin_bit_cast(f32x4v, ad[qt][0]) + __builtin_bit_cast(f32x4v, ad[qt][1]) + __builtin_bit_cast(f32x4v, vb[0]) + __builtin_bit_cast(f32x4v, vb[1]); }
+            if constexpr (s < 3) load_s(s + 1, bf ^ 1);
+#else
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) st[qt] = fa_mfma(aq[bf][qt][1], kb[s][0], st[qt]);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) st[qt] = fa_mfma(aq[bf][qt][0], kb[s][1], st[qt]);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) st[qt] = fa_mfma(aq[bf][qt][0], kb[s][0], st[qt]);
+            if constexpr (s < 3) load_s(s + 1, bf ^ 1);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) dp[qt] = fa_mfma(ad[qt][1], vb[0], dp[qt]);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) dp[qt] = fa_mfma(ad[qt][0], vb[1], dp[qt]);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) dp[qt] = fa_mfma(ad[qt][0], vb[0], dp[qt]);
+#endif
+#ifndef FB_X_NOPARK
             if constexpr (PARK) {
                 if constexpr (s == 0) eb0 = fa_row_scale(g0.v[0], g0.v[1]);
                 if constexpr (s == 1) fa_row_store(g0.v[0], g0.v[1], eb0, nslot, ninv, tid >> 4, tid & 15);
                 if constexpr (s == 2) eb1 = fa_row_scale(g0.v[2], g0.v[3]);
                 if constexpr (s == 3) fa_row_store(g0.v[2], g0.v[3], eb1, nslot, ninv, 32 + (tid >> 4), tid & 15);
-                // pin: this step's fragment reads, then the MFMAs with the staging arithmetic between them
-                __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
-#pragma unroll
-                for (int e = 0; e < 12; ++e) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, (s & 1) ? 3 : 2, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
+#endif
+            // pin the order: [dO / V reads] [S MFMAs + staging arithmetic] [next Q reads] [dP MFMAs + staging arithmetic]
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (PARK) __builtin_amdgcn_sched_group_barrier(0x002, (s & 1) ? 3 : 2, 0);
+            }
+            if constexpr (s < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (PARK) __builtin_amdgcn_sched_group_barrier(0x002, (s & 1) ? 3 : 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         });
         if constexpr (t + 2 < NIT) load_item(t + 2, g0);
         // ---- element-wise: per tile the products of the row / column factors, per element five operations + the mask ----
         float pw[8], u[8];
+#ifdef FB_X_NOEW
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { pw[e] = st[e >> 2][e & 3]; u[e] = dp[e >> 2][e & 3]; }
+#else
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const int T = 2 * c + qt;                                 // 16-query tile of the (sample, head)
@@ -860,19 +909,47 @@ __device__ __forceinline__ float fa_bwd_b_body(const FaArgs &A, FaSmemB &sm, int
                 u[4 * qt + r] = (ex * fmaf(dp[qt][r], dvq[r], -dq_[r])) * zrun;     // (zrun last: |g 2^(e_i - 14)| <= the bound it comes from)
             }
         }
+#endif
         f16x8 pbh, pbl, ubh, ubl;
         fa_split8(pw, pbh, pbl);
         fa_split8(u, ubh, ubl);
-        // ---- dV^T += dO^T P, dK^T += Q^T g ----
+        // ---- dV^T += dO^T P, dK^T += Q^T g: the transposed fragments pipelined the same way (Q^T of tile d in flight beside the dV
+        // MFMAs of tile d, dO^T of tile d + 1 beside its dK MFMAs) ----
+        f16x8 ao[2][2], aqt[2];
+        auto load_o = [&](int d_, int bf) {
 #pragma unroll
-        for (int d = 0; d < AT_D / 16; ++d) {
-            f16x8 ao[2], aq[2];
+            for (int pl = 0; pl < 2; ++pl) ao[bf][pl] = fa_trfrag(cur, pl, 32, d_, c16, kg);
+#ifdef FB_X_NOFRAG3
+            ao[bf][0] = kb[d_ & 3][0]; ao[bf][1] = kb[d_ & 3][1];
+#endif
+        };
+        load_o(0, 0);
+        static_for<AT_D / 16>([&](auto dc) {
+            constexpr int d = decltype(dc)::value, bf = d & 1;
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) { ao[pl] = fa_trfrag(cur, pl, 32, d, c16, kg); aq[pl] = fa_trfrag(cur, pl, 0, d, c16, kg); }
-            accv[d] = fa_mfma(ao[1], pbh, accv[d]); acck[d] = fa_mfma(aq[1], ubh, acck[d]);
-            accv[d] = fa_mfma(ao[0], pbl, accv[d]); acck[d] = fa_mfma(aq[0], ubl, acck[d]);
-            accv[d] = fa_mfma(ao[0], pbh, accv[d]); acck[d] = fa_mfma(aq[0], ubh, acck[d]);
-        }
+            for (int pl = 0; pl < 2; ++pl) aqt[pl] = fa_trfrag(cur, pl, 0, d, c16, kg);
+#ifdef FB_X_NOFRAG3
+            aqt[0] = kb[(d + 1) & 3][0]; aqt[1] = kb[(d + 1) & 3][1];
+#endif
+#ifdef FB_X_NOMFMA3
+            accv[d] += __builtin_bit_cast(f32x4v, ao[bf][1]) + __builtin_bit_cast(f32x4v, ao[bf][0]) + __builtin_bit_cast(f32x4v, pbh) + __builtin_bit_cast(f32x4v, pbl);
+            if constexpr (d + 1 < AT_D / 16) load_o(d + 1, bf ^ 1);
+            acck[d] += __builtin_bit_cast(f32x4v, aqt[1]) + __builtin_bit_cast(f32x4v, aqt[0]) + __builtin_bit_cast(f32x4v, ubh) + __builtin_bit_cast(f32x4v, ubl);
+#else
+            accv[d] = fa_mfma(ao[bf][1], pbh, accv[d]);
+            accv[d] = fa_mfma(ao[bf][0], pbl, accv[d]);
+            accv[d] = fa_mfma(ao[bf][0], pbh, accv[d]);
+            if constexpr (d + 1 < AT_D / 16) load_o(d + 1, bf ^ 1);
+            acck[d] = fa_mfma(aqt[1], ubh, acck[d]);
+            acck[d] = fa_mfma(aqt[0], ubl, acck[d]);
+            acck[d] = fa_mfma(aqt[0], ubh, acck[d]);
+#endif
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            if constexpr (d + 1 < AT_D / 16) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
         __syncthreads();
     });
     // accv = sum_i p dO 2^15 2^(141 - E) = sum / (srun): dv = accv domax / 2^15;  acck = sum_i g Q 2^(141 - zb): dk = acck inv_temper 2^(zb - 141)
@@ -896,6 +973,8 @@ template <int BT, int BH, int BW, int MASKED>
 __global__ __launch_bounds__(512, 1) void lvt_attn_bwd_flash_b_kernel(const FaArgs A, float *__restrict__ d_amax) {
     __shared__ __attribute__((aligned(16))) FaSmemB sm;
     if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);           // (see the forward kernel)
+    // (A persistent form -- one workgroup per CU walking its items, the stores of item i draining beside the prologue of item
+    // i + 1 -- measured the same 175 us: the ~70 us that a timing build with all step work removed still takes are not dispatch.)
     float am;
     if (MASKED) {        // key half 0 meets all eight query chunks, key half 1 the last four: separate workgroups (one workgroup
                          // running both halves back to back spilled ~95 registers inside its step loops)
@@ -986,7 +1065,7 @@ extern "C" int lvt_attn_bwd_flash(const float *q, const float *k, const float *v
     A.bank_partial = A.scal + (size_t)B * H * 4;
     const int nt = 2 * bt - 1, nh = 2 * bh - 1, nw = 2 * bw - 1, nb = nt + nh + nw;
     const dim3 grid((unsigned)(B * H * (masked ? 1 : 2))), blk(512);
-    const dim3 gridb((unsigned)(B * H * 2));                              // kernel B: the two key halves are separate workgroups
+    const dim3 gridb((unsigned)(B * H * 2));                              // kernel B: the two key halves are separate items
     hipStream_t s = (hipStream_t)stream;
 #define LVT_X(BT, BH, BW)                                                                                         \
     if (bt == BT && bh == BH && bw == BW) {                                                                       \
