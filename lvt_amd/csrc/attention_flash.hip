@@ -751,8 +751,10 @@ __device__ __forceinline__ float fa_bwd_b_body(const FaArgs &A, FaSmemB &sm, int
         G4 a, bq;
         fa_load(a, rows, rows + 32 * A.ld, A.ld, tid);
         fa_load(bq, rows + 64 * A.ld, rows + 96 * A.ld, A.ld, tid);
-        fa_park(a, sm.vres[0], sm.vinv[0], tid);
-        fa_park(bq, sm.vres[1], sm.vinv[1], tid);
+#ifdef FB_X_NOVSTAGE
+        if (A.H < 0)
+#endif
+        { fa_park(a, sm.vres[0], sm.vinv[0], tid); fa_park(bq, sm.vres[1], sm.vinv[1], tid); }
     }
     load_item(0, g0);
     f16x8 kb[4][2];
@@ -960,8 +962,10 @@ __device__ __forceinline__ float fa_bwd_b_body(const FaArgs &A, FaSmemB &sm, int
 #pragma unroll
         for (int d = 0; d < AT_D / 16; ++d) {
             const f32x4v ov = accv[d] * fvs, ok = acck[d] * fks;
-            *reinterpret_cast<f32x4v *>(vrow + 16 * d) = ov;
-            *reinterpret_cast<f32x4v *>(krow + 16 * d) = ok;
+#ifdef FB_X_NOSTORE
+            if (A.H < 0)
+#endif
+            { *reinterpret_cast<f32x4v *>(vrow + 16 * d) = ov; *reinterpret_cast<f32x4v *>(krow + 16 * d) = ok; }
 #pragma unroll
             for (int e = 0; e < 4; ++e) am = fmaxf(am, fmaxf(fabsf(ov[e]), fabsf(ok[e])));
         }
