@@ -587,17 +587,29 @@ def bench_generate(device, batch):
     assert tuple(rec.shape) == (batch * 16, 3, 64, 64) and bool(torch.isfinite(rec).all())
     # roofline of the phase that dominates: the single-token decode steps are bound by the K/V-cache reads of the decode attention
     kv_bytes = generation_kv_bytes(cfgs[0].MODEL.AUTOREGRESSIVE.VT, batch, n_prime)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r05_decode_attn_pmc_hbm_traffic.json")) as f:
+            dec = json.load(f)
+    except Exception:
+        dec = {}
     import lvt_amd.modeling.meta_arch.vt as vtmod
     ngroups = (batch + vtmod.DECODE_GROUP_ROWS - 1) // vtmod.DECODE_GROUP_ROWS
     return {"frames_per_s": round(16 * batch / dt, 2), "videos_per_s": round(batch / dt, 3), "batch_videos": batch,
             "seconds": round(dt, 3), "decoder_steps": 11 * 256, "decode_groups": ngroups,
             "group_streams": bool(vtmod.DECODE_GROUP_STREAMS) and ngroups > 1,
             "roofline": {"bound": "hbm", "achieved": round(kv_bytes / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(kv_bytes / dt / (HBM_PEAK_GBS * 1e9), 4), "traffic": None,
+                         "frac": round(kv_bytes / dt / (HBM_PEAK_GBS * 1e9), 4), "traffic": dec.get("hbm_bytes_per_launch"),
+                         "traffic_unit": "HBM bytes per lvt_attn_decode_kernel launch at B = 256, all 256 keys (rocprofv3 --pmc FETCH_SIZE "
+                                         "(x2) + WRITE_SIZE, profiles/r05_decode_attn_pmc_hbm_traffic.json; algorithmic K/V bytes of that "
+                                         "launch: %s): eager launches -- rocprofv3 --pmc crashes on the hipGraph replay of the generation run"
+                                         % dec.get("algorithmic_kv_bytes_per_launch"),
+                         "kernel_alone": {"achieved": round(dec["algorithmic_kv_bytes_per_launch"] / dec["avg_us_under_pmc"] / 1e3, 1),
+                                          "unit": "GB/s", "frac": round(dec["algorithmic_kv_bytes_per_launch"] / dec["avg_us_under_pmc"] / 1e3 / HBM_PEAK_GBS, 4)}
+                         if dec else None,
                          "kernel": "lvt_attn_decode_kernel (K/V-cache reads of the single-token decode attention); "
                                    "`achieved` = algorithmic K/V bytes of the whole run / END-TO-END wall time (encode, "
                                    "%d decode steps of ~110 launches each replayed as one hipGraph, decode of 16 frames); "
-                                   "the kernel alone streams the caches at 6.0 TB/s (profiles/r01_generation_kernel_mix.txt)"
+                                   "kernel mix of the steady replay: profiles/r05_generation_kernel_mix.txt"
                                    % (11 * 256)},
             "note": "5 priming + 11 generated frames per video; random-init weights; sampling is sequential (2816 "
                     "single-token decoder steps per group of <= 256 videos); videos are replicas across GPUs"}

@@ -2207,7 +2207,9 @@ extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const floa
     p.alpha = 1.f; p.flags = flags; p.bias = bias; p.res = res; p.ldr = g->Co; p.mask = mask; p.ldm = g->Co;
     p.splits = 1; p.g = *g;
     LVT_REQUIRE_AMAX(flags, ax, "conv3d_fwd"); set_amax(p, ax);
-    if (lvt_conv4s2_img_ok(g, flags) && lvt_aligned16(x) && lvt_aligned16(wp) && M * g->Co < (1LL << 40))
+    if (lvt_conv4s2_img_ok(g, flags) && lvt_aligned16(x) && lvt_aligned16(wp) && lvt_aligned16(y) &&
+        (!(flags & LVT_EPI_BIAS) || lvt_aligned16(bias)) && (!(flags & LVT_EPI_RESIDUAL) || lvt_aligned16(res)) &&
+        (!(flags & LVT_EPI_MASK) || lvt_aligned16(mask)) && M * g->Co < (1LL << 40))      // (an offset view of any of them: the tile kernel)
         return lvt_conv4s2_img_launch(g, x, wp, bias, res, mask, y, flags, ax->a, ax->b, ax->c, (hipStream_t)stream);
     {
         auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };

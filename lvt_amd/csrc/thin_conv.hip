@@ -461,7 +461,7 @@ extern "C" int lvt_convt4_fwd(const float *x, const float *w, const float *bias,
     LVT_REQUIRE(Ci % TC_CK == 0 && Cr >= 1 && Cr <= 3, "convT4_fwd: needs Ci %% 16 == 0 and 1..3 output channels");
     LVT_REQUIRE(!(flags & LVT_MATH_F16X2) || (ax && ax->a && ax->b), "convT4_fwd: LVT_MATH_F16X2 needs ax->a = max |x|, ax->b = max |w|");
     static const int no_mfma = getenv("LVT_NO_CONVT4_MFMA") ? 1 : 0;
-    if ((flags & LVT_MATH_F16X2) && !no_mfma && Ci == TM_CI && Hi % TM_R == 0 && Wi % TM_W == 0 && lvt_aligned16(x) &&
+    if ((flags & LVT_MATH_F16X2) && !no_mfma && Ci == TM_CI && Hi % TM_R == 0 && Wi % TM_W == 0 && lvt_aligned16(x) && lvt_aligned16(y) &&
         (long long)N * (Hi / TM_R) * (Wi / TM_W) < 0x7fffffffLL) {
         const long long nbands = (long long)N * (Hi / TM_R) * (Wi / TM_W);
         const unsigned grid = (unsigned)(nbands < LVT_NUM_CU ? nbands : LVT_NUM_CU);       // persistent: one workgroup per CU

@@ -246,8 +246,26 @@ def set_amax(t, slot):
 
 
 def drop_amax(t):
+    """EVERY wrapper of a kernel that rewrites a tensor in place through its raw pointer must call this (torch's `_version`
+    does not see such writes): the record of `t` and of the tensor it is a view of are forgotten.  LVT_AMAX_CHECK=1 verifies
+    every record that is used against the tensor (a debugging aid: it synchronises with the device on every engine call)."""
     if getattr(t, "_lvt_amax", None) is not None:
         t._lvt_amax = None
+    base = getattr(t, "_base", None)
+    if base is not None and getattr(base, "_lvt_amax", None) is not None:
+        base._lvt_amax = None
+
+
+AMAX_CHECK = bool(os.environ.get("LVT_AMAX_CHECK"))
+
+
+def _checked(slot, t):
+    if AMAX_CHECK:
+        have, real = float(slot), float(t.detach().abs().max()) if t.numel() else 0.0
+        if not have >= real:
+            raise LvtError("stale max |.| record: %g recorded, %g in the tensor of shape %s (an in-place kernel wrapper that "
+                           "did not call binding.drop_amax?)" % (have, real, tuple(t.shape)))
+    return slot
 
 
 def _valid_amax(t):
@@ -269,12 +287,12 @@ def amax_of(t):
     the part), else one lvt_amax pass whose result is cached on `t`."""
     slot = _valid_amax(t)
     if slot is not None:
-        return slot
+        return _checked(slot, t)
     base = t._base
     if base is not None:
         slot = _valid_amax(base)
         if slot is not None:
-            return slot
+            return _checked(slot, t)
     src = t
     if not t.is_contiguous():
         if base is None or not base.is_contiguous():

@@ -76,7 +76,11 @@ class VQVAEModel(AutoEncoderModel):
         # the decoder needs z_q_st only (pre-update codebook): the all-reduce of the EMA statistics that the quantiser
         # started runs beside the decoder forward and is joined afterwards (reference order of updates: vq_embedding.py:46-59)
         z_q_st = self.codebook.straight_through_cl(z_e, defer=True)
-        x_tilde = self.generator.forward_cl(z_q_st)
+        try:
+            x_tilde = self.generator.forward_cl(z_q_st)
+        except BaseException:
+            self.codebook.abandon_ema()     # (a failed decoder pass must not leave the quantiser unusable: join + drop the update)
+            raise
         z_q_bar = self.codebook.finish_ema()
         c = len(self.cfg.MODEL.PIXEL_MEAN)
         loss = {

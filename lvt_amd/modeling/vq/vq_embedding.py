@@ -132,6 +132,15 @@ class DVQEmbedding(nn.Module):
             vq.ema_finalize(stats, rsize, rsum, w, self.decay, self.eps)
         return vq.gather(idx, w).view(*self._pending_shape)      # from the POST-update codebook
 
+    def abandon_ema(self):
+        """Error path of a deferred pass: wait for the statistics all-reduce that was started and forget the pending update
+        (the codebook stays as it was before the pass)."""
+        pend = getattr(self, "_pending", None)
+        if pend is not None:
+            self._pending = None
+            if pend[2] is not None:
+                pend[2].wait()
+
     def embed_cl(self, latents):
         """(N,num,H,W) int64 -> (N,1,H,W,D) channels-last."""
         n, num, h, w = latents.shape

@@ -149,3 +149,37 @@ def test_deferred_ema_update_equals_the_blocking_form():
         assert torch.equal(v1, v2), k
     with pytest.raises(Exception):
         q2.finish_ema()                                     # nothing pending
+
+
+def test_in_place_softmax_drops_the_stale_record():
+    """lvt_attn_softmax_fwd rewrites the scores in place through a raw pointer; the max |q k^T| record of the
+    buffer must not survive it (with tiny q / k the probabilities, up to 1, would be scaled by a bound ~1e-6 and overflow
+    fp16).  The unfused three-launch path on tiny operands under f16x2, with every used record verified (LVT_AMAX_CHECK)."""
+    import math
+    from lvt_amd.hip import binding as L, gemm as G, tx
+    if L.get_math_mode() != "f16x2":
+        pytest.skip("f16x2 only")
+    B, H, S, da = 1, 8, 256, 128
+    hd = H * da
+    g = torch.Generator().manual_seed(3)
+    q, k, v = (torch.randn(B * S, hd, generator=g) * sc for sc in (1e-3, 1e-3, 1.0))
+    banks = [torch.zeros(H, 2 * n - 1) for n in (1, 16, 16)]
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    bd = [b.to(DEV) for b in banks]
+    old, L.AMAX_CHECK = L.AMAX_CHECK, True
+    try:
+        P = torch.empty(B, H, S, S, device=DEV)
+        G.gemm(qd, kd, P, S, S, da, ta=0, tb=0, lda=hd, ldb=hd, ldc=S, batch_outer=B, batch_inner=H,
+               sA=(S * hd, da), sB=(S * hd, da), sC=(H * S * S, S * S))
+        assert getattr(P, "_lvt_amax", None) is not None
+        tx.attn_softmax_fwd_(P, math.sqrt(da), bd[0], bd[1], bd[2], (1, 16, 16), False)
+        assert getattr(P, "_lvt_amax", None) is None
+        o = torch.empty(B * S, hd, device=DEV)
+        G.gemm(P, vd, o, S, da, S, ta=0, tb=1, lda=S, ldb=hd, ldc=hd, batch_outer=B, batch_inner=H,
+               sA=(H * S * S, S * S), sB=(S * hd, da), sC=(S * hd, da))
+    finally:
+        L.AMAX_CHECK = old
+    assert torch.isfinite(o).all()
+    ref = (torch.softmax((q.view(S, H, da).transpose(0, 1).double() @ k.view(S, H, da).transpose(0, 1).double().transpose(1, 2)) / math.sqrt(da), -1)
+           @ v.view(S, H, da).transpose(0, 1).double()).transpose(0, 1).reshape(S, hd)
+    assert float((o.double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-5

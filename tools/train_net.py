@@ -44,7 +44,9 @@ def default_argument_parser():
     p.add_argument("--data-dir", default="")
     p.add_argument("--synthetic", action="store_true")
     p.add_argument("--max-iter", type=int, default=None)
-    p.add_argument("--eval-batches", type=int, default=4, help="--eval-only: batches of the test loader per rank")
+    p.add_argument("--eval-batches", type=int, default=None,
+                   help="--eval-only: truncate the test loader to this many batches per rank (default: the whole test set, as "
+                        "the reference's test() does; synthetic data: 4)")
     p.add_argument("opts", default=None, nargs=argparse.REMAINDER)
     return p
 
@@ -106,8 +108,8 @@ def data_iterator(cfg, args):
 
 
 def test_batches(cfg, args):
-    """Finite test loader of --eval-only: `--eval-batches` batches of IMS_PER_BATCH / world samples per rank, in order (the
-    reference's InferenceSampler shards the dataset the same way), unmapped for the transformer apart from the frame
+    """Finite test loader of --eval-only: the whole test set (or `--eval-batches` batches) in batches of IMS_PER_BATCH / world
+    samples per rank, every rank a contiguous shard in order (the reference's InferenceSampler), unmapped for the transformer apart from the frame
     window (DatasetMapper(is_train=False): whole code clips, vidgen/data/dataset_mapper.py:113-149)."""
     world, rank = comm.get_world_size(), comm.get_rank()
     per_rank = max(1, cfg.SOLVER.IMS_PER_BATCH // world)
@@ -117,14 +119,14 @@ def test_batches(cfg, args):
         if args.synthetic or not args.data_dir:
             v = cfg.MODEL.AUTOREGRESSIVE.VT
             rng = np.random.default_rng(seed)
-            videos = [rng.integers(0, v.NV, (16, v.NC, 16, 16), dtype=np.int64) for _ in range(world * per_rank * args.eval_batches)]
+            videos = [rng.integers(0, v.NV, (16, v.NC, 16, 16), dtype=np.int64) for _ in range(world * per_rank * (args.eval_batches or 4))]
             load = lambda i: videos[i]                     # noqa: E731
             n = len(videos)
         else:
             vids = list_latent_videos(args.data_dir)
             load = lambda i: load_video_codes(vids[i][0], vids[i][1])      # noqa: E731
             n = len(vids)
-        idx = list(range(rank, n, world))[:per_rank * args.eval_batches]
+        idx = _shard(n, rank, world, None if args.eval_batches is None else per_rank * args.eval_batches)
         for b in range(0, len(idx), per_rank):
             batch = [mapper({"image_sequence": load(i), "video_idx": i}) for i in idx[b:b + per_rank]]
             batch = [d for d in batch if d is not None]
@@ -132,13 +134,21 @@ def test_batches(cfg, args):
                 yield batch
     else:
         if args.synthetic or not args.data_dir:
-            frames = np.random.default_rng(seed).random((world * per_rank * args.eval_batches, 3, 64, 64), dtype=np.float32)
+            frames = np.random.default_rng(seed).random((world * per_rank * (args.eval_batches or 4), 3, 64, 64), dtype=np.float32)
         else:
             frames = np.load(args.data_dir, mmap_mode="r")
         key = "image_sequence" if frames.ndim == 5 else "image"
-        idx = list(range(rank, len(frames), world))[:per_rank * args.eval_batches]
+        idx = _shard(len(frames), rank, world, None if args.eval_batches is None else per_rank * args.eval_batches)
         for b in range(0, len(idx), per_rank):
             yield [{key: np.asarray(frames[i], dtype=np.float32), "video_idx": i} for i in idx[b:b + per_rank]]
+
+
+def _shard(n, rank, world, limit):
+    """Indices of this rank: a CONTIGUOUS shard, as the reference's InferenceSampler cuts the test set
+    (vidgen/data/samplers/distributed_sampler.py: ceil(n / world) per rank), optionally truncated to `limit` samples."""
+    per = -(-n // world)
+    idx = list(range(min(rank * per, n), min((rank + 1) * per, n)))
+    return idx if limit is None else idx[:limit]
 
 
 def main(args):
