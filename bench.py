@@ -408,7 +408,7 @@ def vq_gates(vq, device, oracle_clips):
     enc = {"us_per_launch": round(vq_us, 1), "frames": frames,
            "hbm_frac": round(alg_bytes / (vq_us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4),
            "hbm_gbs": round(alg_bytes / (vq_us * 1e-6) / 1e9, 1),
-           "flop_frac": round(alg_flops / (vq_us * 1e-6) / 1e12 / engine_peak(mode, "attn_vq_search_runs_bf16x3"), 4),
+           "flop_frac": round(alg_flops / (vq_us * 1e-6) / 1e12 / engine_peak(mode, "vq_search"), 4),
            "tflops": round(alg_flops / (vq_us * 1e-6) / 1e12, 1),
            "note": "lvt_vq_nearest on the z_e of one timed batch (all four codebooks): algorithmic bytes 270,336 B/frame "
                    "against the 8 TB/s HBM peak and 33.5 M MAC/frame against the engine ceiling (SURVEY 8d: 248 FLOP/B)"}

@@ -250,10 +250,15 @@ int lvt_colsum(const float *g, long long M, int N, long long ld, float *out, voi
 /* ---- product vector quantiser (vidgen/modeling/vq/vq_utils.py:5-65, vq_embedding.py:9-99; K7-K9) ----
  * z: [rows][ldz] channels-last activations, group g owns columns [g*D, (g+1)*D).  codebooks: [num][KC][D].
  * idx: int64 [rows/P][num][P]  (== the reference's (N, num, H, W) layout with P = H*W).
- * lvt_vq_nearest: idx = argmin_k |e_k|^2 + |x|^2 - 2 x.e_k in fp32, lowest k on ties (torch.min).  In the default
- * (bf16x3) math mode (flags without LVT_MATH_F32) the product runs on the bf16 matrix cores, one workgroup per codebook half, and the per-half
- * (distance, index) candidates go through `workspace`; without a workspace, or in f32 mode, the fp32-MFMA kernel
- * with the whole codebook LDS-resident is used.                                                           */
+ * lvt_vq_nearest: idx = argmin_k |e_k|^2 + |x|^2 - 2 x.e_k, lowest k on ties (torch.min).  Three arithmetics, by `flags`:
+ *   LVT_MATH_F16X2 (the default mode of the Python side): argmax_k x.e_k - |e_k|^2 / 2 -- the same argmin, |x|^2 dropped --
+ *     on two fp16 planes of the codebook group (one power-of-two scale per group) and of every row (one scale per row), three
+ *     fp16 MFMAs per 16 dims, the whole group LDS-resident, indices written directly; no workspace needed;
+ *   neither math flag (bf16x3): the reference's distance form on the bf16 matrix cores, one workgroup per codebook half, the
+ *     per-half (distance, index) candidates go through `workspace`;
+ *   LVT_MATH_F32, or bf16x3 without a workspace: the fp32-MFMA kernel with the whole codebook LDS-resident.
+ * All three agree with an fp64 search wherever the top-2 distance gap exceeds 1e-5 (|x|^2 + max |e|^2); which code a closer
+ * pair resolves to is an artefact of the fp32 evaluation order in the reference as well.                       */
 size_t lvt_vq_nearest_workspace_bytes(long long rows, int num, int KC);
 int lvt_vq_nearest(const float *z, long long rows, int ldz, int num, int D, int KC,
                    const float *codebooks, long long *idx, int P, int flags, void *workspace, size_t workspace_bytes,

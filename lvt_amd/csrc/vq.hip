@@ -6,7 +6,9 @@
 //   lvt_vq_ema_accumulate   stats[g][k][0..D-1] = sum of x rows with idx k, stats[g][k][D] = count (LDS-private, no atomics)
 //   lvt_vq_ema_finalize     decay-lerp of running_size / running_sum, Laplace smoothing, new codebook
 //
-// vq_nearest on MI355X: one codebook group (512 x 64 fp32 = 128 KiB) is made LDS-resident
+// vq_nearest, three arithmetics (include/lvt_hip.h): the f16x2 kernel further down is the default of the Python side since
+// round 5 (103 us per 512 frames against 185 us for the bf16x3 kernel; profiles/r05_vq_f16x2_notes.txt).
+// f32 mode: one codebook group (512 x 64 fp32 = 128 KiB) is made LDS-resident
 // ([dim][code], conflict-free operand reads) by a persistent 8-wave workgroup; each wave walks
 // 32-row tiles, keeps its 32x64 activation fragment in VGPRs, runs the distance product on the fp32
 // matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 FMA chain) and folds a running (min, argmin)
@@ -14,6 +16,7 @@
 // and only the int64 indices are written: 270,336 algorithmic bytes per 64x64 frame.
 #include "lvt_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -490,6 +493,281 @@ __global__ __launch_bounds__(VQ_THREADS) void lvt_vq_nearest_coarse_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// vq_nearest, f16x2 arithmetic (round 5; LVT_MATH_F16X2 in `flags`, the default mode of the Python side).
+//   argmin_k ( |e_k|^2 + |x|^2 - 2 x.e_k )  ==  argmax_k ( x.e_k - |e_k|^2 / 2 ):   |x|^2 is common to a row's 512 candidates,
+//   so it is dropped instead of being added and rounded 512 times (the score's rounding is relative to |x.e| and |e|^2 only).
+// Operands: the codebook group as TWO fp16 planes under ONE power-of-two scale sE (max |e| sE in [2^14, 2^15)): hi = fp16(e sE),
+// lo = fp16(e sE - hi), 22 significant bits down to 2^-17 of the group's maximum; an activation row likewise under its OWN
+// scale sx.  x.e sE sx = lo hi + hi lo + hi hi: three v_mfma_f32_32x32x16_f16 per 16 dims into one fp32 accumulator (six bf16
+// MFMAs in the bf16x3 kernel above), and score = fma(-|e|^2 sE / 2, sx, acc): one FMA, one compare, one max, one select per
+// candidate.  2 x 72 KB of planes hold the WHOLE group: one workgroup per (group, row range), no half / merge passes, indices
+// written in their final layout.  Equal scores (duplicated codes give bit-identical planes, norms and accumulation orders)
+// resolve to the lowest index.
+// Schedule (what the measurements of round 5 asked for, profiles/r05_vq_f16x2_notes.txt):
+//   * the two waves of a SIMD run in lock step (same code, no barrier in the scan), so a wave that issues its MFMAs in one run
+//     and its selects in another leaves the matrix pipe idle during the selects of BOTH: the products of code tile i + 1 are
+//     issued BESIDE the selects of tile i (two accumulators), in a hand-fixed order -- four groups of {2 fragment reads,
+//     3 MFMAs, 4 FMAs, one 12-instruction select block}, each closed by a sched_barrier;
+//   * a wave owns 32 rows at a time and the raw rows of its NEXT tile are requested right after the split of the current one:
+//     z is read once, 134 MB per 512 frames, ~26 us of HBM time that otherwise sits in front of every scan (all waves load at
+//     once); 32-row tiles (not 64) leave the registers for that (32 raw + 32 operand + 32 accumulator + 64 fragment).
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 vqf_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 vqf_h2 __attribute__((ext_vector_type(2)));
+typedef float vqf_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned vqf_u4 __attribute__((ext_vector_type(4)));
+#define VQF_LD (VQ_D + 8)              // plane row stride (fp16): 144 B, conflict-free 16-byte fragment reads
+
+__device__ __forceinline__ float vqf_mix_lo(unsigned h, float c) {        // c - half(h.lo), exact
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(-1.f), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vqf_mix_hi(unsigned h, float c) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(-1.f), "v"(c));
+    return r;
+}
+// (a, b) * s -> packed fp16 hi pair and lo pair
+__device__ __forceinline__ void vqf_split_pair(float a, float b, float s, unsigned &ph, unsigned &pl) {
+    const vqf_f2 t = vqf_f2{a, b} * s;
+    ph = __builtin_bit_cast(unsigned, __builtin_convertvector(t, vqf_h2));
+    const vqf_f2 r = {vqf_mix_lo(ph, t.x), vqf_mix_hi(ph, t.y)};
+    pl = __builtin_bit_cast(unsigned, __builtin_convertvector(r, vqf_h2));
+}
+__device__ __forceinline__ float vqf_absmax4(const float4 a) { return fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))); }
+__device__ __forceinline__ int vqf_ebits(float nonneg) { return (int)((__float_as_uint(nonneg) >> 23) & 0xffu); }
+__device__ __forceinline__ float vqf_pow2(int field) { return __uint_as_float((unsigned)(field < 1 ? 1 : (field > 254 ? 254 : field)) << 23); }
+
+// Two consecutive candidate codes of one row against its running maximum `lb` (position of the maximum inside the code tile:
+// `lp`): compare, max, select per candidate.  Written out because the ORDER is the point: a VALU write of a lane mask needs two
+// wait states before a VALU reads it (gfx940+), and the compiler's own selection (VCC for every compare, an s_nop before every
+// select) spends more issue slots on s_nop than on MFMAs.  Here every select sits two instructions behind its compare.
+// A strict > keeps the lowest position among equal scores.  POS, POS + 1 are inline constants (0 .. 64).
+template <int POS>
+__device__ __forceinline__ void vqf_select2(float s0, float s1, float &lb, int &lp) {
+#ifdef VQF_X_NOSEL
+    lb = fmaxf(lb, s0 + s1); return;
+#endif
+    unsigned long long m0, m1;
+    asm("v_cmp_gt_f32_e64 %2, %4, %0\n\t"
+        "v_max_f32_e32 %0, %0, %4\n\t"
+        "v_cmp_gt_f32_e64 %3, %5, %0\n\t"
+        "v_cndmask_b32_e64 %1, %1, %6, %2\n\t"
+        "v_max_f32_e32 %0, %0, %5\n\t"
+        "v_cndmask_b32_e64 %1, %1, %7, %3"
+        : "+v"(lb), "+v"(lp), "=&s"(m0), "=&s"(m1)
+        : "v"(s0), "v"(s1), "n"(POS), "n"(POS + 1));
+}
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void vqf_static_for(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); vqf_static_for<N, I + 1>(f); }
+}
+
+template <int KC>
+__global__ __launch_bounds__(VQ_THREADS) void lvt_vq_nearest_f16x2_kernel(
+    const float *__restrict__ z, long long rows, int ldz, const float *__restrict__ codebooks, long long *__restrict__ idx_out,
+    int P, int num) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vqf_raw[];
+    constexpr int PL = KC * VQF_LD;
+    unsigned short *planes = reinterpret_cast<unsigned short *>(vqf_raw);            // [2][KC][VQF_LD]: hi, lo
+    float *hcb = reinterpret_cast<float *>(planes + 2 * PL);                         // [KC]  -|e|^2 sE / 2
+    float *red = hcb + KC;                                                           // [16]
+    const int g = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const float *E = codebooks + (long long)g * KC * VQ_D;
+
+    // a wave's 32-row tiles; the raw rows of the first one are requested before the codebook is staged.  A lane holds dims
+    // 16 s + 8 half .. + 7 (s = 0 .. 3) of row tile * 32 + l31: the B operand layout of the four 16-wide steps.  (Rows past the
+    // end are clamped to the last row: their columns of the product are computed and not stored.)
+    const long long ntiles = (rows + 31) / 32;
+    const long long tile0 = (long long)blockIdx.x * (VQ_THREADS / 64) + wave, tstride = (long long)gridDim.x * (VQ_THREADS / 64);
+    float4 raw[8];
+    auto load_rows = [&](long long tile) {
+        const long long row = tile * 32 + l31;
+        const float *zp = z + (row < rows ? row : rows - 1) * (long long)ldz + g * VQ_D + 8 * half;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            raw[2 * s] = *reinterpret_cast<const float4 *>(zp + 16 * s);
+            raw[2 * s + 1] = *reinterpret_cast<const float4 *>(zp + 16 * s + 4);
+        }
+    };
+    if (tile0 < ntiles) load_rows(tile0);
+
+    // ---- stage the group: thread (code = tid >> 1 (+ 256), dims 32 (tid & 1) ..); the group's max |e| first ----
+    {
+        constexpr int IT = KC > 256 ? KC / 256 : 1;
+        float4 ev[IT][8];
+        float sq[IT];
+        float m = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int code = ((tid >> 1) + 256 * it) & (KC - 1);                     // (KC = 128: threads 256 .. repeat codes 0 ..)
+            sq[it] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ev[it][u] = *reinterpret_cast<const float4 *>(E + (long long)code * VQ_D + 32 * (tid & 1) + 4 * u);
+                const float4 v = ev[it][u];
+                sq[it] = fmaf(v.x, v.x, sq[it]); sq[it] = fmaf(v.y, v.y, sq[it]); sq[it] = fmaf(v.z, v.z, sq[it]); sq[it] = fmaf(v.w, v.w, sq[it]);
+                m = fmaxf(m, vqf_absmax4(v));
+            }
+            sq[it] += __shfl_xor(sq[it], 1);        // (dims 0..31) + (dims 32..63)
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = red[0];
+#pragma unroll
+        for (int w = 1; w < VQ_THREADS / 64; ++w) m = fmaxf(m, red[w]);
+        const float sE = vqf_pow2(268 - vqf_ebits(m));                               // max |e| sE in [2^14, 2^15)
+        float hm = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int code = ((tid >> 1) + 256 * it) & (KC - 1);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                uint2 h, l;
+                vqf_split_pair(ev[it][u].x, ev[it][u].y, sE, h.x, l.x);
+                vqf_split_pair(ev[it][u].z, ev[it][u].w, sE, h.y, l.y);
+                unsigned short *dst = planes + code * VQF_LD + 32 * (tid & 1) + 4 * u;
+                *reinterpret_cast<uint2 *>(dst) = h;
+                *reinterpret_cast<uint2 *>(dst + PL) = l;
+            }
+            const float h = -0.5f * sq[it] * sE;
+            if ((tid & 1) == 0) hcb[code] = h;
+            hm = fmaxf(hm, fabsf(h));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) hm = fmaxf(hm, __shfl_xor(hm, o));
+        if (lane == 0) red[8 + wave] = hm;
+        __syncthreads();
+    }
+    float hm = red[8];
+#pragma unroll
+    for (int w = 1; w < VQ_THREADS / 64; ++w) hm = fmaxf(hm, red[8 + w]);
+    // a row's scale is capped so that |e|^2 sE sx / 2 stays below 2^100 (a row that is (nearly) zero against a large codebook)
+    const int sx_cap = 353 - vqf_ebits(hm);
+
+    // lane bases of the fragment reads (plane 1 lies 72 KB behind plane 0: beyond a DS offset field) and of the norm terms
+    const unsigned short *fr0 = planes + l31 * VQF_LD + 8 * half, *fr1 = fr0 + PL;
+    const float *hb = hcb + 4 * half;
+    constexpr int NT = KC / 32;                                                      // 16, 8 or 4 code tiles
+    constexpr std::true_type yes{};
+    constexpr std::false_type no{};
+
+    for (long long tile = tile0; tile < ntiles; tile += tstride) {
+        // B operand of the tile: hi and lo fragments of the four steps under the row's scale
+        vqf_h8 zb[4][2];
+        float sx;
+        {
+            float xm = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xm = fmaxf(xm, vqf_absmax4(raw[u]));
+            xm = fmaxf(xm, __shfl_xor(xm, 32));
+            const int f = 268 - vqf_ebits(xm);
+            sx = vqf_pow2(f < sx_cap ? f : sx_cap);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                vqf_u4 uh, ul;
+                unsigned a, b;
+                vqf_split_pair(raw[2 * s].x, raw[2 * s].y, sx, a, b); uh[0] = a; ul[0] = b;
+                vqf_split_pair(raw[2 * s].z, raw[2 * s].w, sx, a, b); uh[1] = a; ul[1] = b;
+                vqf_split_pair(raw[2 * s + 1].x, raw[2 * s + 1].y, sx, a, b); uh[2] = a; ul[2] = b;
+                vqf_split_pair(raw[2 * s + 1].z, raw[2 * s + 1].w, sx, a, b); uh[3] = a; ul[3] = b;
+                zb[s][0] = __builtin_bit_cast(vqf_h8, uh);
+                zb[s][1] = __builtin_bit_cast(vqf_h8, ul);
+            }
+        }
+#ifndef VQF_X_NOROWS
+        if (tile + tstride < ntiles) load_rows(tile + tstride);                      // in flight during the scan
+#endif
+
+        float best = -INFINITY, lb = 0.f;
+        int bidx = 0, lp = 0;
+        float4 hnext = *reinterpret_cast<const float4 *>(hb);                         // -|e|^2 sE / 2 of the next four candidates
+        // One STEP: the 12 MFMAs of code tile cp (accP) beside the selects of tile cs (accS, left by the previous step) and the
+        // reads of the fragments of tile cn (afN, multiplied by the next step).
+        auto step = [&](auto has_prod, auto has_sel, auto has_next, int cp, f32x16 &accP, const vqf_h8 (&afP)[4][2], int cs,
+                        const f32x16 &accS, int cn, vqf_h8 (&afN)[4][2]) {
+            constexpr bool PROD = decltype(has_prod)::value, SEL = decltype(has_sel)::value, NEXT = decltype(has_next)::value;
+            if constexpr (SEL) { lb = best; lp = 0; }
+            const unsigned short *f0 = fr0 + cn * 32 * VQF_LD, *f1 = fr1 + cn * 32 * VQF_LD;
+            const float *hs = hb + cs * 32, *hp = hb + cp * 32;
+            vqf_static_for<4>([&](auto ig) {
+                constexpr int G = decltype(ig)::value;
+                // The three MFMAs of a group are a dependent chain (one accumulator): a select block behind the first and the second,
+                // the LDS reads behind the third, each piece pinned by a sched_barrier (the compiler's order is MFMA MFMA MFMA, then
+                // all of the vector work: the wave then waits out two MFMA latencies with nothing to issue).
+                const float4 h4 = hnext;
+                if constexpr (PROD) {                                                 // smallest terms first: lo hi, hi lo, hi hi
+                    if constexpr (G == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        accP = __builtin_amdgcn_mfma_f32_32x32x16_f16(afP[G][1], zb[G][0], zero, 0, 0, 0);
+                    } else {
+                        accP = __builtin_amdgcn_mfma_f32_32x32x16_f16(afP[G][1], zb[G][0], accP, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // (the norm terms of the next group are requested now: a just-in-time read stalls the wave for the LDS round trip)
+                if constexpr (SEL && G < 3) hnext = *reinterpret_cast<const float4 *>(hs + 8 * (G + 1));
+                if constexpr (PROD && G == 3) hnext = *reinterpret_cast<const float4 *>(hp);
+                if constexpr (SEL) {                                                  // accumulator registers 4 G .. + 3 <-> codes 8 G .. + 3 (+ 4 half)
+                    vqf_select2<8 * G>(fmaf(h4.x, sx, accS[4 * G]), fmaf(h4.y, sx, accS[4 * G + 1]), lb, lp);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (PROD) {
+                    accP = __builtin_amdgcn_mfma_f32_32x32x16_f16(afP[G][0], zb[G][1], accP, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (SEL) {
+                    vqf_select2<8 * G + 2>(fmaf(h4.z, sx, accS[4 * G + 2]), fmaf(h4.w, sx, accS[4 * G + 3]), lb, lp);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (PROD) {
+                    accP = __builtin_amdgcn_mfma_f32_32x32x16_f16(afP[G][0], zb[G][0], accP, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#ifdef VQF_X_NOFRAG
+                if constexpr (NEXT) if (cn == 0) {
+#else
+                if constexpr (NEXT) {
+#endif
+                    afN[G][0] = *reinterpret_cast<const vqf_h8 *>(f0 + 16 * G);
+                    afN[G][1] = *reinterpret_cast<const vqf_h8 *>(f1 + 16 * G);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (SEL) {
+                const bool imp = lb > best;
+                best = lb;
+                bidx = imp ? cs * 32 + lp : bidx;                                     // (+ 4 half: added once at the end)
+            }
+        };
+        f32x16 accA, accB;
+        vqf_h8 afA[4][2], afB[4][2];
+        step(no, no, yes, 0, accA, afA, 0, accA, 0, afA);                             // fragments of tile 0
+        step(yes, no, yes, 0, accA, afA, 0, accA, 1, afB);                            // products of tile 0, fragments of tile 1
+#pragma unroll 1
+        for (int ct = 1; ct < NT - 1; ct += 2) {
+            step(yes, yes, yes, ct, accB, afB, ct - 1, accA, ct + 1, afA);
+            step(yes, yes, yes, ct + 1, accA, afA, ct, accB, ct + 2 < NT ? ct + 2 : NT - 1, afB);
+        }
+        step(yes, yes, no, NT - 1, accB, afB, NT - 2, accA, 0, afA);
+        step(no, yes, no, 0, accB, afB, NT - 1, accB, 0, afA);
+
+        // the other half-wave saw the other codes of every tile
+        bidx += 4 * half;
+        const float ob = __shfl_xor(best, 32);
+        const int oi = __shfl_xor(bidx, 32);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        const long long row = tile * 32 + l31;
+        if (half == 0 && row < rows) idx_out[((row / P) * num + g) * (long long)P + row % P] = bidx;
+    }
+}
+
 __global__ void lvt_vq_nearest_merge_kernel(const float *__restrict__ pbest, const int *__restrict__ pidx, long long rows,
                                             int num, int nparts, int P, long long *__restrict__ idx_out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -696,6 +974,24 @@ extern "C" int lvt_vq_nearest(const float *z, long long rows, int ldz, int num, 
         else if (KC == 256) hipLaunchKernelGGL(lvt_vq_nearest_coarse_kernel<256>, dim3(bpp, num), dim3(VQ_THREADS), 0, s, z, rows, ldz, codebooks, idx_out, P, num);
         else hipLaunchKernelGGL(lvt_vq_nearest_coarse_kernel<128>, dim3(bpp, num), dim3(VQ_THREADS), 0, s, z, rows, ldz, codebooks, idx_out, P, num);
         LVT_CHECK_LAUNCH("lvt_vq_nearest_coarse_kernel");
+        return LVT_OK;
+    }
+    if ((flags & LVT_MATH_F16X2) && !(flags & LVT_MATH_F32)) {
+        const long long need_ = lvt_cdiv((rows + 31) / 32, VQ_THREADS / 64);
+        int bpp = LVT_NUM_CU / num;                     // one workgroup per CU (LDS-bound)
+        if (bpp > need_) bpp = (int)need_;
+        if (bpp < 1) bpp = 1;
+        hipStream_t s = (hipStream_t)stream;
+        const int smem = 2 * KC * VQF_LD * (int)sizeof(unsigned short) + (KC + 16) * (int)sizeof(float);
+        hipError_t e;
+#define VQF_LAUNCH(KCV)                                                                                                \
+    e = hipFuncSetAttribute((const void *)lvt_vq_nearest_f16x2_kernel<KCV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+    if (e != hipSuccess) { lvt_set_error("vq_nearest: cannot get %d B LDS: %s", smem, hipGetErrorString(e));           \
+        return LVT_ELAUNCH; }                                                                                          \
+    hipLaunchKernelGGL(lvt_vq_nearest_f16x2_kernel<KCV>, dim3(bpp, num), dim3(VQ_THREADS), smem, s, z, rows, ldz, codebooks, idx_out, P, num);
+        if (KC == 512) { VQF_LAUNCH(512) } else if (KC == 256) { VQF_LAUNCH(256) } else { VQF_LAUNCH(128) }
+#undef VQF_LAUNCH
+        LVT_CHECK_LAUNCH("lvt_vq_nearest_f16x2_kernel");
         return LVT_OK;
     }
     if (!(flags & LVT_MATH_F32) && KC % VQH_CODES == 0 && workspace &&

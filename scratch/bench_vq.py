@@ -4,9 +4,10 @@ import torch
 from lvt_amd.hip import vq
 dev = "cuda:0"
 COARSE = os.environ.get("LVT_VQ_COARSE") == "1"
+FR = int(os.environ.get("FRAMES", "512"))
 torch.manual_seed(0)
 for scale, name in ((1.0 / 512, "init-like codebook U(-1/512, 1/512), z ~ N(0,1)"), (1.0, "codebook ~ N(0,1), z ~ N(0,1)")):
-    z = torch.randn(512 * 256, 256, device=dev)
+    z = torch.randn(FR * 256, 256, device=dev)
     cb = (torch.rand(4, 512, 64, device=dev) * 2 - 1) * scale if scale < 1 else torch.randn(4, 512, 64, device=dev)
     idx = vq.nearest(z, cb, 256, coarse=COARSE)
     # fp64 check
@@ -17,7 +18,7 @@ for scale, name in ((1.0 / 512, "init-like codebook U(-1/512, 1/512), z ~ N(0,1)
         for s0 in range(0, x.shape[0], 32768):
             d = (e ** 2).sum(1)[None] + (x[s0:s0 + 32768] ** 2).sum(1, keepdim=True) - 2 * x[s0:s0 + 32768] @ e.t()
             best[s0:s0 + 32768] = d.argmin(1)
-        mine = idx.view(512, 4, 256)[:, g].reshape(-1)
+        mine = idx.view(FR, 4, 256)[:, g].reshape(-1)
         bad += int((mine != best).sum())
     for _ in range(3): vq.nearest(z, cb, 256, coarse=COARSE)
     torch.cuda.synchronize()
@@ -26,4 +27,4 @@ for scale, name in ((1.0 / 512, "init-like codebook U(-1/512, 1/512), z ~ N(0,1)
     for _ in range(20): vq.nearest(z, cb, 256, coarse=COARSE)
     b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) / 20 * 1e3
-    print("%-50s %7.1f us  (%.2f TB/s of 270,336 B/frame)  rows differing from the fp64 argmin: %d of %d" % (name, us, 270336 * 512 / us / 1e6, bad, 4 * z.shape[0]))
+    print("%-50s %7.1f us  (%.2f TB/s of 270,336 B/frame)  rows differing from the fp64 argmin: %d of %d" % (name, us, 270336 * FR / us / 1e6, bad, 4 * z.shape[0]))

@@ -62,6 +62,40 @@ def test_vq_nearest_exact_ties_pick_lowest_index():
     assert idx[0, 0, :4].tolist() == [17, 17, 5, 17]
 
 
+@pytest.mark.parametrize("K", [128, 256, 512])
+def test_vq_nearest_f16x2_shapes_and_scales(K):
+    """The f16x2 search (csrc/vq.hip: lvt_vq_nearest_f16x2_kernel, argmax of x.e - |e|^2 / 2 on two fp16 planes under power-of-two
+    scales) against an fp64 search of the reference's distance (vq_utils.py:13-20) on rows with a clear margin: every codebook
+    size, three groups, a row count that is no multiple of the 32-row tile, operands 1e-20 .. 1e12 in size, all-zero rows (the
+    smallest-norm code), and agreement of the three arithmetic modes."""
+    from lvt_amd.hip import binding as L, vq
+    assert L.get_math_mode() == "f16x2"
+    torch.manual_seed(K)
+    P, n, num = 16, 7, 3                                             # 112 rows: three and a half 32-row tiles
+    for zs, es in ((1.0, 1.0), (1e-20, 1e10), (1e12, 1e12), (1e-15, 1e-15), (3.0, 1.0 / 512)):
+        z = torch.randn(n * P, num * 64) * zs
+        z[5] = 0                                                     # an all-zero row: nearest = the code of smallest norm
+        cb = torch.randn(num, K, 64) * es
+        idx = vq.nearest(z.to(DEV), cb.to(DEV), P).cpu()             # (n, num, P)
+        others = {}
+        for mode in ("f32", "bf16x3"):
+            L.set_math_mode(mode)
+            try:
+                others[mode] = vq.nearest(z.to(DEV), cb.to(DEV), P).cpu()
+            finally:
+                L.set_math_mode("f16x2")
+        for g in range(num):
+            rows = z[:, 64 * g:64 * g + 64]
+            ok = margin_ok(rows, cb[g]).view(n, P)
+            assert ok.float().mean() > 0.5, (K, zs, es, float(ok.float().mean()))
+            _, _, ref = O.vq_margin_fp64(rows, cb[g])
+            ref = ref.view(n, P)
+            assert torch.equal(idx[:, g][ok], ref[ok]), (K, zs, es, g)
+            for mode, o in others.items():
+                assert torch.equal(o[:, g][ok], ref[ok]), (mode, K, zs, es, g)
+            assert int(idx[0, g, 5]) == int((cb[g].double() ** 2).sum(-1).argmin())
+
+
 def test_g1_encoder(golden):
     g = golden("g1_encoder")
     model, enc, _, _ = vqvae_seeded(int(g["seed"]))
