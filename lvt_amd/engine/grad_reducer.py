@@ -2,11 +2,14 @@
 torch DistributedDataParallel: ae.py:69-73, vt.py:61-63).
 
 One process per GPU.  Parameters are grouped, in reverse registration order (the order their
-gradients become available in the backward pass), into flat buckets of >= `bucket_bytes`, and every
-`.grad` IS a view of its bucket slot: autograd accumulates straight into the bucket, so there is no
-copy-in, no copy-out and no separate 1/world pass (RCCL reduces with ReduceOp.AVG).  When the last
-gradient of a bucket has been accumulated the bucket is all-reduced asynchronously on a dedicated
-communication stream (RCCL drives all 7 xGMI links) while the remaining backward kernels run.
+gradients become available in the backward pass), into flat buckets of >= `bucket_bytes`.  Autograd hands
+every parameter a FRESH gradient tensor (`.grad` is None between steps, so nothing is accumulated on the
+compute stream); when the last gradient of a bucket has arrived, ONE multi-tensor copy moves the bucket's
+gradients into its flat buffer on the communication stream, the buffer is all-reduced there
+(ReduceOp.AVG: no separate 1/world pass; RCCL drives all 7 xGMI links) while the remaining backward kernels
+run, and `.grad` is re-pointed at the bucket slot -- the compute stream sees no copy, no add and no memset.
+(Round 4 kept `.grad` attached to a zeroed bucket view instead: autograd then ADDS every new gradient into
+it, one extra kernel per parameter on the compute stream -- 1.2 ms of a 50 ms step at 320 parameters.)
 
 Semantics are those of torch DDP, with no call required from the training loop
 (vidgen/engine/trainer.py:79-87 has none):
@@ -18,9 +21,10 @@ Semantics are those of torch DDP, with no call required from the training loop
     `wait()` for callers that read `.grad` themselves.  A gradient that arrives for a bucket whose
     previous reduction is still in flight (two `backward()` calls with none of (a)-(c) in between) is an
     ERROR, as it is in torch DDP: autograd has by then accumulated into memory the collective is reading.
-  * `optimizer.zero_grad(set_to_none=True)` (torch's default) detaches `.grad` from the bucket; the
-    next gradient is then moved into the slot once and `.grad` re-pointed -- still no copy-back.
-    `zero_()` restores the zero-copy path and is what `solver/fused.py` optimizers do.
+  * `optimizer.zero_grad(set_to_none=True)` (torch's default, and what `solver/fused.py` optimizers do) drops `.grad`;
+    the next backward's gradient is moved into the slot as above.  A gradient that is ALREADY the bucket view
+    (gradient accumulation: a second backward before the step; or `zero_grad(set_to_none=False)`) was accumulated in
+    place by autograd and needs no move.
 
 On CPU (gloo, used by the world_size-2 unit tests) the same logic runs with SUM + a division, because
 gloo has no AVG.
@@ -40,12 +44,14 @@ FORCE_SINGLE_RANK = bool(os.environ.get("LVT_DP_SINGLE_RANK"))
 
 
 class BucketedGradReducer:
-    def __init__(self, params, bucket_bytes=16 << 20, group=None, broadcast_params=True, reduce_single_rank=None):
+    def __init__(self, params, bucket_bytes=None, group=None, broadcast_params=True, reduce_single_rank=None):
         """reduce_single_rank: run the collectives also in a process group of ONE rank (they are identities there);
         tests use it to drive the RCCL code path -- AVG reduction, asynchronous work on the side stream, the joins -- on
         a single-GPU box."""
         self.params = [p for p in params if p.requires_grad]
         self.group = group
+        if bucket_bytes is None:
+            bucket_bytes = int(float(os.environ.get("LVT_DP_BUCKET_MB", "16")) * (1 << 20))
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._div = self.world
         if reduce_single_rank is None:
@@ -71,7 +77,8 @@ class BucketedGradReducer:
         self._comm_stream = None
         self.trace = None          # a list: every bucket launch / join appends (kind, bucket index, bytes, event) -- a HIP event on the
                                    # stream the collective / the join was issued on (scratch/dp_overlap_trace.py)
-        self.enabled = True        # False: gradients stay local (bench.py times a step without communication)
+        self.enabled = not os.environ.get("LVT_DP_REDUCERS_OFF")     # False: gradients stay local (bench.py times a step without
+                                   # communication; the environment switch does the same from the first step: timing only)
         # gloo (CPU unit tests, and the 2-ranks-on-one-GPU tests) has no AVG: SUM + one division there
         self._avg = self.world > 1 and dist.get_backend(group) == "nccl"
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
@@ -98,7 +105,8 @@ class BucketedGradReducer:
         dev, dt = plist[0].device, plist[0].dtype
         total = sum(p.numel() for p in plist)
         flat = torch.zeros(total, dtype=dt, device=dev)
-        b = {"flat": flat, "params": list(plist), "views": [], "pending": len(plist), "work": None, "index": len(self.buckets)}
+        b = {"flat": flat, "params": list(plist), "views": [], "pending": len(plist), "work": None, "index": len(self.buckets),
+             "moves": [], "hold": None}   # (parameter, view, fresh gradient) of this backward, copied by _launch
         off = 0
         for p in plist:
             v = flat[off:off + p.numel()].view_as(p)
@@ -116,21 +124,15 @@ class BucketedGradReducer:
         return self._comm_stream
 
     def zero_grad(self, only=None):
-        """Zero the gradients (of the parameters in `only`, default all) inside their buckets and keep `.grad`
-        attached to the slot: the zero-copy state.  Parameters that have no gradient keep `None` (an optimizer
-        skips them, as it does in the reference)."""
+        """Drop the gradients (of the parameters in `only`, default all): `.grad = None`, torch's set_to_none semantics.
+        The next backward then hands autograd-fresh tensors to the hooks (no accumulation kernel on the compute stream)."""
         if self.world == 1:
             return False
         self.wait()
         for b in self.buckets:
-            mine = [only is None or p in only for p in b["params"]]
-            if all(mine):
-                b["flat"].zero_()
-            for p, v, m in zip(b["params"], b["views"], mine):
-                if m and p.grad is not None:
-                    if not all(mine):
-                        v.zero_()
-                    p.grad = v
+            for p in b["params"]:
+                if only is None or p in only:
+                    p.grad = None
         return True
 
     @property
@@ -153,8 +155,7 @@ class BucketedGradReducer:
                 "reducer.wait() -- before calling backward() again (torch DDP has the same rule)")
         g = p.grad
         if g.data_ptr() != view.data_ptr():
-            view.copy_(g)                      # .grad was detached by zero_grad(set_to_none=True)
-            p.grad = view
+            b["moves"].append((p, view, g))    # a fresh tensor from autograd: moved into the slot by _launch, in one copy per bucket
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch(b)
@@ -163,30 +164,59 @@ class BucketedGradReducer:
         flat = b["flat"]
         cs = self._stream(flat.device)
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        moves, b["moves"] = b["moves"], []
         if cs is not None:
             cs.wait_stream(torch.cuda.current_stream(flat.device))
             with torch.cuda.stream(cs):
+                self._move(b, moves)
                 b["work"] = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
         else:
+            self._move(b, moves)
             b["work"] = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
         if self.trace is not None and cs is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(cs)               # completes when the collective of this bucket has
             self.trace.append(("allreduce_done", b["index"], flat.numel() * flat.element_size(), ev))
 
-    def _join(self, b):
-        b["work"].wait()
+    @staticmethod
+    def _move(b, moves):
+        """Fresh gradients -> their bucket slots (one multi-tensor copy on the current = communication stream), `.grad`
+        re-pointed at the slot.  Anything that reads `.grad` does so after a join, which orders it behind this copy; the
+        fresh tensors are kept alive until that join (cheaper than `record_stream`, which makes the caching allocator poll an
+        event for every one of them on later allocations)."""
+        if not moves:
+            return
+        with torch.no_grad():
+            torch._foreach_copy_([v for _, v, _ in moves], [g for _, _, g in moves])
+        for p, v, g in moves:
+            p.grad = v
+        b["hold"] = [g for _, _, g in moves]
+
+    def _join_all(self, todo):
+        """The collectives of `todo` joined with ONE wait of the compute stream: the communication stream waits for each of
+        them (c10d runs a collective on its own stream and `Work.wait()` orders the CURRENT stream behind it), the compute
+        stream then waits for the communication stream once -- a wait + an event per bucket on the compute stream cost
+        0.25 ms of a 12-bucket step."""
         cs = self._comm_stream
         if cs is not None:
-            torch.cuda.current_stream(cs.device).wait_stream(cs)
+            with torch.cuda.stream(cs):
+                for b in todo:
+                    b["work"].wait()
+            main = torch.cuda.current_stream(cs.device)
+            main.wait_stream(cs)
             if self.trace is not None:
                 ev = torch.cuda.Event(enable_timing=True)
-                ev.record(torch.cuda.current_stream(cs.device))
-                self.trace.append(("joined", b["index"], 0, ev))
-        if not self._avg:
-            b["flat"].div_(self._div)
-        b["work"] = None
-        b["pending"] = len(b["params"])
+                ev.record(main)
+                self.trace.append(("joined", todo[-1]["index"], 0, ev))
+        else:
+            for b in todo:
+                b["work"].wait()
+        for b in todo:
+            if not self._avg:
+                b["flat"].div_(self._div)
+            b["work"] = None
+            b["hold"] = None               # (the compute stream is now ordered behind the copy that read them)
+            b["pending"] = len(b["params"])
 
     def wait(self):
         """Join outstanding all-reduces; afterwards every `.grad` holds the cross-rank mean."""
@@ -196,6 +226,6 @@ class BucketedGradReducer:
         for b in self.buckets:
             if b["work"] is None and 0 < b["pending"] < len(b["params"]):
                 self._launch(b)
-        for b in self.buckets:
-            if b["work"] is not None:
-                self._join(b)
+        todo = [b for b in self.buckets if b["work"] is not None]
+        if todo:
+            self._join_all(todo)

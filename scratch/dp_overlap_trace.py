@@ -36,7 +36,10 @@ for i in range(steps):
     with EventStorage(i):
         loss = leg.model.compute_supervised_loss(ctx, sl, sidx, ign)["loss_cross_entropy"]
     ev["fwd_end"].record()
+    import time
+    h0 = time.perf_counter()
     loss.backward()
+    host_bwd_ms = (time.perf_counter() - h0) * 1e3          # host time of backward(): below the GPU's when the host runs ahead
     ev["bwd_end"].record()
     for o in leg.optimizers:
         o["optimizer"].step()
@@ -46,7 +49,8 @@ for i in range(steps):
     torch.cuda.synchronize()
     tr, r.trace = r.trace, None
     t = lambda e: ev["t0"].elapsed_time(e)
-    print("step %d: forward ends %.2f ms, backward ends %.2f ms, step ends %.2f ms" % (i, t(ev["fwd_end"]), t(ev["bwd_end"]), t(ev["step_end"])))
+    print("step %d: forward ends %.2f ms, backward ends %.2f ms (host returned from backward() after %.2f ms), step ends %.2f ms"
+          % (i, t(ev["fwd_end"]), t(ev["bwd_end"]), host_bwd_ms, t(ev["step_end"])))
     for kind, bi, nbytes, e in tr:
         if kind == "allreduce_done":
             print("    bucket %2d (%6.1f MB) runnable at %7.2f ms = %6.2f ms BEFORE the backward pass ends" % (bi, nbytes / 1e6, t(e), t(ev["bwd_end"]) - t(e)))

@@ -231,10 +231,13 @@ def _rccl_single_rank_worker(port, ret):
             if (it + 1) % 2 == 0:
                 for o in optimizers:
                     o["optimizer"].step()          # joins through the pre-step hook
+                # what the optimizer just read: every gradient lives in its bucket slot (moved there on the side stream)
+                views = sum(int(p.grad is not None and p.grad.data_ptr() == red._slot[p][1].data_ptr()) for p in red.params)
                 for o in optimizers:
                     o["optimizer"].zero_grad()
+                dropped = sum(int(p.grad is None) for p in red.params)
         torch.cuda.synchronize()
-        views = sum(int(p.grad is not None and p.grad.data_ptr() == red._slot[p][1].data_ptr()) for p in red.params)
+        assert dropped == len(red.params)          # .grad is None between steps: the next backward accumulates nothing
         # the same first backward without any reducer
         torch.manual_seed(5)
         plain = build_model(cfg)
@@ -250,8 +253,8 @@ def _rccl_single_rank_worker(port, ret):
 
 def test_reducer_on_rccl_backend_single_rank():
     """The RCCL-specific code of the gradient reducer (ReduceOp.AVG, asynchronous all-reduce per bucket on the side stream
-    launched from gradient hooks, joins by the optimizer pre-step hook and at the next forward, in-place zero_grad with the
-    gradients staying bucket views) in a one-rank `nccl` group: a single-GPU box cannot host two RCCL ranks, and with one
+    launched from gradient hooks, joins by the optimizer pre-step hook and at the next forward, gradients moved into their
+    bucket slots on the side stream) in a one-rank `nccl` group: a single-GPU box cannot host two RCCL ranks, and with one
     rank every collective is an identity, so the averaged gradients must equal the plain ones."""
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
@@ -260,5 +263,5 @@ def test_reducer_on_rccl_backend_single_rank():
     p.join(600)
     assert p.exitcode == 0
     views, nparams, worst, loss = ret["out"]
-    assert views > 0.9 * nparams                  # after zero_grad the gradients are views of the buckets again
+    assert views > 0.9 * nparams                  # at optimizer.step() the gradients are views of the buckets
     assert worst < 1e-6 and loss == loss
