@@ -31,6 +31,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #ifndef LVT_WG_ANTIPHASE_MODES
 #define LVT_WG_ANTIPHASE_MODES 2         // bit MODE: the stride-2 kernel (24 MFMAs per staged row) gains, the 3x3 one (54) does not
 #endif
+#ifndef LVT_WG_S2_PAIR
+#define LVT_WG_S2_PAIR 1                 // stride-2 kernel in f16x2: two parity classes per workgroup (0: one, the round-4 form)
+#endif
 #define LVT_WG_ANTIPHASE(mode) (((LVT_WG_ANTIPHASE_MODES) >> (mode)) & 1)
 
 struct WgParams {
@@ -52,6 +55,9 @@ struct WgParams {
 //         channels): a workgroup owns ONE parity class (ky & 1, kx & 1) of the sixteen taps -- its four taps (ky >> 1, kx >> 1)
 //         are row / column offsets 0..1 into the 17x17 sub-image in[2r + py - 1][2c + px - 1] of the big frame, which is the
 //         patch here.  blockIdx decodes to (class, chunk, split); partial rows are (tap16 = ky * 4 + kx, c_patch).
+//         f16x2 (two planes: room for a second patch image): a workgroup owns the TWO classes (py, 0) and (py, 1) -- eight taps,
+//         24 MFMAs per staged slab row instead of 12 (the slab row costs the same fetch + split + store whatever is multiplied
+//         with it, and with 12 MFMAs per row that staging bounded the kernel: 218 TFLOP/s against 388 for the nine-tap form).
 
 __device__ __forceinline__ unsigned wg_cvt_pk(float lo, float hi) {
     unsigned r;
@@ -116,10 +122,11 @@ __device__ __forceinline__ bf16x8 wg_frag(const unsigned short *p, int pitch4) {
 
 template <int MODE, int MATH>
 __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const WgParams p) {
-    constexpr int NTAPS = MODE == 0 ? 9 : 4;
+    constexpr int NCLS = (MODE == 1 && MATH == 2 && LVT_WG_S2_PAIR) ? 2 : 1;         // parity classes (patch images) per workgroup
+    constexpr int NTAPS = MODE == 0 ? 9 : 4 * NCLS;
     constexpr int NP = MATH == 2 ? 2 : 3;
-    __shared__ __attribute__((aligned(16))) unsigned short lds[NP * WG_PPL + 2 * NP * WG_QPL];
-    unsigned short *patch = lds, *slab0 = lds + NP * WG_PPL;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[NCLS * NP * WG_PPL + 2 * NP * WG_QPL];
+    unsigned short *patch = lds, *slab0 = lds + NCLS * NP * WG_PPL;
     int unscale = 0;
     float sp = 1.f, sq = 1.f;
     if (MATH == 2) { sp = wg_f16_scale(p.p_amax, unscale); sq = wg_f16_scale(p.q_amax, unscale); }
@@ -159,48 +166,52 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
     // the slab operand, the same patch pixels), so the split index is the fast one -- its low bits pick the XCD
     const int nsplits = p.nsplits;
     const int split = blockIdx.x % nsplits;
-    const int pc = MODE == 1 ? (blockIdx.x / nsplits) >> 2 : blockIdx.x / nsplits;       // 32-channel chunk of the patch operand
-    const int cls = MODE == 1 ? (blockIdx.x / nsplits) & 3 : 0;                          // parity class (py, px)
+    const int job = blockIdx.x / nsplits;
+    const int pc = MODE == 1 ? (NCLS == 2 ? job >> 1 : job >> 2) : job;                  // 32-channel chunk of the patch operand
+    const int cls = MODE == 1 ? (NCLS == 2 ? (job & 1) << 1 : job & 3) : 0;              // (first) parity class (py, px)
     const int f0 = split * p.frames_per_split, f1 = min(p.N, f0 + p.frames_per_split);
     const int Cp = p.Cp;
 
-    constexpr int PUNITS = WG_PIX * 8, PPASS = (PUNITS + WG_THREADS - 1) / WG_THREADS;
-    float4 pv[PPASS], qv[2];
+    // (MODE 1 walks the 17x17 pixels its taps read, placed at the 18-pixel pitch: 5 passes instead of 6, 8 registers per image)
+    constexpr int PWALK = MODE == 1 ? 17 : WG_PW;
+    constexpr int PUNITS = PWALK * PWALK * 8, PPASS = (PUNITS + WG_THREADS - 1) / WG_THREADS;
+    float4 pv[NCLS][PPASS], qv[2];
     // (a thread stages the same channel quad tid & 7 of every patch pixel it touches)
     const bool sum_p = p.sum_mode == 2;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto patch_fetch = [&](int f) {
+    auto patch_fetch = [&](int f, int c) {         // c: image of class cls + c
         const float *xf = p.P + (long long)f * (MODE == 1 ? 1024 : 256) * Cp + pc * 32;
 #pragma unroll
         for (int j = 0; j < PPASS; ++j) {
             const int u = tid + WG_THREADS * j;
             const int pp = u >> 3, q = u & 7;
-            const int py = pp / WG_PW, px = pp - py * WG_PW;
+            const int py = pp / PWALK, px = pp - py * PWALK;
             if (MODE == 1) {
-                const int iy = 2 * py + (cls >> 1) - 1, ix = 2 * px + (cls & 1) - 1;
-                const bool ok = u < PUNITS && py < 17 && px < 17 && (unsigned)iy < 32u && (unsigned)ix < 32u;
-                pv[j] = ok ? *reinterpret_cast<const float4 *>(xf + (iy * 32 + ix) * Cp + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int iy = 2 * py + (cls >> 1) - 1, ix = 2 * px + ((cls + c) & 1) - 1;
+                const bool ok = u < PUNITS && (unsigned)iy < 32u && (unsigned)ix < 32u;
+                pv[c][j] = ok ? *reinterpret_cast<const float4 *>(xf + (iy * 32 + ix) * Cp + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 const bool ok = u < PUNITS && (unsigned)(py - 1) < 16u && (unsigned)(px - 1) < 16u;
-                pv[j] = ok ? *reinterpret_cast<const float4 *>(xf + ((py - 1) * 16 + (px - 1)) * Cp + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                pv[c][j] = ok ? *reinterpret_cast<const float4 *>(xf + ((py - 1) * 16 + (px - 1)) * Cp + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
-    auto patch_store = [&]() {
+    auto patch_store = [&](int c) {
 #pragma unroll
         for (int j = 0; j < PPASS; ++j) {
             const int u = tid + WG_THREADS * j;
             if (u < PUNITS) {
-                if (sum_p) { cs.x += pv[j].x; cs.y += pv[j].y; cs.z += pv[j].z; cs.w += pv[j].w; }    // (halo / out-of-range: zeros)
-                unsigned short *d = patch + (u >> 3) * WG_PP + (u & 7) * 4;
+                if (sum_p) { cs.x += pv[c][j].x; cs.y += pv[c][j].y; cs.z += pv[c][j].z; cs.w += pv[c][j].w; }    // (halo / out-of-range: zeros)
+                const int pp = u >> 3;
+                unsigned short *d = patch + c * (NP * WG_PPL) + (MODE == 1 ? pp + pp / PWALK : pp) * WG_PP + (u & 7) * 4;
                 if (MATH == 2) {
                     uint2 ph, pl;
-                    wg_split2(pv[j], sp, ph, pl);
+                    wg_split2(pv[c][j], sp, ph, pl);
                     *reinterpret_cast<uint2 *>(d) = ph;
                     *reinterpret_cast<uint2 *>(d + WG_PPL) = pl;
                 } else {
                     uint2 p1, p2, p3;
-                    wg_split4(pv[j], p1, p2, p3);
+                    wg_split4(pv[c][j], p1, p2, p3);
                     *reinterpret_cast<uint2 *>(d) = p1;
                     *reinterpret_cast<uint2 *>(d + WG_PPL) = p2;
                     *reinterpret_cast<uint2 *>(d + 2 * WG_PPL) = p3;
@@ -250,12 +261,16 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
     // split / store the next slab row and then both queue on the matrix pipe.  Waves 4..7 ("early") therefore store row r + 1
     // BEFORE their MFMAs of row r (their fetch runs two rows ahead), waves 0..3 after them: on every SIMD one wave converts
     // while the other multiplies.  (Both orders sit between the same two barriers; each thread stores its own part of a row.)
-    const bool early = LVT_WG_ANTIPHASE(MODE) && ((wave >> 2) & 1);
+    const bool early = LVT_WG_ANTIPHASE(MODE) && NCLS == 1 && ((wave >> 2) & 1);     // (two images: 24 MFMAs per row in f16x2, in phase is 2 % faster)
     const int r_end = f1 * 16;
     auto slab_fetch_row = [&](int r) { if (r < r_end) slab_fetch(r >> 4, r & 15); };
     if (f0 < f1) {
-        patch_fetch(f0); slab_fetch(f0, 0);
-        patch_store(); slab_store(slab0);
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) patch_fetch(f0, c);
+        slab_fetch(f0, 0);
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) patch_store(c);
+        slab_store(slab0);
         if (early) slab_fetch_row(f0 * 16 + 1);
     }
     __syncthreads();
@@ -271,7 +286,9 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
             } else {
                 slab_fetch_row(r + 1);
             }
-            if (last_row && next_frame) patch_fetch(f + 1);
+            // (two images: the second one is requested a row earlier, so that its 6 loads are not queued behind the first one's)
+            if (NCLS == 2 && y == 14 && next_frame) patch_fetch(f + 1, 1);
+            if (last_row && next_frame) patch_fetch(f + 1, 0);
             const unsigned short *slab = slab0 + buf * (NP * WG_QPL);
             bf16x8 b[NP];
 #pragma unroll
@@ -279,20 +296,22 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
             constexpr int TD = MODE == 0 ? 3 : 2;                                         // taps per dimension
             if constexpr (MATH == 2) {
 #pragma unroll
+                for (int c = 0; c < NCLS; ++c)
+#pragma unroll
                 for (int dy = 0; dy < TD; ++dy) {
                     bf16x8 a[TD][2];
 #pragma unroll
                     for (int dx = 0; dx < TD; ++dx)
 #pragma unroll
                         for (int q = 0; q < 2; ++q)
-                            a[dx][q] = wg_frag(patch + ((y + dy) * WG_PW + dx) * WG_PP + aoff + q * WG_PPL, 4 * WG_PP);
+                            a[dx][q] = wg_frag(patch + c * (NP * WG_PPL) + ((y + dy) * WG_PW + dx) * WG_PP + aoff + q * WG_PPL, 4 * WG_PP);
                     constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};                    // lo hi, hi lo, hi hi
 #pragma unroll
                     for (int t = 0; t < 3; ++t)
 #pragma unroll
                         for (int dx = 0; dx < TD; ++dx)
-                            acc[dy * TD + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                                __builtin_bit_cast(f16x8, a[dx][TA[t]]), __builtin_bit_cast(f16x8, b[TB[t]]), acc[dy * TD + dx], 0, 0, 0);
+                            acc[(c * TD + dy) * TD + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                __builtin_bit_cast(f16x8, a[dx][TA[t]]), __builtin_bit_cast(f16x8, b[TB[t]]), acc[(c * TD + dy) * TD + dx], 0, 0, 0);
                 }
             } else {
 #pragma unroll
@@ -315,7 +334,8 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
             if (!early && r + 1 < r_end) slab_store(slab0 + (buf ^ 1) * (NP * WG_QPL));
             if (last_row && next_frame) {
                 __syncthreads();             // every wave is done with this frame's patch
-                patch_store();
+#pragma unroll
+                for (int c = 0; c < NCLS; ++c) patch_store(c);
             }
             __syncthreads();
             buf ^= 1;
@@ -330,7 +350,8 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
         if (tid < 32) {
             float t = 0.f;
             for (int i = 0; i < WG_THREADS / 8; ++i) t += scratch[(i * 8 + (tid >> 2)) * 4 + (tid & 3)];
-            p.colsum_partial[((long long)split * (MODE == 1 ? 4 : 1) + cls) * Cp + pc * 32 + tid] = t;
+            // (MODE 1: one partial row per (split, class) or, with two images per workgroup, per (split, py))
+            p.colsum_partial[((long long)split * (MODE == 1 ? 4 / NCLS : 1) + (NCLS == 2 ? cls >> 1 : cls)) * Cp + pc * 32 + tid] = t;
         }
     }
     // partial[split][tap * Cp + pc * 32 + m][32 * wave + n]: lane = column n, 16 rows m per register file
@@ -338,7 +359,8 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
         // MODE 1: accumulator (a, b) of class (py, px) is tap (ky, kx) = (2a + py, 2b + px) of the 4x4 kernel
-        const int trow = MODE == 0 ? t : (2 * (t >> 1) + (cls >> 1)) * 4 + 2 * (t & 1) + (cls & 1);
+        // (two images: accumulator (c, a, b) belongs to class cls + c)
+        const int trow = MODE == 0 ? t : (2 * ((t >> 1) & 1) + (cls >> 1)) * 4 + 2 * (t & 1) + ((cls + (t >> 2)) & 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -393,8 +415,9 @@ static int wg_role(const lvt_conv_geom *g, int flags = 0) {
         return 3;
     return 0;
 }
-static int wg_splits(const lvt_conv_geom *g, int role) {
-    const int jobs = role == 3 ? 4 * (g->Ci / 32) : (role == 1 ? g->Ci : g->Co) / 32;
+static int wg_splits(const lvt_conv_geom *g, int role, bool f16) {
+    // (role 3: four parity classes per chunk, two per workgroup in f16x2)
+    const int jobs = role == 3 ? (f16 && LVT_WG_S2_PAIR ? 2 : 4) * (g->Ci / 32) : (role == 1 ? g->Ci : g->Co) / 32;
     int s = 256 / jobs;                            // one workgroup per CU (118 KB of LDS each): a single full wave
     if (s > g->N) s = g->N;
     return s < 1 ? 1 : s;
@@ -404,7 +427,7 @@ size_t lvt_wgrad_frames_workspace_bytes(const lvt_conv_geom *g) {
     const int role = wg_role(g);
     if (!role) return 0;
     const size_t bias_rows = (size_t)WG_SUM_PARTS * g->Co > (size_t)4 * g->Ci ? (size_t)WG_SUM_PARTS * g->Co : (size_t)4 * g->Ci;
-    return (size_t)wg_splits(g, role) * ((size_t)g->Kh * g->Kw * g->Ci * g->Co + bias_rows) * sizeof(float);     // + the bias partials
+    return (size_t)wg_splits(g, role, true) * ((size_t)g->Kh * g->Kw * g->Ci * g->Co + bias_rows) * sizeof(float);     // + the bias partials
 }
 int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float *dy, float *dw, int Ci_real, int Co_real,
                             void *workspace, hipStream_t s, void (*unpack_plain)(const float *, long long, int, float *,
@@ -416,15 +439,16 @@ int lvt_wgrad_frames_launch(const lvt_conv_geom *g, const float *x, const float 
     p.P = role == 2 ? dy : x; p.Q = role == 2 ? x : dy;
     p.p_amax = role == 2 ? dy_amax : x_amax; p.q_amax = role == 2 ? x_amax : dy_amax;
     p.Cp = role == 2 ? g->Co : g->Ci; p.N = g->N; p.nchunks = p.Cp / 32;
-    const int splits = wg_splits(g, role);
+    const int splits = wg_splits(g, role, f16);
+    const int ncls = role == 3 ? (f16 && LVT_WG_S2_PAIR ? 2 : 4) : 1;         // class jobs per chunk
     p.frames_per_split = (g->N + splits - 1) / splits;
     p.partial = (float *)workspace; p.partial_stride = (long long)g->Kh * g->Kw * g->Ci * g->Co;
     // dy is the patch operand in role 2, the slab (256 = Co channels) otherwise; x (db_of_x: role 3 only) is the patch operand there
     p.sum_mode = db ? ((role == 2 || db_of_x) ? 2 : 1) : 0;
     p.colsum_partial = p.partial + (long long)splits * p.partial_stride;
     p.nsplits = splits;
-    p.nmain = (role == 3 ? 4 : 1) * p.nchunks * splits;
-    p.nsum = p.sum_mode == 1 ? WG_SUM_PARTS * splits : (role == 3 ? 4 * splits : splits);
+    p.nmain = ncls * p.nchunks * splits;
+    p.nsum = p.sum_mode == 1 ? WG_SUM_PARTS * splits : ncls * splits;
     const unsigned grid = (unsigned)(p.nmain + (p.sum_mode == 1 ? p.nsum : 0));
     if (role == 3 && f16)
         hipLaunchKernelGGL((lvt_conv_wgrad_frames_kernel<1, 2>), dim3(grid), dim3(WG_THREADS), 0, s, p);
