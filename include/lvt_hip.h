@@ -33,7 +33,7 @@ extern "C" {
 #define LVT_ENODEVICE   (-4)   /* no gfx950 device visible                             */
 
 const char *lvt_last_error(void);
-int lvt_version(void);          /* 500 = round 5 (ABI changes are listed in INTEGRATION.md) */
+int lvt_version(void);          /* 510 = round 5 (ABI changes are listed in INTEGRATION.md) */
 /* Device probe: name, CU count, clock (kHz), HBM bytes.  Returns LVT_ENODEVICE without a GPU. */
 int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long long *hbm_bytes);
 
@@ -366,6 +366,9 @@ int lvt_attn_bwd_planes(const void *qkv_planes, long long plane_stride, long lon
  * forward : o, and `stats` (2, B*H*S) fp32: row max m of the biased (masked) scores, then 1 / sum_j exp(score - m).
  * backward: dq, dk, dv and the bank gradients ddt (H, 2bt-1), ddh (H, 2bh-1), ddw (H, 2bw-1); P and dS are recomputed from
  *           q, k, v, d_o and `stats` in both backward launches (workspace: one float per row + the per-workgroup bank sums).
+ *           `o` (ABI 510): the forward's output (row stride ld).  With it the softmax-backward row term delta_i = sum_j P_ij dP_ij
+ *           is taken as dO_i . O_i and the query-stationary launch makes ONE pass over the keys (three score-sized products
+ *           instead of five); o == NULL keeps the two-pass form, which derives delta from the dP values it recomputes.
  * Operands are split in-kernel into two fp16 terms under an exact power-of-two scale PER ROW (token x head, 128 values):
  * 22 bits + sign for every element within 2^-16 of its row's max |.|, absolute error <= 2^-39 of the row max below that;
  * three fp16 MFMAs per product, fp32 accumulation.  S == 256, da == 128, (bt,bh,bw) in {(1,16,16), (4,8,8)}, B*H % 8 == 0.
@@ -376,7 +379,7 @@ int lvt_attn_fwd_flash(const float *q, const float *k, const float *v, long long
                        int masked, float fill, float *o, float *stats, float *o_amax, void *stream);
 size_t lvt_attn_bwd_flash_workspace_bytes(int B, int H, int S, int bt, int bh, int bw);
 int lvt_attn_bwd_flash(const float *q, const float *k, const float *v, const float *d_o, long long ld, const float *stats,
-                       int B, int H, int S, int da, float temper, const float *dt, const float *dh, const float *dw,
+                       const float *o, int B, int H, int S, int da, float temper, const float *dt, const float *dh, const float *dw,
                        int bt, int bh, int bw, int masked, float fill, float *dq, float *dk, float *dv, float *ddt,
                        float *ddh, float *ddw, float *d_amax, void *workspace, size_t workspace_bytes, void *stream);
 

@@ -454,7 +454,21 @@ __global__ __launch_bounds__(512, 1) void lvt_attn_fwd_flash_kernel(const FaArgs
 // ===========================================================================================================================
 // backward A: delta, dQ, bias-bank partial sums (query-stationary)
 // ===========================================================================================================================
-template <int BT, int BH, int BW, int MASKED, int NCH>
+// ONEP = 1 (round 5): ONE pass over the keys.  delta_i = sum_j P_ij dP_ij = dO_i . O_i comes from the forward's output row (the
+// identity every flash backward uses; O carries the same 2^-22-class error as the recomputed dP), and what pass 1 also supplied --
+// the bound of g and the largest K-row scale, both needed to put g K into fp16 terms -- becomes ONE running power-of-two scale per
+// query row: t_ij = g_ij 2^(e_Kj - 14) is formed unscaled, the chunk's max |t| moves the exponent, and dQ's accumulator is
+// rescaled (exactly) when it moves, as the forward rescales O.  Three score-sized products instead of five, K and V staged once.
+// What the first pass also bought is CONSISTENCY: with delta2_i = sum_j p_ij dP_ij from the very dP values of pass 2 the row sums of
+// g vanish; dO . O differs from it by eps_i ~ 2^-22 sum_j |p dP| (p and dO are rounded to 22 bits at different places of the two
+// evaluations), and -eps_i sum_j p_ij K_j is an error COMMON to a row of dQ -- 1.06x over the gradient tolerance of the first
+// encoder layer's w_q (tests/test_gpu_vt.py, G12).  The pass therefore also accumulates C_i = sum_j p_ij K_j at fp16 precision
+// (one MFMA per 16 dims on the hi plane of the K^T fragments that dQ loads anyway) and the realised row sum eps_i = sum_j g_ij,
+// returns dQ_i - eps_i C_i / temper, and hands kernel B delta + eps (B then forms g as the two-pass form did).
+#ifndef LVT_FA_A_CORR
+#define LVT_FA_A_CORR 1                   // (timing builds: 0 = one pass without the C_i accumulation -- fails G12's w_q bound)
+#endif
+template <int BT, int BH, int BW, int MASKED, int NCH, int ONEP>
 __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo16<BH, BW>::HP + 4> &sm, int bh_, int qhalf) {
     using GE = Geo16<BH, BW>;
     using BI = BankIdx<BT, BH, BW>;
@@ -467,7 +481,7 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
     const long long row0 = (long long)b * AT_S;
     const int il = wave * 16 + c16, i = qhalf * 128 + il;
     const float *kbase = A.k + row0 * A.ld + h * AT_D, *vbase = A.v + row0 * A.ld + h * AT_D;
-    constexpr int NIT = 2 * NCH;                                     // pass 1: chunks 0 .. NCH-1, pass 2: the same again
+    constexpr int NIT = ONEP ? NCH : 2 * NCH;                        // two passes: chunks 0 .. NCH-1, then the same again
 
     if (tid < 2 * BH - 1) sm.dhs[tid] = A.dh[h * (2 * BH - 1) + tid] * FA_LOG2E;
     float *mine = sm.R + (il * 4 + kg) * NR;                          // this lane's class sums: [t index | h slot | register]
@@ -503,10 +517,29 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
     float kmax = fa_u2f((unsigned)(FA_EMIN - 14) << 23);             // largest 2^(e - 14) over the K rows (pass 1)
     float sgf = 0.f, kmr = 0.f, dl = 0.f;                             // pass 2: scale of g from its bound, 1 / kmax (applied one
                                                                       // after the other: their product can leave the float range), delta / l
-    int ebG = FA_EMIN;
+    int ebG = FA_EMIN;                                                // ONEP: the running exponent of max |g 2^(e_K - 14)| of this query row
+    if constexpr (ONEP) {
+        // delta_i = dO_i . O_i: the lane's 32 columns (those of its B fragments), then the four lanes of the column
+        const float *orow = A.o + (row0 + i) * A.ld + h * AT_D + 8 * kg, *drow = A.d_o + (row0 + i) * A.ld + h * AT_D + 8 * kg;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const float4 o0 = *reinterpret_cast<const float4 *>(orow + 32 * s_), o1 = *reinterpret_cast<const float4 *>(orow + 32 * s_ + 4);
+            const float4 d0 = *reinterpret_cast<const float4 *>(drow + 32 * s_), d1 = *reinterpret_cast<const float4 *>(drow + 32 * s_ + 4);
+            a0 = fmaf(o0.x, d0.x, a0); a0 = fmaf(o0.y, d0.y, a0); a0 = fmaf(o0.z, d0.z, a0); a0 = fmaf(o0.w, d0.w, a0);
+            a1 = fmaf(o1.x, d1.x, a1); a1 = fmaf(o1.y, d1.y, a1); a1 = fmaf(o1.z, d1.z, a1); a1 = fmaf(o1.w, d1.w, a1);
+        }
+        delta = fa_kg_sum(a0 + a1);
+        dl = delta * linv;
+    }
     f32x4v qacc[AT_D / 16];
 #pragma unroll
     for (int d = 0; d < AT_D / 16; ++d) qacc[d] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    constexpr bool CORR = ONEP && LVT_FA_A_CORR;
+    f32x4v cacc[CORR ? AT_D / 16 : 1];                               // ONEP: C_i = sum_j p_ij K_j under the scale 2^(268 - ebC)
+#pragma unroll
+    for (int d = 0; d < (CORR ? AT_D / 16 : 1); ++d) cacc[d] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    int ebC = 16;                                                     // running max of the exponent field of the K rows' 2^(e - 14)
     float rst[BT], rsw[4];                                            // class sums over the t index and the register; h slots: LDS
 #pragma unroll
     for (int x = 0; x < BT; ++x) rst[x] = 0.f;
@@ -516,13 +549,13 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
     static_for<NIT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         constexpr int c = t < NCH ? t : t - NCH;
-        constexpr bool PASS2 = t >= NCH;
+        constexpr bool PASS2 = ONEP || t >= NCH;
         const unsigned short *cur = sm.ring[t & 1];
         const float *cinv = sm.rs_inv[t & 1];
         constexpr bool PARK = t + 1 < NIT;
         unsigned short *nslot = sm.ring[(t + 1) & 1];
         float *ninv = sm.rs_inv[(t + 1) & 1];
-        if constexpr (t == NCH) {                                     // between the passes: delta, the scale bound of g, the bounds for B
+        if constexpr (!ONEP && t == NCH) {                            // between the passes: delta, the scale bound of g, the bounds for B
             delta = fa_kg_sum(delta) * linv;
             gmax = fa_kg_max(gmax);
             kmax = fa_kg_max(kmax);
@@ -574,6 +607,19 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
         });
         if constexpr (t + 2 < NIT) load_item(t + 2, g0);
         float w[8];
+        u32x4 pku = {0u, 0u, 0u, 0u};                                  // CORR: the eight p 2^(e_K - 14) scc of the lane, fp16 pairs
+        if constexpr (CORR) {
+            // the chunk's largest K-row scale (all 32 rows: this lane's eight + the three other lanes of the column)
+            const f32x4v k0 = *reinterpret_cast<const f32x4v *>(cinv + 4 * kg), k1 = *reinterpret_cast<const f32x4v *>(cinv + 16 + 4 * kg);
+            const int ebN = max(ebC, (int)(__float_as_uint(fa_kg_max(fmaxf(fa_max4(k0), fa_max4(k1)))) >> 23));
+            if (__builtin_amdgcn_ballot_w64(ebN != ebC) != 0) {
+                const float f = fa_exp_field(127 + ebC - ebN);
+#pragma unroll
+                for (int d = 0; d < AT_D / 16; ++d) cacc[d] = cacc[d] * f;
+                ebC = ebN;
+            }
+        }
+        const float scc = CORR ? fa_u2f((unsigned)(268 - ebC) << 23) * linv : 0.f;      // p 2^(e_K - 14) scc <= 2^14
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             const int T = 2 * c + kt;
@@ -584,6 +630,8 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
             const f32x4v qk = kinv * qc, bm = bw4 + bth;
             const f32x4v dv = vinv * (PASS2 ? doinv * linv : doinv), kw = kinv * kmr;         // kw <= 1
             float gt = 0.f;
+            const f32x4v ks = kinv * scc;
+            f32x4v pkv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float x = fa_score(st[kt][r], qk[r], bm[r]);
@@ -599,14 +647,35 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
                     const float g = ex * fmaf(dp[kt][r], dv[r], -dl);  // p (dP - delta)
                     gt += g;
                     rsw[r] += g;
-                    w[4 * kt + r] = (g * sgf) * kw[r];
+                    if constexpr (ONEP) { w[4 * kt + r] = g * kinv[r]; gmax = fmaxf(gmax, fabsf(g)); if constexpr (CORR) pkv[r] = ex * ks[r]; }
+                    else w[4 * kt + r] = (g * sgf) * kw[r];
                 }
             }
             if constexpr (PASS2) { rst[T / HP] += gt; mine[BT + T % HP] += gt; }
+            if constexpr (CORR) {
+                pku[2 * kt] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{pkv[0], pkv[1]}, f16x2v));
+                pku[2 * kt + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{pkv[2], pkv[3]}, f16x2v));
+            }
         }
         if constexpr (PASS2) {
+            if constexpr (ONEP) {
+                float tm = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tm = fmaxf(tm, fabsf(w[e]));
+                const int ebN = max(ebG, fa_ebits(fa_kg_max(tm)));
+                if (__builtin_amdgcn_ballot_w64(ebN != ebG) != 0) {   // (rare after the first chunks; exact: a power of two)
+                    const float f = fa_exp_field(127 + ebG - ebN);
+#pragma unroll
+                    for (int d = 0; d < AT_D / 16; ++d) qacc[d] = qacc[d] * f;
+                    ebG = ebN;
+                }
+                const float sct = fa_u2f((unsigned)(268 - ebG) << 23);       // max |w| in [2^14, 2^15)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] *= sct;
+            }
             f16x8 wbh, wbl;
             fa_split8(w, wbh, wbl);
+            const f16x8 pcb = __builtin_bit_cast(f16x8, pku);
             // ---- dQ^T += K^T g^T ----
 #pragma unroll
             for (int dq_ = 0; dq_ < AT_D / 32; ++dq_) {
@@ -621,18 +690,39 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
                 for (int dd = 0; dd < 2; ++dd) qacc[2 * dq_ + dd] = fa_mfma(a[dd][0], wbl, qacc[2 * dq_ + dd]);
 #pragma unroll
                 for (int dd = 0; dd < 2; ++dd) qacc[2 * dq_ + dd] = fa_mfma(a[dd][0], wbh, qacc[2 * dq_ + dd]);
+                if constexpr (CORR) {
+#pragma unroll
+                    for (int dd = 0; dd < 2; ++dd) cacc[2 * dq_ + dd] = fa_mfma(a[dd][0], pcb, cacc[2 * dq_ + dd]);
+                }
             }
         }
         __syncthreads();
     });
     // acc = sum_j g K 2^(14 - E_K) 2^(141 - ebG): dq = acc inv_temper kmax 2^(ebG - 141)   (kmax = 2^(E_K - 14), E_K unbiased)
-    const float f1 = kmax, f2 = fa_exp_field(ebG - 14) * A.inv_temper;
+    // (ONEP: acc = sum_j g 2^(e_K - 14) K~ 2^(141 - ebG), no common K scale)
+    if constexpr (ONEP) {
+        // per-workgroup bounds for kernel B: max 2^(e - 14) over the dO rows, max of max_j |g_ij| 2^(e_i - 14) over the q rows
+        float r0 = doinv, r1 = fa_kg_max(gmax) * qinv;
+#pragma unroll
+        for (int dd = 32; dd > 0; dd >>= 1) { r0 = fmaxf(r0, __shfl_xor(r0, dd, 64)); r1 = fmaxf(r1, __shfl_xor(r1, dd, 64)); }
+        if (lane == 0) { sm.red[wave] = r0; sm.red[8 + wave] = r1; }
+        __syncthreads();
+    }
+    const float f1 = ONEP ? 1.f : kmax, f2 = fa_exp_field(ebG - 14) * A.inv_temper;
+    // ONEP: eps_i = sum_j g_ij (every g sits in exactly one rsw register of one of the column's four lanes); C = cacc 2^(ebC - 141)
+    float epsc = 0.f;
+    if constexpr (CORR) {
+        const float eps = fa_kg_sum((rsw[0] + rsw[1]) + (rsw[2] + rsw[3]));
+        delta += eps;
+        epsc = (eps * fa_exp_field(ebC - 14)) * A.inv_temper;
+    }
     float am = 0.f;
     {
         float *qrow = A.dq + (row0 + i) * A.ld + h * AT_D + 4 * kg;
 #pragma unroll
         for (int d = 0; d < AT_D / 16; ++d) {
-            const f32x4v ov = (qacc[d] * f1) * f2;
+            f32x4v ov = (qacc[d] * f1) * f2;
+            if constexpr (CORR) ov = ov - cacc[d] * epsc;
             *reinterpret_cast<f32x4v *>(qrow + 16 * d) = ov;
             am = fmaxf(am, fmaxf(fmaxf(fabsf(ov[0]), fabsf(ov[1])), fmaxf(fabsf(ov[2]), fabsf(ov[3]))));
         }
@@ -691,17 +781,17 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
     return am;
 }
 
-template <int BT, int BH, int BW, int MASKED>
+template <int BT, int BH, int BW, int MASKED, int ONEP>
 __global__ __launch_bounds__(512, 1) void lvt_attn_bwd_flash_a_kernel(const FaArgs A, float *__restrict__ d_amax) {
     __shared__ __attribute__((aligned(16))) FaSmemA<BT + Geo16<BH, BW>::HP + 4> sm;
     if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);           // (see the forward kernel)
     float am;
     if (MASKED) {        // one workgroup = both query halves of a (sample, head): 8 + 4 key chunks (as separate workgroups: 219 us against 182)
-        am = fa_bwd_a_body<BT, BH, BW, MASKED, 8>(A, sm, blockIdx.x, 1);
+        am = fa_bwd_a_body<BT, BH, BW, MASKED, 8, ONEP>(A, sm, blockIdx.x, 1);
         __syncthreads();
-        am = fmaxf(am, fa_bwd_a_body<BT, BH, BW, MASKED, 4>(A, sm, fa_opaque(blockIdx.x), 0));
+        am = fmaxf(am, fa_bwd_a_body<BT, BH, BW, MASKED, 4, ONEP>(A, sm, fa_opaque(blockIdx.x), 0));
     } else {
-        am = fa_bwd_a_body<BT, BH, BW, MASKED, 8>(A, sm, fa_pair(blockIdx.x), fa_half(blockIdx.x));
+        am = fa_bwd_a_body<BT, BH, BW, MASKED, 8, ONEP>(A, sm, fa_pair(blockIdx.x), fa_half(blockIdx.x));
     }
     if (d_amax) {
         __syncthreads();
@@ -1005,9 +1095,15 @@ __global__ __launch_bounds__(256) void lvt_attn_flash_bank_reduce_kernel(const f
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
     if (lane) return;
-    if (e < nt) ddt[h * nt + e] = s;
-    else if (e < nt + nh) ddh[h * nh + e - nt] = s;
-    else ddw[h * (NB - nt - nh) + e - nt - nh] = s;
+    // A bank with ONE entry (the t bank of the (1, 16, 16) blocks) adds the same constant to every score of a row: softmax is
+    // shift-invariant, its gradient sum_ij g_ij is identically zero and what the sum holds is the rounding residue of the row
+    // cancellations (p (dP - delta) summed over j).  RMSprop divides a gradient by its own running magnitude, i.e. turns any
+    // residue above its eps into lr-sized steps of a parameter that cannot change the output; the residue of the one-pass form
+    // (delta from dO . O) is a few times the two-pass form's.  The exact value is returned instead.
+    const int nw = NB - nt - nh;
+    if (e < nt) ddt[h * nt + e] = nt == 1 ? 0.f : s;
+    else if (e < nt + nh) ddh[h * nh + e - nt] = nh == 1 ? 0.f : s;
+    else ddw[h * nw + e - nt - nh] = nw == 1 ? 0.f : s;
 }
 
 }  // namespace
@@ -1048,7 +1144,7 @@ extern "C" size_t lvt_attn_bwd_flash_workspace_bytes(int B, int H, int S, int bt
 }
 
 extern "C" int lvt_attn_bwd_flash(const float *q, const float *k, const float *v, const float *d_o, long long ld, const float *stats,
-                                  int B, int H, int S, int da, float temper, const float *dt, const float *dh, const float *dw,
+                                  const float *o, int B, int H, int S, int da, float temper, const float *dt, const float *dh, const float *dw,
                                   int bt, int bh, int bw, int masked, float fill, float *dq, float *dk, float *dv, float *ddt,
                                   float *ddh, float *ddw, float *d_amax, void *workspace, size_t workspace_bytes, void *stream) {
     LVT_REQUIRE(q && k && v && d_o && stats && dt && dh && dw && dq && dk && dv && ddt && ddh && ddw && B > 0 && H > 0, "attn_bwd_flash: bad args");
@@ -1064,6 +1160,11 @@ extern "C" int lvt_attn_bwd_flash(const float *q, const float *k, const float *v
     A.q = q; A.k = k; A.v = v; A.d_o = d_o; A.ld = ld; A.H = H; A.inv_temper = 1.f / temper; A.c1 = FA_LOG2E / temper; A.fill2 = fill * FA_LOG2E;
     A.dt = dt; A.dh = dh; A.dw = dw; A.m = const_cast<float *>(stats); A.l = const_cast<float *>(stats) + (size_t)B * H * S;
     A.dq = dq; A.dk = dk; A.dv = dv;
+    // o (the forward's output, row stride ld) selects the one-pass form of kernel A; NULL (or LVT_FA_TWOPASS): delta from a first pass over the keys
+    static const int twopass = getenv("LVT_FA_TWOPASS") ? 1 : 0;
+    LVT_REQUIRE(!o || lvt_aligned16(o), "attn_bwd_flash: o must be 16-byte aligned");
+    const bool onep = o && !twopass;
+    A.o = const_cast<float *>(o);
     A.delta = (float *)workspace;
     A.scal = A.delta + (size_t)B * H * S;
     A.bank_partial = A.scal + (size_t)B * H * 4;
@@ -1073,8 +1174,10 @@ extern "C" int lvt_attn_bwd_flash(const float *q, const float *k, const float *v
     hipStream_t s = (hipStream_t)stream;
 #define LVT_X(BT, BH, BW)                                                                                         \
     if (bt == BT && bh == BH && bw == BW) {                                                                       \
-        if (masked) hipLaunchKernelGGL((lvt_attn_bwd_flash_a_kernel<BT, BH, BW, 1>), grid, blk, 0, s, A, d_amax); \
-        else hipLaunchKernelGGL((lvt_attn_bwd_flash_a_kernel<BT, BH, BW, 0>), grid, blk, 0, s, A, d_amax);        \
+        if (masked && onep) hipLaunchKernelGGL((lvt_attn_bwd_flash_a_kernel<BT, BH, BW, 1, 1>), grid, blk, 0, s, A, d_amax); \
+        else if (masked) hipLaunchKernelGGL((lvt_attn_bwd_flash_a_kernel<BT, BH, BW, 1, 0>), grid, blk, 0, s, A, d_amax);    \
+        else if (onep) hipLaunchKernelGGL((lvt_attn_bwd_flash_a_kernel<BT, BH, BW, 0, 1>), grid, blk, 0, s, A, d_amax);      \
+        else hipLaunchKernelGGL((lvt_attn_bwd_flash_a_kernel<BT, BH, BW, 0, 0>), grid, blk, 0, s, A, d_amax);                \
     }
     LVT_FA_GEOMS(LVT_X)
 #undef LVT_X

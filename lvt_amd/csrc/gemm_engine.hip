@@ -1242,7 +1242,9 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
     const float *xf = p.A + (long long)frame * (MODE == 2 ? 1024 : 256) * Ci;
 
     // ---- patch staging: unit u = pixel * 8 + channel quad; 2592 units over 512 threads -> 6 passes
-    constexpr int PUNITS = PT_PIX * 8, PPASS = (PUNITS + PT_THREADS - 1) / PT_THREADS;
+    // (MODE 2 walks only the 17x17 sub-image pixels its taps read, placed at the 18-pixel pitch: 5 passes)
+    constexpr int PWALK = MODE == 2 ? 17 : PT_PW;
+    constexpr int PUNITS = PWALK * PWALK * 8, PPASS = (PUNITS + PT_THREADS - 1) / PT_THREADS;
     float4 pv[PPASS];
     // `chunk`: the 32-channel chunk (MODE 0 / 1), or chunk * 4 + parity class (MODE 2)
     auto patch_fetch = [&](int chunk) {
@@ -1250,10 +1252,10 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
         for (int j = 0; j < PPASS; ++j) {
             const int u = tid + PT_THREADS * j;
             const int pp = u >> 3, q = u & 7;
-            const int py = pp / PT_PW, px = pp - py * PT_PW;
+            const int py = pp / PWALK, px = pp - py * PWALK;
             if (MODE == 2) {
                 const int iy = 2 * py + ((chunk >> 1) & 1) - 1, ix = 2 * px + (chunk & 1) - 1;      // sub-image pixel -> input pixel
-                const bool ok = u < PUNITS && (unsigned)iy < 32u && (unsigned)ix < 32u && py < 17 && px < 17;
+                const bool ok = u < PUNITS && (unsigned)iy < 32u && (unsigned)ix < 32u;
                 pv[j] = ok ? ldg4(xf + (iy * 32 + ix) * Ci + (chunk >> 2) * 32 + q * 4) : zero4();
             } else {
                 const bool ok = u < PUNITS && (unsigned)(py - 1) < 16u && (unsigned)(px - 1) < 16u;
@@ -1267,7 +1269,8 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
         for (int j = 0; j < PPASS; ++j) {
             const int u = tid + PT_THREADS * j;
             if (u < PUNITS) {
-                unsigned short *d = Ah + (u >> 3) * HLD + (u & 7) * 4;
+                const int pp = u >> 3;
+                unsigned short *d = Ah + (MODE == 2 ? pp + pp / PWALK : pp) * HLD + (u & 7) * 4;
                 if (MATH == 2) {
                     uint2 ph, pl;
                     split2(pv[j], sa, ph, pl);

@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("LVT_HIP_LIB") or os.path.join(os.path.dirname(_HERE)
 
 EPI_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_TANH, EPI_MASK, EPI_ACCUM, EPI_PLANES = 1, 2, 4, 8, 16, 32, 64
 CAUSAL_KMAX, CAUSAL_KMIN, CAUSAL_TILE = 1 << 8, 1 << 9, 1 << 10      # causal attention products (include/lvt_hip.h)
-ABI_VERSION = 500           # lvt_version() of the library this module binds (argument lists below)
+ABI_VERSION = 510           # lvt_version() of the library this module binds (argument lists below)
 MATH_F32 = 1 << 16          # per-call arithmetic selectors of the engine entry points (include/lvt_hip.h)
 MATH_F16X2 = 1 << 18
 ONEHOT_DENSE = 1 << 19
@@ -135,7 +135,7 @@ def _declare(lib):
         "lvt_attn_flash_supported": (ci, [ci, ci, ci, ci, ci]),
         "lvt_attn_fwd_flash": (ci, [vp, vp, vp, cll, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp, vp]),
         "lvt_attn_bwd_flash_workspace_bytes": (sz, [ci, ci, ci, ci, ci, ci]),
-        "lvt_attn_bwd_flash": (ci, [vp, vp, vp, vp, cll, vp, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp, vp,
+        "lvt_attn_bwd_flash": (ci, [vp, vp, vp, vp, cll, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp, vp,
                                     vp, vp, vp, vp, sz, vp]),
         "lvt_attn_decode": (ci, [vp, cll, vp, vp, ci, ci, ci, ci, ci, cf, vp, vp, vp, ci, ci, ci, vp, vp, cll, vp]),
         "lvt_decode_gather_codes": (ci, [vp, vp, vp, ci, ci, ci, vp, vp]),

@@ -106,9 +106,10 @@ def attn_fwd_flash(qkv, B, H, S, da, temper, dt, dh, dw, block, masked, fill=-1e
     return o, stats
 
 
-def attn_bwd_flash(qkv, do, stats, B, H, S, da, temper, dt, dh, dw, block, masked, fill=-1e4):
-    """-> (dqkv (3, B*S, H*da) fp32, ddt, ddh, ddw); do (B*S, H*da) fp32."""
-    L.require(qkv, do, stats, dt, dh, dw)
+def attn_bwd_flash(qkv, do, stats, B, H, S, da, temper, dt, dh, dw, block, masked, fill=-1e4, o=None):
+    """-> (dqkv (3, B*S, H*da) fp32, ddt, ddh, ddw); do (B*S, H*da) fp32.  o: the forward's output (B*S, H*da) -- with it the
+    query-stationary launch takes delta_i = dO_i . O_i and makes one pass over the keys (None: two passes)."""
+    L.require(qkv, do, stats, dt, dh, dw, o)
     M, hd = B * S, H * da
     dev = qkv.device
     dqkv = torch.empty(3, M, hd, dtype=torch.float32, device=dev)
@@ -119,7 +120,7 @@ def attn_bwd_flash(qkv, do, stats, B, H, S, da, temper, dt, dh, dw, block, maske
     nws = lib.lvt_attn_bwd_flash_workspace_bytes(B, H, S, block[0], block[1], block[2])
     ws = L.workspace(nws, dev, "attn_bwd")
     t0 = L.TIMER.begin() if L.TIMER is not None else None
-    L.check(lib.lvt_attn_bwd_flash(L.ptr(qkv[0]), L.ptr(qkv[1]), L.ptr(qkv[2]), L.ptr(do), hd, L.ptr(stats), B, H, S, da, temper,
+    L.check(lib.lvt_attn_bwd_flash(L.ptr(qkv[0]), L.ptr(qkv[1]), L.ptr(qkv[2]), L.ptr(do), hd, L.ptr(stats), L.ptr(o), B, H, S, da, temper,
                                    L.ptr(dt), L.ptr(dh), L.ptr(dw), block[0], block[1], block[2], 1 if masked else 0, fill,
                                    L.ptr(dqkv[0]), L.ptr(dqkv[1]), L.ptr(dqkv[2]), L.ptr(ddt), L.ptr(ddh), L.ptr(ddw),
                                    L.out_amax(dqkv), L.ptr(ws), nws, L.stream_ptr()), "lvt_attn_bwd_flash")

@@ -36,7 +36,8 @@ for masked in (False, True):
     if which in ("both", "fwd"):
         print("flash ", "masked" if masked else "full  ", "fwd %.1f us" % timeit(lambda: tx.attn_fwd_flash(qkv, b, na, S, da, T, dt, dh, dw, blk, masked)))
     if which in ("both", "bwd"):
-        print("flash ", "masked" if masked else "full  ", "bwd %.1f us" % timeit(lambda: tx.attn_bwd_flash(qkv, do, stats, b, na, S, da, T, dt, dh, dw, blk, masked)))
+        print("flash ", "masked" if masked else "full  ", "bwd %.1f us" % timeit(lambda: tx.attn_bwd_flash(qkv, do, stats, b, na, S, da, T, dt, dh, dw, blk, masked)),
+              "bwd one-pass A %.1f us" % timeit(lambda: tx.attn_bwd_flash(qkv, do, stats, b, na, S, da, T, dt, dh, dw, blk, masked, o=o)))
 if "noplanes" not in sys.argv:
     qkvp = torch.stack([planes(qkv[i]) for i in range(3)]).contiguous()
     dop = planes(do).contiguous()

@@ -40,7 +40,14 @@ def _reference(q, k, v, go, banks, blk, masked, dtype=torch.float64):
     return [o.detach(), m.detach().reshape(-1), linv.detach().reshape(-1)] + [t.grad for t in leaves] + [t.grad for t in bl]
 
 
-def _flash(q, k, v, go, banks, blk, masked):
+@pytest.fixture(params=[True, False], ids=["onepass", "twopass"])
+def onepass(request):
+    """Backward A with delta_i = dO_i . O_i in one pass over the keys (the product path: `o` handed to lvt_attn_bwd_flash), or
+    with delta from a first pass over the keys (o == NULL)."""
+    return request.param
+
+
+def _flash(q, k, v, go, banks, blk, masked, onepass=True):
     from lvt_amd.hip import binding as L, tx
     assert L.get_math_mode() == "f16x2"
     B = q.shape[0] // S
@@ -49,7 +56,7 @@ def _flash(q, k, v, go, banks, blk, masked):
     bd = [t.to(DEV).contiguous() for t in banks]
     o, stats = tx.attn_fwd_flash(qkv, B, H, S, DA, math.sqrt(DA), bd[0], bd[1], bd[2], blk, masked)
     dqkv, ddt, ddh, ddw = tx.attn_bwd_flash(qkv, go.to(DEV).contiguous(), stats, B, H, S, DA, math.sqrt(DA), bd[0], bd[1], bd[2],
-                                            blk, masked)
+                                            blk, masked, o=o if onepass else None)
     torch.cuda.synchronize()
     return [o, stats[0], stats[1], dqkv[0], dqkv[1], dqkv[2], ddt, ddh, ddw]
 
@@ -59,7 +66,7 @@ NAMES = ["o", "m", "linv", "dq", "dk", "dv", "ddt", "ddh", "ddw"]
 
 @pytest.mark.parametrize("masked", [False, True])
 @pytest.mark.parametrize("blk", [(1, 16, 16), (4, 8, 8)])
-def test_flash_attention_vs_fp64(masked, blk):
+def test_flash_attention_vs_fp64(masked, blk, onepass):
     B, H = 2, 8
     hd = H * DA
     q, k, v, go = (_rand(B * S, hd, seed=s) for s in (1, 2, 3, 4))
@@ -67,7 +74,7 @@ def test_flash_attention_vs_fp64(masked, blk):
     banks = [_rand(H, 2 * n - 1, seed=5 + i) * 0.5 for i, n in enumerate(blk)]
     ref = _reference(q, k, v, go, banks, blk, masked)
     ref32 = _reference(q, k, v, go, banks, blk, masked, dtype=torch.float32)
-    got = _flash(q, k, v, go, banks, blk, masked)
+    got = _flash(q, k, v, go, banks, blk, masked, onepass)
     bank_scale = max(float(ref[i].abs().max()) for i in (6, 7, 8))
     for n, a, r, r32 in zip(NAMES, got, ref, ref32):
         # (the gradient of a one-entry bank is sum_ij g_ij == 0 up to rounding: judged against the scale of the other banks)
@@ -80,7 +87,7 @@ def test_flash_attention_vs_fp64(masked, blk):
 
 
 @pytest.mark.parametrize("kind", ["row_ladder", "heavy_tail", "tiny", "huge"])
-def test_flash_attention_accuracy_envelope(kind):
+def test_flash_attention_accuracy_envelope(kind, onepass):
     """The per-row split keeps 22 bits relative to each ROW's max: rows of very different magnitude (a ladder down to 2^-20),
     heavy-tailed rows, tiny (1e-6) and huge (1e4) operands must come out no worse than a plain fp32 evaluation of the same
     formula (judged against fp64: error <= 1.5 x the fp32 evaluation's, or 2e-6 of the tensor's max)."""
@@ -101,7 +108,7 @@ def test_flash_attention_accuracy_envelope(kind):
     banks = [_rand(H, 2 * n - 1, seed=5 + i) * 0.5 for i, n in enumerate(blk)]
     ref = _reference(q, k, v, go, banks, blk, masked)
     ref32 = _reference(q, k, v, go, banks, blk, masked, dtype=torch.float32)
-    got = _flash(q, k, v, go, banks, blk, masked)
+    got = _flash(q, k, v, go, banks, blk, masked, onepass)
     for n, a, r, r32 in zip(NAMES, got, ref, ref32):
         if n.startswith("dd") or n in ("m", "linv"):
             continue
@@ -112,7 +119,7 @@ def test_flash_attention_accuracy_envelope(kind):
 
 
 @pytest.mark.parametrize("blk", [(1, 16, 16), (4, 8, 8)])
-def test_flash_attention_zero_rows_and_zero_gradients(blk):
+def test_flash_attention_zero_rows_and_zero_gradients(blk, onepass):
     """Operands with all-zero rows, a (sample, head) whose dO is entirely zero (a block that does not reach the loss: the DSSVT
     encoder has them) and one whose V is zero: every scale derived from a row maximum stays finite -- no inf * 0."""
     B, H = 2, 8
@@ -125,7 +132,7 @@ def test_flash_attention_zero_rows_and_zero_gradients(blk):
     banks = [_rand(H, 2 * n - 1, seed=5 + i) * 0.5 for i, n in enumerate(blk)]
     for masked in (False, True):
         ref = _reference(q, k, v, go, banks, blk, masked)
-        got = _flash(q, k, v, go, banks, blk, masked)
+        got = _flash(q, k, v, go, banks, blk, masked, onepass)
         bank_scale = max(float(ref[i].abs().max()) for i in (6, 7, 8))
         for n, a, r in zip(NAMES, got, ref):
             assert torch.isfinite(a).all(), n
