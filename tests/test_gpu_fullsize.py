@@ -118,6 +118,15 @@ def test_dsfvt_train_step_64_slices_equals_mean_of_chunks(math_mode):
         for p in parts[1:]:
             acc = acc + p[1][k].double()
         e = rel_err(gf, acc / 4)
+        if k.endswith("mha.w_k"):
+            # dW_k = sum_i xn_i (x) dK_i with sum_j dK_j == 0 over every 256-key block: the result is what is left of a ~3000-fold
+            # cancellation (max |dW_k| 3.6e-9 here, 30x below the other attention weights), and every PARTIAL sum over rows -- a
+            # split-K range, a k-tile -- is uncancelled, so the fp32 accumulation order alone (16384 rows against 4 x 4096) moves
+            # it by ~6e-8 x 3000.  The CPU fp32 oracle is 6e-5 ... 3e-3 from fp64 on these tensors, this path 7e-5 ... 1.3e-3
+            # (one-pass backward; two-pass: 1.6e-4 ... 4.2e-3): tests/test_gpu_vt.py::test_g12_full_dsfvt_loss_and_grads holds them to
+            # that bound.  Here: consistent to 3e-4.
+            assert e < 3e-4, (e, k)
+            continue
         if e > worst:
             worst, worst_k = e, k
     assert worst < 1e-5, (worst, worst_k)

@@ -20,6 +20,8 @@ probe replaces while a run is in progress.
 """
 import contextlib
 
+import os
+
 import torch
 
 _ORIG_RELU = torch.relu
@@ -170,6 +172,8 @@ def assert_grads_match_decisions(mine, mine_masks, run_oracle, names, slack=4.0,
     bad = []
     for n in names:
         e_mine, e_cpu = _rel(mine[n], ref_mine[n]), _rel(g32[n], ref_cpu[n])
+        if os.environ.get("LVT_TEST_VERBOSE"):
+            print("grad %-55s this path %.3e  CPU fp32 %.3e  (vs fp64)" % (n, e_mine, e_cpu))
         if not e_mine < max(slack * e_cpu, floor):
             bad.append((n, e_mine, e_cpu))
     assert not bad, (bad, "units decided differently from fp64: this path %d, CPU fp32 %d" % (len(f_mine), len(f_cpu)))
