@@ -47,10 +47,15 @@ class VQVAEModel(AutoEncoderModel):
         import torch.distributed as dist
         from ...utils import comm
         super().wrap_parallel(device_ids, broadcast_buffers)
+        if not self.use_codebook_ema:
+            # a trained codebook is a DDP module of its own in the reference (vqvae.py:46-49): its gradients are averaged too
+            from ...engine.grad_reducer import BucketedGradReducer
+            self._reducers.append(BucketedGradReducer(self.codebook.parameters()))
         if comm.get_world_size() > 1:
             with torch.no_grad():
                 for t in self.codebook._flat():
-                    dist.broadcast(t, 0)
+                    if t is not None:
+                        dist.broadcast(t, 0)
 
     def _generator_parameters(self):
         params = super()._generator_parameters()
@@ -85,8 +90,11 @@ class VQVAEModel(AutoEncoderModel):
         c = len(self.cfg.MODEL.PIXEL_MEAN)
         loss = {
             "loss_reconstruction": self.pixel_loss(x_tilde, x, denom=x.numel() // x.shape[-1] * c),
-            "loss_commitment": mse(z_e, z_q_bar, scale=self.beta),
+            "loss_commitment": mse(z_e, z_q_bar.detach(), scale=self.beta),
         }
+        if not self.use_codebook_ema:
+            # vector-quantisation objective of a TRAINED codebook, under the reference's key (vqvae.py:83-84)
+            loss["loss_dict"] = mse(z_q_bar, z_e.detach())
         return (loss, x, x_tilde) if return_x else loss
 
     def _generator_loss_cl(self, x):

@@ -60,14 +60,30 @@ class _StraightThroughFn(torch.autograd.Function):
         return g_st, None, None                          # straight-through (vq_utils.py:52-54)
 
 
+class _GatherWithGradFn(torch.autograd.Function):
+    """rows of the codebooks selected by idx, differentiable w.r.t. the codebooks (CODEBOOK.EMA False): the backward pass is
+    `grad_codebook.index_add_(0, indices, grad_rows)` (vq_utils.py:56-63) per codebook -- here the per-code row sums of the
+    EMA-statistics kernel (fixed summation order, no atomics) applied to the gradient rows."""
+
+    @staticmethod
+    def forward(ctx, idx, owner, *weights):
+        ctx.save_for_backward(idx)
+        ctx.K, ctx.num, ctx.d = owner.K, owner.num, owner.D // owner.num
+        return vq.gather(idx, owner._flat()[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        stats = vq.ema_accumulate(idx, g.contiguous(), ctx.K)                 # (num, K, d + 1): sums | counts
+        return (None, None) + tuple(stats[i, :, :ctx.d].contiguous() for i in range(ctx.num))
+
+
 class DVQEmbedding(nn.Module):
     def __init__(self, num, K, D, ema):
         super().__init__()
         assert D % num == 0
         if D // num != 64:
             raise NotImplementedError("the HIP quantiser is instantiated for 64-d sub-vectors (got %d)" % (D // num))
-        if not ema:
-            raise NotImplementedError("non-EMA codebooks are not used by any shipped config")
         self.num, self.D, self.K, self.ema = num, D, K, ema
         self.decay, self.eps = 0.99, 1e-5
         self.ve = nn.ModuleList([VQEmbedding(K, D // num, ema) for _ in range(num)])
@@ -81,17 +97,21 @@ class DVQEmbedding(nn.Module):
         fw = self._flat_w
         ok = fw is not None and fw.device == w0.device and all(
             self.ve[i].embedding.weight.data_ptr() == fw[i].data_ptr()
-            and self.ve[i].running_size.data_ptr() == self._flat_rs[i].data_ptr()
-            and self.ve[i].running_sum.data_ptr() == self._flat_rsum[i].data_ptr() for i in range(self.num))
+            and (not self.ema or (self.ve[i].running_size.data_ptr() == self._flat_rs[i].data_ptr()
+                                  and self.ve[i].running_sum.data_ptr() == self._flat_rsum[i].data_ptr()))
+            for i in range(self.num))
         if not ok:
             with torch.no_grad():
                 fw = torch.stack([v.embedding.weight.data for v in self.ve]).contiguous()
-                frs = torch.stack([v.running_size for v in self.ve]).contiguous()
-                frsum = torch.stack([v.running_sum for v in self.ve]).contiguous()
+                frs = frsum = None
+                if self.ema:                 # (a trained codebook, CODEBOOK.EMA False, has no running buffers: vq_embedding.py:17-21)
+                    frs = torch.stack([v.running_size for v in self.ve]).contiguous()
+                    frsum = torch.stack([v.running_sum for v in self.ve]).contiguous()
                 for i, v in enumerate(self.ve):
                     v.embedding.weight.data = fw[i]
-                    v.running_size = frs[i]
-                    v.running_sum = frsum[i]
+                    if self.ema:
+                        v.running_size = frs[i]
+                        v.running_sum = frsum[i]
             self._flat_w, self._flat_rs, self._flat_rsum = fw, frs, frsum
         return self._flat_w, self._flat_rs, self._flat_rsum
 
@@ -130,6 +150,10 @@ class DVQEmbedding(nn.Module):
             if work is not None:
                 work.wait()
             vq.ema_finalize(stats, rsize, rsum, w, self.decay, self.eps)
+        if not self.ema:
+            # a trained codebook: z_q_bar carries the graph to the `num` weight parameters (vq_embedding.py:61-64); their
+            # gradient is the reference's index_add_ of the incoming rows (vq_utils.py:56-63)
+            return _GatherWithGradFn.apply(idx, self, *[v.embedding.weight for v in self.ve]).view(*self._pending_shape)
         return vq.gather(idx, w).view(*self._pending_shape)      # from the POST-update codebook
 
     def abandon_ema(self):

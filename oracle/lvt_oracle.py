@@ -142,8 +142,10 @@ def vq_straight_through(x_last, codebook):
 # A5  EMA codebook update                      (vq/vq_embedding.py:35-66)
 # --------------------------------------------------------------------------------------------
 def vq_ema_step(state, z_e_part, decay=0.99, eps=1e-5, all_reduce=None, alias_running_sum=False,
-                force_idx=None):
-    """One `_straight_through` call of VQEmbedding with ema=True.
+                force_idx=None, ema=True):
+    """One `_straight_through` call of VQEmbedding (vq_embedding.py:35-66).  ema=False (CODEBOOK.EMA False: the codebook
+    is a trained parameter): no update, z_q_bar is gathered from the codebook WITH its graph (vq_embedding.py:61-64), the
+    straight-through value from the detached one (:37).
 
     state: dict with 'embedding.weight' (K,D), 'running_size' (K,), 'running_sum' (K,D).
     z_e_part: (N, D, H, W).  Returns (z_q_st, z_q_bar, new_state, idx_flat).
@@ -164,6 +166,9 @@ def vq_ema_step(state, z_e_part, decay=0.99, eps=1e-5, all_reduce=None, alias_ru
         idx = force_idx.reshape(-1)
         codes = torch.index_select(w, 0, idx).view_as(x)
     z_q_st = codes.permute(0, 3, 1, 2).contiguous()
+    if not ema:
+        z_q_bar = torch.index_select(w, 0, idx).view_as(x).permute(0, 3, 1, 2).contiguous()
+        return z_q_st.detach(), z_q_bar, dict(state), idx
 
     size = torch.zeros(k, dtype=torch.int64)
     size.index_add_(0, idx, torch.ones_like(idx))
@@ -208,14 +213,14 @@ def dvq_indices(state, z_e, num=4):
     return torch.stack(out, dim=1)
 
 
-def dvq_straight_through(state, z_e, num=4, all_reduce=None, alias_running_sum=False, force_idx=None):
+def dvq_straight_through(state, z_e, num=4, all_reduce=None, alias_running_sum=False, force_idx=None, ema=True):
     """mode "st" (vq_embedding.py:84-91).  Returns (z_q_st, z_q_bar, new_state, idx (num, N*H*W))."""
     assert z_e.dim() == 4 and z_e.size(1) % num == 0
     r1, r2, idxs, new_state = [], [], [], {}
     for i, part in enumerate(z_e.split(z_e.size(1) // num, dim=1)):
         a, b, ns, idx = vq_ema_step(_split_state(state, i), part, all_reduce=all_reduce,
                                     alias_running_sum=alias_running_sum,
-                                    force_idx=None if force_idx is None else force_idx[:, i])
+                                    force_idx=None if force_idx is None else force_idx[:, i], ema=ema)
         r1.append(a)
         r2.append(b)
         idxs.append(idx)
@@ -246,7 +251,7 @@ class _StraightThrough(torch.autograd.Function):
 
 
 def vqvae_supervised_loss(enc, dec, cb_state, x, beta=1.0, lam=1.0, num=4, all_reduce=None,
-                          alias_running_sum=False, force_idx=None, n_layers=2):
+                          alias_running_sum=False, force_idx=None, n_layers=2, ema=True):
     """compute_supervised_loss (vqvae.py:66-91).  x already normalised, (N,3,H,W) or (B,T,3,H,W).
     n_layers = residual blocks per side (2: PR-DVQVAE2, 4: K-DVQVAE).
 
@@ -257,13 +262,15 @@ def vqvae_supervised_loss(enc, dec, cb_state, x, beta=1.0, lam=1.0, num=4, all_r
         x = x.reshape(b * t, c, h, w)
     z_e = res_encoder(enc, x, n_layers)
     z_q_st_val, z_q_bar, new_state, idx = dvq_straight_through(
-        cb_state, z_e.detach(), num, all_reduce, alias_running_sum, force_idx)
+        cb_state, z_e.detach(), num, all_reduce, alias_running_sum, force_idx, ema)
     z_q_st = _StraightThrough.apply(z_e, z_q_st_val)
     x_tilde = res_decoder(dec, z_q_st, n_layers)
     losses = {
         "loss_reconstruction": lam * F.mse_loss(x_tilde, x),
         "loss_commitment": beta * F.mse_loss(z_e, z_q_bar.detach()),
     }
+    if not ema:
+        losses["loss_dict"] = F.mse_loss(z_q_bar, z_e.detach())      # (the reference's key name: vqvae.py:83-84)
     return losses, new_state, {"z_e": z_e, "z_q_st": z_q_st_val, "x_tilde": x_tilde, "idx": idx}
 
 

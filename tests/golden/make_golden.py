@@ -180,6 +180,29 @@ def golden_vqvae():
              grad_names=np.array(list(g.keys())),
              **{"new." + k: v for k, v in st.items() if "ve.0." in k})
 
+    # G22 CODEBOOK.EMA False: the codebook is a trained parameter (vqvae.py:83-84, vq_embedding.py:61-64) -----------
+    cfg_ne = ref_cfg("configs/vqvae/PR-DVQVAE2.yaml", **{"MODEL.CODEBOOK.EMA": False})
+    model_ne = build_model(cfg_ne)
+    load_into(model_ne.encoder, enc)
+    load_into(model_ne.generator, dec)
+    for i, ve in enumerate(model_ne.codebook.ve):
+        ve.embedding.weight.data = state0["ve.%d.embedding.weight" % i].clone()
+    model_ne.train()
+    model_ne.zero_grad()
+    data = [{"image": seeded.seeded_input("g5.f%d" % i, (3, 64, 64), SEED).numpy()} for i in range(2)]
+    with EventStorage(0):
+        losses = model_ne(data, mode="supervised")
+    assert sorted(losses) == ["loss_commitment", "loss_dict", "loss_reconstruction"], sorted(losses)
+    sum(losses.values()).backward()
+    cbg = {n: p.grad.clone() for n, p in model_ne.codebook.named_parameters()}
+    with torch.no_grad():
+        idx_ne = model_ne.codebook(model_ne.encoder(model_ne.normalizer(torch.stack([torch.from_numpy(d["image"]) for d in data]))))
+    save("g22_vqvae_no_ema", seed=SEED, scale=zstd, loss_reconstruction=losses["loss_reconstruction"],
+         loss_commitment=losses["loss_commitment"], loss_dict=losses["loss_dict"], idx=idx_ne,
+         grad_enc_first=model_ne.encoder.layers[0].weight.grad, grad_dec_last_bias=model_ne.generator.layers[6].bias.grad,
+         generator_param_count=np.array(len(model_ne._generator_parameters())),
+         **{"grad." + n: g for n, g in cbg.items()})
+
     # G6 inference on the five example frames ------------------------------------------------------
     from PIL import Image
     imgs = np.stack([np.asarray(Image.open(os.path.join(REF, "example", "%d.png" % i)).convert("RGB"))

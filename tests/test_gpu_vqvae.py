@@ -322,3 +322,46 @@ def test_vq_nearest_coarse_then_exact_search():
     zt = cb[[17, 300, 5, 511]].repeat(64, 4).contiguous()
     idx = vq.nearest(zt.to(DEV), torch.stack([cb] * 4).to(DEV), 256, coarse=True).cpu()
     assert idx[0, 0, :4].tolist() == [17, 17, 5, 17]
+
+
+def test_g22_trained_codebook(golden):
+    """CODEBOOK.EMA False: the codebook is a parameter of the generator's optimizer (vqvae.py:83-84, 53-57; vq_embedding.py:61-64;
+    vq_utils.py:56-63): losses under the reference's three keys, codebook gradients against the reference's index_add_, the same
+    code indices, no EMA buffers in the state dict, and one Adam step that moves the codebook."""
+    from lvt_amd.modeling import build_model
+    from lvt_amd.utils.events import EventStorage
+    from util_models import vqvae_cfg
+    g = golden("g22_vqvae_no_ema")
+    seed = int(g["seed"])
+    cfg = vqvae_cfg(DEV)
+    cfg.MODEL.CODEBOOK.EMA = False
+    model = build_model(cfg)
+    model.encoder.load_state_dict(seeded.seeded_params(seeded.VQVAE_ENCODER_SHAPES, seed, "enc."))
+    model.generator.load_state_dict(seeded.seeded_params(seeded.VQVAE_DECODER_SHAPES, seed, "dec."))
+    st0 = {k: v for k, v in seeded.seeded_codebook_state(seed, scale=float(g["scale"])).items() if k.endswith("embedding.weight")}
+    assert sorted(model.codebook.state_dict()) == sorted(st0)                  # no running_size / running_sum
+    model.codebook.load_state_dict(st0)
+    model.train()
+    assert all(p.requires_grad for p in model.codebook.parameters())
+    assert len(model._generator_parameters()) == int(g["generator_param_count"])
+    opts, _ = model.configure_optimizers_and_checkpointers()
+    data = [{"image": seeded.seeded_input("g5.f%d" % i, (3, 64, 64), seed).numpy()} for i in range(2)]
+    with EventStorage(0):
+        losses = model(data, mode="supervised")
+    assert set(losses) == {"loss_reconstruction", "loss_commitment", "loss_dict"}
+    sum(losses.values()).backward()
+    assert abs(float(losses["loss_reconstruction"]) - float(g["loss_reconstruction"])) < 1e-5 * float(g["loss_reconstruction"])
+    for k in ("loss_commitment", "loss_dict"):          # |z_e - e|^2: a difference of nearly equal numbers (see G5)
+        assert abs(float(losses[k]) - float(g[k])) < 2e-4 * float(g[k]), k
+    assert torch.equal(model.codebook.last_indices.cpu(), g["idx"])
+    for i in range(4):
+        assert rel_err(model.codebook.ve[i].embedding.weight.grad, g["grad.ve.%d.embedding.weight" % i]) < 2e-5, i
+    assert rel_err(model.encoder.layers[0].weight.grad, g["grad_enc_first"]) < 1e-3
+    assert rel_err(model.generator.layers[6].bias.grad, g["grad_dec_last_bias"]) < 1e-4
+    before = model.codebook.ve[0].embedding.weight.detach().clone()
+    for o in opts:
+        o["optimizer"].step()
+    assert float((model.codebook.ve[0].embedding.weight.detach() - before).abs().max()) > 0
+    # the quantiser still serves the other modes
+    lat = model.codebook(model.encoder(torch.zeros(1, 3, 64, 64, device=DEV)))
+    assert tuple(lat.shape) == (1, 4, 16, 16)

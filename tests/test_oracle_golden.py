@@ -87,6 +87,29 @@ def test_g5_vqvae_loss_and_grads(golden, tag):
         assert rel_err(new["ve.0." + k], g["new.ve.0." + k]) < 1e-5, k
 
 
+def test_g22_vqvae_trained_codebook(golden):
+    """CODEBOOK.EMA False (vqvae.py:83-84, vq_embedding.py:61-64): three losses, codebook gradients = index_add of the rows."""
+    g = golden("g22_vqvae_no_ema")
+    seed = int(g["seed"])
+    enc, dec = _vqvae_params(seed)
+    st0 = {k: v for k, v in seeded.seeded_codebook_state(seed, scale=float(g["scale"])).items() if k.endswith("embedding.weight")}
+    for p in list(enc.values()) + list(dec.values()) + list(st0.values()):
+        p.requires_grad_(True)
+    x = torch.stack([seeded.seeded_input("g5.f%d" % i, (3, 64, 64), seed) for i in range(2)])
+    losses, new, aux = O.vqvae_supervised_loss(enc, dec, st0, O.normalize(x, MEAN, STD), ema=False)
+    assert sorted(losses) == ["loss_commitment", "loss_dict", "loss_reconstruction"]
+    sum(losses.values()).backward()
+    for k in losses:
+        assert abs(float(losses[k]) - float(g[k])) < 1e-6 * abs(float(g[k])) + 1e-6, k
+    assert torch.equal(aux["idx"].view(4, -1, 16, 16).transpose(0, 1), g["idx"])
+    for i in range(4):
+        assert rel_err(st0["ve.%d.embedding.weight" % i].grad, g["grad.ve.%d.embedding.weight" % i]) < 1e-5, i
+        assert torch.equal(new["ve.%d.embedding.weight" % i], st0["ve.%d.embedding.weight" % i])      # no EMA update
+    assert rel_err(enc["layers.0.weight"].grad, g["grad_enc_first"]) < 1e-4
+    assert rel_err(dec["layers.6.bias"].grad, g["grad_dec_last_bias"]) < 1e-4
+    assert int(g["generator_param_count"]) == len(enc) + len(dec) + 4        # the codebooks join the generator's optimizer
+
+
 def test_g6_inference_on_example_frames(golden):
     g = golden("g6_inference")
     seed = int(g["seed"])
