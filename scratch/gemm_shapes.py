@@ -1,5 +1,11 @@
 """Log the distinct tile-engine GEMM shapes of one DSFVT train step, then time each shape alone.
-usage: python scratch/gemm_shapes.py            (LVT_HIP_LIB=... selects a variant library)"""
+usage: python scratch/gemm_shapes.py            (LVT_HIP_LIB=... selects a variant library)
+
+STALE since round 4: the batched launches now address their batches by stride from ONE base pointer (the q / k / v slabs of the
+packed projection output, the two operands of a paired weight gradient), so `torch.randn_like(A)` below allocates less than the
+launch reads and the replay faults.  Kept for the round-3 table in profiles/r03_gemm_shape_and_power_probes.txt; per-kind timings
+of the current code are in the bench line (`roofline.per_kind`) and profiles/r05_dsfvt_kernel_stats.txt."""
+raise SystemExit(__doc__)
 import collections
 import os
 import sys
