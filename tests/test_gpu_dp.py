@@ -100,6 +100,76 @@ def test_vqvae_two_ranks_equal_one_big_batch(backend):
     assert abs(mean_loss - float(losses["loss_reconstruction"].detach())) < 1e-5 * mean_loss
 
 
+def _trained_codebook_model(seed, scale, dev):
+    """PR-DVQVAE2 with CODEBOOK.EMA False (the codebooks are parameters), seeded weights."""
+    from util_models import vqvae_cfg
+    from lvt_amd.modeling import build_model
+    cfg = vqvae_cfg(dev)
+    cfg.MODEL.CODEBOOK.EMA = False
+    model = build_model(cfg)
+    model.encoder.load_state_dict(seeded.seeded_params(seeded.VQVAE_ENCODER_SHAPES, seed, "enc."))
+    model.generator.load_state_dict(seeded.seeded_params(seeded.VQVAE_DECODER_SHAPES, seed, "dec."))
+    model.codebook.load_state_dict({k: v for k, v in seeded.seeded_codebook_state(seed, scale=scale).items()
+                                    if k.endswith("embedding.weight")})
+    model.train()
+    return model
+
+
+def _vq_trained_codebook_worker(rank, world, port, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from lvt_amd.utils.events import EventStorage
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _trained_codebook_model(50 + rank, 0.05 * (1 + rank), "cuda:0")          # ranks start different
+        model.wrap_parallel(device_ids=[0], broadcast_buffers=False)
+        x = seeded.seeded_input("dp", (8, 3, 64, 64), 9)[4 * rank:4 * rank + 4]
+        with EventStorage(0):
+            losses = model([{"image": x[i].numpy()} for i in range(4)], mode="supervised")
+        sum(losses.values()).backward()
+        model.finish_gradient_sync()
+        torch.cuda.synchronize()
+        ret[rank] = {"cb_w": model.codebook.ve[1].embedding.weight.detach().cpu(),
+                     "cb_g": [v.embedding.weight.grad.cpu() for v in model.codebook.ve],
+                     "g_enc": model.encoder.layers[4].weight.grad.cpu(), "keys": sorted(losses)}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_vqvae_trained_codebook_two_ranks_equal_one_big_batch():
+    """CODEBOOK.EMA False under data parallelism (the reference wraps the codebook in DDP, vqvae.py:46-49): the codebook is
+    broadcast with the other parameters and its gradients are averaged by a reducer of its own."""
+    from lvt_amd.utils.events import EventStorage
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_vq_trained_codebook_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    a, b = ret[0], ret[1]
+    assert a["keys"] == ["loss_commitment", "loss_dict", "loss_reconstruction"]
+    assert torch.equal(a["cb_w"], b["cb_w"]) and torch.equal(a["g_enc"], b["g_enc"])
+    for i in range(4):
+        assert torch.equal(a["cb_g"][i], b["cb_g"][i]), i
+    model = _trained_codebook_model(50, 0.05, "cuda:0")
+    x = seeded.seeded_input("dp", (8, 3, 64, 64), 9)
+    with EventStorage(0):
+        losses = model([{"image": x[i].numpy()} for i in range(8)], mode="supervised")
+    sum(losses.values()).backward()
+    for i in range(4):
+        assert rel_err(a["cb_g"][i], model.codebook.ve[i].embedding.weight.grad) < 1e-5, i
+    assert rel_err(a["g_enc"], model.encoder.layers[4].weight.grad) < 1e-4
+
+
 # ---- BASELINE configs[3]: DSFVT on Kinetics codes (configs/vt/KDSFVT.yaml), data parallel -------------------------
 def _vt_cfg(acc):
     from lvt_amd.config import get_cfg
