@@ -1215,13 +1215,21 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
     constexpr int NTAPS = MODE == 0 ? 9 : 4;
     constexpr int NP = MATH == 2 ? 2 : 3;
     constexpr int PSB = HPlane<BN>::SIZE;
-    constexpr int A_BYTES = NP * PT_PLANE * 2, B_BYTES = NP * PSB * 2;
+    // f16x2 (two planes): TWO patch images -- the patch of chunk c + 1 is fetched during the second-to-last tap step of chunk c
+    // and split + stored into the other image right behind the last tap step's MFMAs, instead of between two barriers
+    // of its own with the matrix pipe idle (bf16x3: three planes, one image fits).  -DLVT_PX_ONE_PATCH=1: the round-4 form.
+#ifndef LVT_PX_ONE_PATCH
+#define LVT_PX_ONE_PATCH 0
+#endif
+    constexpr bool DBLA = MATH == 2 && !LVT_PX_ONE_PATCH;
+    constexpr int A_IMG = NP * PT_PLANE;                                      // one patch image (bf16 / fp16 elements)
+    constexpr int A_BYTES = A_IMG * 2 * (DBLA ? 2 : 1), B_BYTES = NP * PSB * 2;
     constexpr int STAGE_FLOATS = (A_BYTES + 2 * B_BYTES) / 4 + 8;
     constexpr int TURN_FLOATS = WM * WN * 32 * (TN * 32);
     constexpr int LDS_FLOATS = STAGE_FLOATS > TURN_FLOATS ? STAGE_FLOATS : TURN_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     unsigned short *Ah = reinterpret_cast<unsigned short *>(lds);
-    unsigned short *Bh0 = Ah + NP * PT_PLANE;
+    unsigned short *Bh0 = Ah + A_IMG * (DBLA ? 2 : 1);
     int unscale = 0;
     float sa = 1.f, sb = 1.f;
     if (MATH == 2) { sa = lvt_f16_scale(p.a_amax, unscale); sb = lvt_f16_scale(p.b_amax, unscale); }
@@ -1264,13 +1272,13 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
             }
         }
     };
-    auto patch_store = [&]() {
+    auto patch_store = [&](unsigned short *img) {
 #pragma unroll
         for (int j = 0; j < PPASS; ++j) {
             const int u = tid + PT_THREADS * j;
             if (u < PUNITS) {
                 const int pp = u >> 3;
-                unsigned short *d = Ah + (MODE == 2 ? pp + pp / PWALK : pp) * HLD + (u & 7) * 4;
+                unsigned short *d = img + (MODE == 2 ? pp + pp / PWALK : pp) * HLD + (u & 7) * 4;
                 if (MATH == 2) {
                     uint2 ph, pl;
                     split2(pv[j], sa, ph, pl);
@@ -1332,7 +1340,7 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
     const int nchunks = (Ci / 32) * (MODE == 2 ? 4 : 1), nsteps = nchunks * NTAPS;
     patch_fetch(0);
     if (bact) b_fetch(0);
-    patch_store();
+    patch_store(Ah);
     if (bact) b_store(Bh0);
     __syncthreads();
 
@@ -1341,10 +1349,11 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
         const bool has_next = step + 1 < nsteps;
         const bool new_chunk = has_next && tap == NTAPS - 1;
         if (has_next && bact) b_fetch(step + 1);
-        if (new_chunk) patch_fetch(cc + 1);
+        if (DBLA ? (cc + 1 < nchunks && tap == NTAPS - 2) : new_chunk) patch_fetch(cc + 1);
         const unsigned short *Bh = Bh0 + (step & 1) * (NP * PSB);
-        const unsigned short *Ap = MODE == 0 ? Ah + ((tap / 3) * PT_PW + (tap % 3)) * HLD
-                                             : Ah + (((phase >> 1) + (tap >> 1)) * PT_PW + (phase & 1) + (tap & 1)) * HLD;   // (phase 0 in MODE 2)
+        const unsigned short *Acur = Ah + (DBLA ? (cc & 1) * A_IMG : 0);
+        const unsigned short *Ap = MODE == 0 ? Acur + ((tap / 3) * PT_PW + (tap % 3)) * HLD
+                                             : Acur + (((phase >> 1) + (tap >> 1)) * PT_PW + (phase & 1) + (tap & 1)) * HLD;   // (phase 0 in MODE 2)
         if constexpr (MATH == 2) {
 #pragma unroll
             for (int ks = 0; ks < BK; ks += 16) {
@@ -1372,6 +1381,10 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
                     for (int j = 0; j < TN; ++j)
                         acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0][j], acx[i][j], 0, 0, 0);
             }
+            // the other image was last read in chunk cc - 1 (every wave has passed NTAPS barriers since): its split + store follows
+            // the issue of this step's MFMAs with no barrier in between, the matrix pipe drains beside it.  (As part of the MFMA
+            // block itself -- one basic block for the scheduler to interleave -- the allocator spilled ~320 registers.)
+            if (DBLA && new_chunk) patch_store(Ah + ((cc + 1) & 1) * A_IMG);
         } else {
 #pragma unroll
             for (int ks = 0; ks < BK; ks += 16) {
@@ -1397,9 +1410,9 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
 #ifndef LVT_PX_NOBSPLIT      // (timing experiment: the weight tile is split + stored for step 0 only)
         if (has_next && bact) b_store(Bh0 + ((step + 1) & 1) * (NP * PSB));
 #endif
-        if (new_chunk) {
+        if (!DBLA && new_chunk) {
             __syncthreads();              // every wave is done with the old patch
-            patch_store();
+            patch_store(Ah);
         }
 #ifdef LVT_PX_HALFBARRIERS   // (timing experiment, wrong results: a barrier every second step)
         if ((step & 1) || new_chunk)
