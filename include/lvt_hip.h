@@ -33,7 +33,7 @@ extern "C" {
 #define LVT_ENODEVICE   (-4)   /* no gfx950 device visible                             */
 
 const char *lvt_last_error(void);
-int lvt_version(void);          /* 510 = round 5 (ABI changes are listed in INTEGRATION.md) */
+int lvt_version(void);          /* 600 = round 6 (ABI changes are listed in INTEGRATION.md) */
 /* Device probe: name, CU count, clock (kHz), HBM bytes.  Returns LVT_ENODEVICE without a GPU. */
 int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long long *hbm_bytes);
 
@@ -129,6 +129,46 @@ typedef struct {
 } lvt_gemm_desc;
 size_t lvt_gemm_workspace_bytes(const lvt_gemm_desc *d);
 int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- plane-fed GEMM of the f16x2 arithmetic (ABI 600, csrc/gemm_p2.hip; replaces the same torch linear / bmm products as
+ * lvt_gemm_f32: vt_attention.py:120-128,138 and their autograd backward) ------------------------------------------------------
+ * A "P2 image" of a matrix X[rows][K] (K % 32 == 0) is what the f16x2 arithmetic stages in LDS, made ONCE and kept in HBM:
+ *     X s = hi + 2^-11 lo,   hi = RN16(X s),  lo = RN16(2^11 (X s - hi)),   s = the power of two of LVT_MATH_F16X2 taken
+ * from a device scalar >= max |X| (the SAME scalar must be handed to every consumer as a_amax / b_amax).  Layout: row-major
+ * with the fp32 matrix's footprint (row pitch ld floats = 4 ld bytes); each group of 32 consecutive k of a row is one 128-byte
+ * line [fp16 hi of the 32 elements | fp16 lo of the 32 elements].  ld % 32 == 0, base 128-byte aligned.
+ * lvt_gemm_p2_f32:  C[z][m][n] = epi(alpha sum_k A[z](m,k) B[z](n,k))   -- both operands k-contiguous ("NT").
+ *   B is a P2 image (rows = n); A is a P2 image when a_planes != 0, else plain fp32 addressed as lvt_gemm_f32's ta == 0 operand
+ *   (two-level k through a_kb / a_skb allowed).  P2 operands go global memory -> LDS by LDS-DMA (no registers, no vector ALU);
+ *   an fp32 A is split in the kernel as in lvt_gemm_f32.  Results are bit-identical to lvt_gemm_f32 in LVT_MATH_F16X2 mode on
+ *   the fp32 matrices the images were made from.  Epilogue flags: BIAS, RESIDUAL, RELU, MASK.  Cp (nullable): the result is
+ *   ALSO written as a P2 image (row pitch ldcp, same batch offsets as C) under the scale of *cp_amax, a device scalar that must
+ *   bound max |C| a priori (an overflowing element becomes inf, like an fp16 cast).  c_amax as in lvt_gemm_f32.                 */
+typedef struct {
+    int M, N, K;
+    const void *A; long long lda; int a_planes; int a_kb; long long a_skb;
+    const void *B; long long ldb;
+    float *C; long long ldc;
+    int batch_outer, batch_inner;
+    long long sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
+    float alpha;
+    int flags;
+    const float *bias;
+    const float *res;  long long ldr;
+    const float *mask; long long ldm;
+    const float *a_amax, *b_amax;
+    float *c_amax;
+    void *Cp; long long ldcp; const float *cp_amax;
+} lvt_gemm_p2_desc;
+int lvt_gemm_p2_f32(const lvt_gemm_p2_desc *d, void *stream);
+/* P2 images of up to any number of fp32 matrices, 32 entries per launch (`entries` is a HOST array): src [rows][cols] with row pitch
+ * ld_src; transpose == 0: image rows = src rows, k = src columns; transpose == 1: image rows = src columns, k = src rows (the
+ * image of src^T).  The image's k extent must be a multiple of 32; ld_dst % 32 == 0; scale from *amax (device scalar).        */
+typedef struct { const float *src; void *dst; int rows, cols; long long ld_src, ld_dst; int transpose; const float *amax;
+                 int batch; long long bs_src, bs_dst; } lvt_p2_pack_entry;
+/* batch > 1: the entry stands for `batch` matrices of the same shape, src + z bs_src floats -> dst + z bs_dst floats (one scale):
+ * e.g. the packed (3 na, d, da) q/k/v weights -> one (3 na da, d) image with transpose = 1, bs_src = d da, bs_dst = da d.        */
+int lvt_p2_pack_multi(const lvt_p2_pack_entry *entries, int n, void *stream);
 
 /* Small-M variant (a few rows, e.g. one token per sample in incremental decoding): same addressing as
  * lvt_gemm_f32 with ta == 0, a single batch level (A shared, B += z*sB, C += z*sC), flags BIAS|RESIDUAL|RELU.
@@ -309,6 +349,11 @@ int lvt_layernorm_fwd(const float *x, long long rows, int d, float eps, const fl
 /* (y_amax / dx_amax, nullable: max |y| resp. max |dx| folded into a device scalar as lvt_amax_io.c is.  With w_amax and
  *  b_amax -- device scalars >= max |w|, max |b| -- the forward STORES the bound max |w| sqrt(d - 1) + max |b| into *y_amax
  *  instead of reducing: |(x - mean) rstd| <= sqrt(d - 1) on every row.)                                                   */
+/* The same forward that ALSO writes y as a P2 image `yp` (ABI 600; row pitch d floats, d % 32 == 0) under the scale of the
+ * a-priori bound it stores into *y_amax: w_amax, b_amax and y_amax are required.  The image feeds lvt_gemm_p2_f32 (a_planes). */
+int lvt_layernorm_fwd_p2(const float *x, long long rows, int d, float eps, const float *w, const float *b,
+                         float *y, void *yp, float *mean, float *rstd, float *y_amax, const float *w_amax,
+                         const float *b_amax, void *stream);
 size_t lvt_layernorm_bwd_workspace_bytes(int d);
 /* dx = LN'(dy) (+ add); dw[d], db[d] reduced in a fixed order                                        */
 int lvt_layernorm_bwd(const float *dy, const float *x, const float *mean, const float *rstd,

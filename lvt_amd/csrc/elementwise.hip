@@ -238,20 +238,54 @@ extern "C" int lvt_add_periodic(float *x, const float *table, long long rows, in
 // one wave per row, row kept in registers (d <= 1024), two-pass mean / variance
 // ------------------------------------------------------------------------------------------------
 #define LN_MAXV 4   // float4 per lane -> d <= 1024
+// the a-priori bound of a LayerNorm output (ONE expression: the P2 form scales its image by the value the consumers read back)
+__device__ __forceinline__ float ln_bound(const float *w_amax, const float *b_amax, int d) {
+    return fmaf(*w_amax, sqrtf((float)(d - 1)), *b_amax);
+}
+__device__ __forceinline__ float ln_mix_lo(unsigned h, float k, float c) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(k), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float ln_mix_hi(unsigned h, float k, float c) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(k), "v"(c));
+    return r;
+}
+typedef float ln_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 ln_f16x2 __attribute__((ext_vector_type(2)));
+// the f16x2 split of gemm_engine.hip (f16_split_pair<2048>), bit for bit
+__device__ __forceinline__ void ln_split_pair(float a, float b, float s, unsigned &ph, unsigned &pl) {
+    const ln_f32x2 v = {a, b};
+    ph = __builtin_bit_cast(unsigned, __builtin_convertvector(v * s, ln_f16x2));
+    const ln_f32x2 t2 = v * (s * 2048.f);
+    const ln_f32x2 r = {ln_mix_lo(ph, -2048.f, t2.x), ln_mix_hi(ph, -2048.f, t2.y)};
+    pl = __builtin_bit_cast(unsigned, __builtin_convertvector(r, ln_f16x2));
+}
+template <int P2>
 __global__ void lvt_layernorm_fwd_kernel(const float *__restrict__ x, long long rows, int d, float eps,
                                          const float *__restrict__ w, const float *__restrict__ b,
                                          float *__restrict__ y, float *__restrict__ mean_out,
                                          float *__restrict__ rstd_out, float *__restrict__ y_amax,
-                                         const float *__restrict__ w_amax, const float *__restrict__ b_amax) {
+                                         const float *__restrict__ w_amax, const float *__restrict__ b_amax,
+                                         char *__restrict__ yimg) {
     __shared__ float amax_scratch[4];
     const int lane = threadIdx.x & 63;
     const int d4 = d / 4;
     float am = 0.f;
+    float ps = 1.f;
+    if (P2) {
+        // scale of the image: lvt_f16_scale (gemm_engine.hip) of the bound that block 0 stores below
+        const int eb = (int)((__float_as_uint(ln_bound(w_amax, b_amax, d)) >> 23) & 0xffu);
+        int se = 268 - eb;
+        se = se < 2 ? 2 : (se > 252 ? 252 : se);
+        ps = __uint_as_float((unsigned)se << 23);
+    }
     if (y_amax && w_amax) {
         // a-priori bound instead of a reduction: |(x - mean) rstd| <= sqrt(d - 1) on every row, so
         // max |y| <= max |w| sqrt(d - 1) + max |b| -- ~4x above the actual maximum of a 16384 x 512 output (2 of the 27
         // binades an f16x2 operand scale has to spare), for one store instead of one atomic per workgroup
-        if (blockIdx.x == 0 && threadIdx.x == 0) *y_amax = *w_amax * sqrtf((float)(d - 1)) + *b_amax;
+        if (blockIdx.x == 0 && threadIdx.x == 0) *y_amax = ln_bound(w_amax, b_amax, d);
         y_amax = nullptr;
     }
     for (long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < rows;
@@ -286,6 +320,15 @@ __global__ void lvt_layernorm_fwd_kernel(const float *__restrict__ x, long long 
                 o.x = (v[i].x - mean) * rstd * ww.x + bb.x; o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
                 o.z = (v[i].z - mean) * rstd * ww.z + bb.z; o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
                 yp[c] = o;
+                if (P2) {
+                    // float4 c = elements 4 c .. 4 c + 3: group (4 c) / 32 of the row's image, 8 bytes into its hi and lo halves
+                    uint2 ph, pl;
+                    ln_split_pair(o.x, o.y, ps, ph.x, pl.x);
+                    ln_split_pair(o.z, o.w, ps, ph.y, pl.y);
+                    char *ip = yimg + (long long)row * d * 4 + (c >> 3) * 128 + (c & 7) * 8;
+                    *reinterpret_cast<uint2 *>(ip) = ph;
+                    *reinterpret_cast<uint2 *>(ip + 64) = pl;
+                }
                 am = fmaxf(am, fmaxf(fmaxf(lvt_absf(o.x), lvt_absf(o.y)), fmaxf(lvt_absf(o.z), lvt_absf(o.w))));
             }
         }
@@ -298,9 +341,20 @@ extern "C" int lvt_layernorm_fwd(const float *x, long long rows, int d, float ep
                                  void *stream) {
     LVT_REQUIRE(x && w && b && y && rows > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "layernorm_fwd: bad args (d=%d)", d);
     LVT_REQUIRE(!w_amax == !b_amax, "layernorm_fwd: w_amax and b_amax come together");
-    hipLaunchKernelGGL(lvt_layernorm_fwd_kernel, dim3(grid_for(rows, 4, (y_amax && !w_amax) ? 2048 : 16384)), dim3(256), 0,
-                       (hipStream_t)stream, x, rows, d, eps, w, b, y, mean, rstd, y_amax, w_amax, b_amax);
+    hipLaunchKernelGGL(lvt_layernorm_fwd_kernel<0>, dim3(grid_for(rows, 4, (y_amax && !w_amax) ? 2048 : 16384)), dim3(256), 0,
+                       (hipStream_t)stream, x, rows, d, eps, w, b, y, mean, rstd, y_amax, w_amax, b_amax, (char *)nullptr);
     LVT_CHECK_LAUNCH("lvt_layernorm_fwd_kernel");
+    return LVT_OK;
+}
+extern "C" int lvt_layernorm_fwd_p2(const float *x, long long rows, int d, float eps, const float *w, const float *b,
+                                    float *y, void *yp, float *mean, float *rstd, float *y_amax, const float *w_amax,
+                                    const float *b_amax, void *stream) {
+    LVT_REQUIRE(x && w && b && y && yp && rows > 0 && d % 32 == 0 && d <= 256 * LN_MAXV, "layernorm_fwd_p2: bad args (d=%d)", d);
+    LVT_REQUIRE(y_amax && w_amax && b_amax, "layernorm_fwd_p2: the image is scaled by the a-priori bound: y_amax, w_amax, b_amax are required");
+    LVT_REQUIRE(((uintptr_t)yp & 127) == 0, "layernorm_fwd_p2: the image must be 128-byte aligned");
+    hipLaunchKernelGGL(lvt_layernorm_fwd_kernel<1>, dim3(grid_for(rows, 4, 16384)), dim3(256), 0,
+                       (hipStream_t)stream, x, rows, d, eps, w, b, y, mean, rstd, y_amax, w_amax, b_amax, (char *)yp);
+    LVT_CHECK_LAUNCH("lvt_layernorm_fwd_kernel<p2>");
     return LVT_OK;
 }
 

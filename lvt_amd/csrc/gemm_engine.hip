@@ -19,6 +19,7 @@
 //   transposed convolution; the parity classes of the stride-2 convolution).  Staging, not the matrix pipe, bounds (1):
 //   profiles/r02_engine_staging_experiments.txt.  The matching weight-gradient kernel lives in conv_wgrad.hip.
 #include "lvt_common.h"
+#include "epilogue_fast.h"
 #include <string.h>
 #include <stdlib.h>
 #include <stdint.h>
@@ -1651,12 +1652,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void lvt_gemm_wide_kernel(const KP
     }
     if (kt < ntiles) tile(S0 + (kt & 1) * STAGE, nullptr, no_t(), no_t());
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = ldexpf(fmaf(acx[i][j][r], 1.f / 2048.f, acc[i][j][r]), unscale);
+    lvt_f16x2_finish<TM, TN>(acc, acx, unscale);
 
     if (TA && sum_on) {
         // column sums of everything this workgroup fetched (bias gradient): lanes with the same m quad are added in kk0 order
@@ -1670,6 +1666,27 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void lvt_gemm_wide_kernel(const KP
         }
         __syncthreads();
     }
+#ifndef LVT_NO_FAST_EPILOGUE
+    if (p.vec_epi && !(p.flags & (LVT_EPI_PLANES | LVT_EPI_ACCUM | LVT_EPI_TANH))) {
+        // plain forms (every launch of the transformer): epilogue_fast.h -- same arithmetic, compile-time flag sets, no workgroup
+        // barriers, max |C| peeked before the stores
+        LvtEpi e;
+        e.M = p.M; e.N = p.N;
+        float *wave_tile = lds + wave * (32 * TN * 32);
+        if (p.splits > 1) {
+            e.C = p.partial; e.ldc = p.N; e.coff = tc.split * p.partial_stride + (long long)tc.z * p.M * p.N; e.alpha = 1.f; e.flags = 0;
+            e.bias = nullptr; e.res = nullptr; e.ldr = 0; e.mask = nullptr; e.ldm = 0;
+            (void)lvt_epi_fast_wave<0, TM, TN>(e, acc, wave_tile, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+            return;
+        }
+        const unsigned seen = lvt_amax_peek(p.c_amax);
+        e.C = p.C; e.ldc = p.ldc; e.coff = tc.coff; e.alpha = p.alpha; e.flags = p.flags;
+        e.bias = p.bias; e.res = p.res; e.ldr = p.ldr; e.mask = p.mask; e.ldm = p.ldm;
+        const float am_w = lvt_epi_fast_dispatch<TM, TN>(e, acc, wave_tile, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+        if (p.c_amax) lvt_block_amax_commit_seen(am_w, p.c_amax, lds + TURN_FLOATS, seen);
+        return;
+    }
+#endif
     if (p.vec_epi) lvt_epilogue_vec<AMODE, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, 0, tc.coff, tc.z, tc.split);
     else lvt_epilogue<AMODE, BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, l31, half, 0, tc.coff, tc.z, tc.split);
 }

@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("LVT_HIP_LIB") or os.path.join(os.path.dirname(_HERE)
 
 EPI_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_TANH, EPI_MASK, EPI_ACCUM, EPI_PLANES = 1, 2, 4, 8, 16, 32, 64
 CAUSAL_KMAX, CAUSAL_KMIN, CAUSAL_TILE = 1 << 8, 1 << 9, 1 << 10      # causal attention products (include/lvt_hip.h)
-ABI_VERSION = 510           # lvt_version() of the library this module binds (argument lists below)
+ABI_VERSION = 600           # lvt_version() of the library this module binds (argument lists below)
 MATH_F32 = 1 << 16          # per-call arithmetic selectors of the engine entry points (include/lvt_hip.h)
 MATH_F16X2 = 1 << 18
 ONEHOT_DENSE = 1 << 19
@@ -40,6 +40,30 @@ class GemmDesc(C.Structure):
         ("a_colsum", C.c_void_p), ("c_plane", C.c_longlong),
         ("a_amax", C.c_void_p), ("b_amax", C.c_void_p), ("a_amax2", C.c_void_p), ("b_amax2", C.c_void_p), ("c_amax", C.c_void_p),
     ]
+
+
+class GemmP2Desc(C.Structure):
+    """lvt_gemm_p2_desc (include/lvt_hip.h): the plane-fed NT GEMM of the f16x2 arithmetic."""
+    _fields_ = [
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("A", C.c_void_p), ("lda", C.c_longlong), ("a_planes", C.c_int), ("a_kb", C.c_int), ("a_skb", C.c_longlong),
+        ("B", C.c_void_p), ("ldb", C.c_longlong),
+        ("C", C.c_void_p), ("ldc", C.c_longlong),
+        ("batch_outer", C.c_int), ("batch_inner", C.c_int),
+        ("sA_o", C.c_longlong), ("sA_i", C.c_longlong), ("sB_o", C.c_longlong), ("sB_i", C.c_longlong),
+        ("sC_o", C.c_longlong), ("sC_i", C.c_longlong),
+        ("alpha", C.c_float), ("flags", C.c_int),
+        ("bias", C.c_void_p), ("res", C.c_void_p), ("ldr", C.c_longlong),
+        ("mask", C.c_void_p), ("ldm", C.c_longlong),
+        ("a_amax", C.c_void_p), ("b_amax", C.c_void_p), ("c_amax", C.c_void_p),
+        ("Cp", C.c_void_p), ("ldcp", C.c_longlong), ("cp_amax", C.c_void_p),
+    ]
+
+
+class P2PackEntry(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld_src", C.c_longlong),
+                ("ld_dst", C.c_longlong), ("transpose", C.c_int), ("amax", C.c_void_p),
+                ("batch", C.c_int), ("bs_src", C.c_longlong), ("bs_dst", C.c_longlong)]
 
 
 class AmaxEntry(C.Structure):
@@ -82,6 +106,9 @@ def _declare(lib):
         "lvt_device_info": (ci, [C.c_char_p, ci, P(ci), P(ci), P(cll)]),
         "lvt_gemm_workspace_bytes": (sz, [P(GemmDesc)]),
         "lvt_gemm_f32": (ci, [P(GemmDesc), vp, sz, vp]),
+        "lvt_gemm_p2_f32": (ci, [P(GemmP2Desc), vp]),
+        "lvt_p2_pack_multi": (ci, [P(P2PackEntry), ci, vp]),
+        "lvt_layernorm_fwd_p2": (ci, [vp, cll, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "lvt_gemm_smallm_f32": (ci, [ci, ci, ci, ci, vp, cll, vp, cll, vp, cll, ci, cll, cll, cf, ci, vp, vp, cll, vp, cll, cll, vp]),
         "lvt_gemm_smallm_splitk_workspace_bytes": (sz, [ci, ci, ci]),
         "lvt_gemm_smallm_splitk_f32": (ci, [ci, ci, ci, ci, vp, cll, vp, cll, vp, cll, cf, ci, vp, vp, cll, vp, cll, cll, vp, sz, vp]),

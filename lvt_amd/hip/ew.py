@@ -91,6 +91,21 @@ def layernorm_fwd(x, w, b, eps=1e-5, save_stats=True):
     return y, mean, rstd
 
 
+def layernorm_fwd_p2(x, w, b, eps=1e-5):
+    """layernorm_fwd that also writes the output as a P2 image (csrc/gemm_p2.hip) under the a-priori bound it stores as the
+    output's max |.|: -> (y, image data (float32-typed, y's shape), mean, rstd).  f16x2 arithmetic only."""
+    L.require(x, w, b)
+    d = x.shape[-1]
+    rows = x.numel() // d
+    y = torch.empty_like(x)
+    yp = torch.empty_like(x)
+    mean, rstd = _f32(rows, like=x), _f32(rows, like=x)
+    L.check(L.lib().lvt_layernorm_fwd_p2(L.ptr(x), rows, d, eps, L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(yp), L.ptr(mean),
+                                         L.ptr(rstd), L.out_amax(y), L.ptr(L.amax_of(w)), L.ptr(L.amax_of(b)),
+                                         L.stream_ptr()), "lvt_layernorm_fwd_p2")
+    return y, yp, mean, rstd
+
+
 def layernorm_bwd(dy, x, mean, rstd, w, add=None):
     L.require(dy, x, mean, rstd, w, add)
     d = x.shape[-1]

@@ -54,6 +54,74 @@ def gemm(A, B, C_out, M, N, K, ta=0, tb=0, lda=None, ldb=None, ldc=None, a_kb=0,
     return C_out
 
 
+class P2Image:
+    """The P2 image (include/lvt_hip.h, csrc/gemm_p2.hip) of a (rows, K) fp32 matrix: `data` has the matrix's shape and dtype
+    float32 but holds the image bytes (per row and group of 32 k: 32 fp16 hi terms, then 32 fp16 lo terms); `amax` is the device
+    scalar whose power-of-two scale the image was made under -- every consumer must be handed the same scalar."""
+    __slots__ = ("data", "amax")
+
+    def __init__(self, data, amax):
+        self.data, self.amax = data, amax
+
+
+def p2_supported():
+    """The plane-fed GEMM path exists for the f16x2 arithmetic only (LVT_NO_P2=1: A/B switch, everything stays on lvt_gemm_f32)."""
+    return L.f16x2() and not os.environ.get("LVT_NO_P2")
+
+
+def p2_pack(specs):
+    """P2 images of many matrices in ONE launch per 64 (lvt_p2_pack_multi).  specs: (src, transpose, dst, amax[, batch, bs_src,
+    bs_dst]) with src a 2-D fp32 view with unit column stride (row stride = src.stride(0)), dst a 2-D float32 view that receives
+    the image (rows = src rows, or src columns when transpose; its row stride must be a multiple of 32) and amax the device
+    scalar of the scale; batch > 1 repeats the entry for matrices bs_src / bs_dst floats apart."""
+    arr = (L.P2PackEntry * len(specs))()
+    for e, sp in zip(arr, specs):
+        src, transpose, dst, amax = sp[:4]
+        if src.dim() != 2 or dst.dim() != 2 or src.stride(1) != 1 or dst.stride(1) != 1 or not src.is_cuda:
+            raise L.LvtError("p2_pack: 2-D device views with unit column stride expected")
+        e.src, e.dst, e.rows, e.cols = src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1]
+        e.ld_src, e.ld_dst, e.transpose, e.amax = src.stride(0), dst.stride(0), int(bool(transpose)), amax.data_ptr()
+        e.batch, e.bs_src, e.bs_dst = sp[4:7] if len(sp) > 4 else (1, 0, 0)
+    L.check(L.lib().lvt_p2_pack_multi(arr, len(specs), L.stream_ptr()), "lvt_p2_pack_multi")
+
+
+def gemm_p2(A, Bimg, C_out, M, N, K, lda=None, a_kb=0, a_skb=0, ldb=None, ldc=None, batch_outer=1, batch_inner=1, sA=(0, 0),
+            sB=(0, 0), sC=(0, 0), alpha=1.0, flags=0, bias=None, res=None, ldr=0, mask=None, ldm=0, out_image=None, out_bound=None):
+    """C = epi(alpha * A @ B^T) with B a P2Image (rows = n, k contiguous) and A a P2Image or an fp32 tensor (lvt_gemm_p2_f32).
+    out_image (a float32 tensor shaped like C_out) additionally receives the P2 image of the result under the scale of the
+    device scalar out_bound, an a-priori bound of max |C|; returns (C_out, P2Image or None)."""
+    a_img = isinstance(A, P2Image)
+    At = A.data if a_img else A
+    L.require(C_out, bias, res, mask)
+    d = L.GemmP2Desc()
+    d.M, d.N, d.K = M, N, K
+    d.A, d.lda, d.a_planes, d.a_kb, d.a_skb = At.data_ptr(), (lda if lda is not None else K), int(a_img), a_kb, a_skb
+    d.B, d.ldb = Bimg.data.data_ptr(), (ldb if ldb is not None else K)
+    d.C, d.ldc = C_out.data_ptr(), (ldc if ldc is not None else N)
+    d.batch_outer, d.batch_inner = batch_outer, batch_inner
+    d.sA_o, d.sA_i = sA
+    d.sB_o, d.sB_i = sB
+    d.sC_o, d.sC_i = sC
+    d.alpha, d.flags = alpha, flags | L.MATH_F16X2
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.res = res.data_ptr() if res is not None else None
+    d.ldr = ldr if res is not None and ldr else d.ldc
+    d.mask = mask.data_ptr() if mask is not None else None
+    d.ldm = ldm if mask is not None and ldm else d.ldc
+    d.a_amax = (A.amax if a_img else L.amax_of(A)).data_ptr()
+    d.b_amax = Bimg.amax.data_ptr()
+    d.c_amax = L.new_amax(C_out).data_ptr()
+    img = None
+    if out_image is not None:
+        d.Cp, d.ldcp, d.cp_amax = out_image.data_ptr(), d.ldc, out_bound.data_ptr()
+        img = P2Image(out_image, out_bound)
+    t0 = L.TIMER.begin() if L.TIMER is not None else None
+    L.check(L.lib().lvt_gemm_p2_f32(C.byref(d), L.stream_ptr()), "lvt_gemm_p2_f32")
+    if t0 is not None:
+        L.TIMER.end("gemm_p2a" if a_img else "gemm_p2", 2.0 * M * N * K * batch_outer * batch_inner, t0)
+    return C_out, img
+
+
 def _smallm_splits(N, K):
     """k ranges of 256 for reductions of 1024 and more (one workgroup per 32 columns walks k at ~1.3 us per 128: a
     64 x 512 x 2048 product takes 23 us on 16 CUs unsplit, ~8 us as 8 x 16 workgroups plus the reduction launch)."""

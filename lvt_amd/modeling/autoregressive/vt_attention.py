@@ -104,6 +104,42 @@ def _splits(tiles, k):
     return max(1, min(s, k // 512 if k >= 1024 else 1))
 
 
+P2_IMAGES = None     # None: whenever the arithmetic is f16x2 (hip/gemm.py p2_supported); False: never (tests force either side)
+
+
+def prefetch_p2_images(module):
+    """Round 6: the P2 images (csrc/gemm_p2.hip) of the weights that meet a LayerNorm output in a forward product -- the packed
+    q/k/v weights as (3 na da, d) rows and the first FFN weight -- for every attention layer of `module`, in ONE launch per 64
+    matrices at the start of a pass (the weights change once per optimizer step).  Those two products then run with both
+    operands staged by LDS-DMA (no split, no registers): bit-identical results, -13 % on the q/k/v product.  The images ride on
+    the layers (`_p2`) and are dropped in the other arithmetic modes."""
+    use = G.p2_supported() and P2_IMAGES is not False
+    specs, layers = [], []
+    for m in module.modules():
+        if not isinstance(m, BlockLocalAttention):
+            continue
+        m._p2 = None
+        mha, f1 = m.mha, m.ffn[1]
+        na, d, da = mha.w_q.shape
+        if not use or not mha.w_q.is_cuda or d % 32 or da % 32 or f1.weight.shape[1] % 32:
+            continue
+        wqkv = mha.packed_qkv()
+        buf = getattr(m, "_p2_buf", None)
+        if buf is None or buf[0].device != wqkv.device or buf[0].shape != (3 * na * da, d) or buf[1].shape != f1.weight.shape:
+            buf = m._p2_buf = (torch.empty(3 * na * da, d, dtype=torch.float32, device=wqkv.device),
+                               torch.empty_like(f1.weight, dtype=torch.float32))
+        aq, a1 = L.amax_of(wqkv), L.amax_of(f1.weight)
+        # (3 na) blocks of (d, da) -> image rows (p, h, j), k = d: one batched entry (building 24 views per layer cost the host
+        # 1.7 ms per pass, more than the launches gain)
+        specs.append((wqkv.view(3 * na * d, da)[:d], True, buf[0][:da], aq, 3 * na, d * da, da * d))
+        specs.append((f1.weight.detach(), False, buf[1], a1))
+        layers.append((m, G.P2Image(buf[0], aq), G.P2Image(buf[1], a1)))
+    if specs:
+        G.p2_pack(specs)
+    for m, iq, i1 in layers:
+        m._p2 = (iq, i1)
+
+
 def linear_wgrad(dy, x, n_out, k_in, rows, want_bias=False):
     """dW (n_out, k_in) = dy^T x with deterministic split-K; want_bias additionally returns db = column sums of dy,
     accumulated by the same launch from the dy tiles it streams."""
@@ -179,7 +215,7 @@ def _use_planes(S, da, block, pairs):
 class _BlockLocalAttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, block, masked, dt, dh, dw, ln_w, ln_b, w_q, w_k, w_v, proj_w, f0w, f0b, f1w, f1b, f3w, f3b,
-                wqkv):
+                wqkv, p2=None):
         L.require(x)
         M, d = x.shape
         S = block[0] * block[1] * block[2]
@@ -188,9 +224,16 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         hd = na * da
         temper = math.sqrt(da)
         dev = x.device
-        xn, mean1, rstd1 = ew.layernorm_fwd(x, ln_w, ln_b)
         flash = FUSED_ATTENTION and _use_flash(S, da, block, b * na)
         planes = FUSED_ATTENTION and not flash and _use_planes(S, da, block, b * na)
+        # p2 = (image of the packed q/k/v weights, image of the first FFN weight) made by prefetch_p2_images: the two products
+        # that read a LayerNorm output then take BOTH operands as P2 images (the LayerNorm writes its output a second time, as an
+        # image under its a-priori bound) and stage them by LDS-DMA -- same bits as the engine's in-kernel split
+        p2 = p2 if (p2 is not None and not planes and G.p2_supported()) else None
+        if p2 is not None:
+            xn, xn_img, mean1, rstd1 = ew.layernorm_fwd_p2(x, ln_w, ln_b)
+        else:
+            xn, mean1, rstd1 = ew.layernorm_fwd(x, ln_w, ln_b)
         if planes:
             # q, k, v of all heads in ONE launch whose epilogue writes them as their exact 3-way bf16 split (3 operands x
             # 3 planes x (M, hd)): the operand format of the pipelined attention kernels, which then stage by copying
@@ -201,8 +244,13 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         else:
             # q, k, v of all heads in ONE launch: 3 x na batches of (M x da x d) against the packed weights, C = (3, M, hd)
             qkv = torch.empty(3, M, hd, dtype=torch.float32, device=dev)
-            G.gemm(xn, wqkv, qkv, M, da, d, ta=0, tb=1, lda=d, ldb=da, ldc=hd, batch_outer=3, batch_inner=na,
-                   sB=(na * d * da, d * da), sC=(M * hd, da))
+            if p2 is not None:
+                G.gemm_p2(G.P2Image(xn_img, L.amax_of(xn)), p2[0], qkv, M, da, d, lda=d, ldb=d, ldc=hd, batch_outer=3,
+                          batch_inner=na, sB=(na * da * d, da * d), sC=(M * hd, da))
+                del xn_img
+            else:
+                G.gemm(xn, wqkv, qkv, M, da, d, ta=0, tb=1, lda=d, ldb=da, ldc=hd, batch_outer=3, batch_inner=na,
+                       sB=(na * d * da, d * da), sC=(M * hd, da))
             q, k, v = qkv[0], qkv[1], qkv[2]
         if planes:
             pass
@@ -220,9 +268,14 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
                    sA=(na * S * S, S * S), sB=(S * hd, da), sC=(S * hd, da))
         y1 = torch.empty(M, d, dtype=torch.float32, device=dev)
         G.gemm(o, proj_w, y1, M, d, hd, flags=L.EPI_RESIDUAL, res=x)
-        fn, mean2, rstd2 = ew.layernorm_fwd(y1, f0w, f0b)
         h1 = torch.empty(M, f1w.shape[0], dtype=torch.float32, device=dev)
-        G.gemm(fn, f1w, h1, M, f1w.shape[0], d, flags=L.EPI_BIAS | L.EPI_RELU, bias=f1b)
+        if p2 is not None:
+            fn, fn_img, mean2, rstd2 = ew.layernorm_fwd_p2(y1, f0w, f0b)
+            G.gemm_p2(G.P2Image(fn_img, L.amax_of(fn)), p2[1], h1, M, f1w.shape[0], d, flags=L.EPI_BIAS | L.EPI_RELU, bias=f1b)
+            del fn_img
+        else:
+            fn, mean2, rstd2 = ew.layernorm_fwd(y1, f0w, f0b)
+            G.gemm(fn, f1w, h1, M, f1w.shape[0], d, flags=L.EPI_BIAS | L.EPI_RELU, bias=f1b)
         if L.RELU_TRACE is not None:
             L.RELU_TRACE.append(h1 > 0)
         y2 = torch.empty(M, d, dtype=torch.float32, device=dev)
@@ -314,7 +367,7 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
                sB=(M * hd, da), sC=(na * d * da, d * da), splits=_splits(3 * na * -(-d // 128), M))
         dx, dlnw, dlnb = ew.layernorm_bwd(dxn, x, mean1, rstd1, ln_w, add=dy1)
         return (dx, None, None, ddt, ddh, ddw, dlnw, dlnb, dws[0], dws[1], dws[2], dproj, df0w, df0b,
-                df1w, df1b, df3w, df3b, None)
+                df1w, df1b, df3w, df3b, None, None)
 
 
 class BlockLocalAttention(nn.Module):
@@ -360,7 +413,7 @@ class BlockLocalAttention(nn.Module):
         y = _BlockLocalAttentionFn.apply(
             x_tok, self.block_size, self.masked, self.dt_bank, self.dh_bank, self.dw_bank,
             m.layer_norm.weight, m.layer_norm.bias, m.w_q, m.w_k, m.w_v, m.proj.weight,
-            f[0].weight, f[0].bias, f[1].weight, f[1].bias, f[3].weight, f[3].bias, m.packed_qkv())
+            f[0].weight, f[0].bias, f[1].weight, f[1].bias, f[3].weight, f[3].bias, m.packed_qkv(), getattr(self, "_p2", None))
         if split:
             y = _RowPermuteFn.apply(y, inv, perm, S)
         return y

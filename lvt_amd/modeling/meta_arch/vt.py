@@ -15,6 +15,7 @@ from ...solver import build_lr_scheduler, build_optimizer
 from ...utils.checkpoint import Checkpointer
 from ...utils.events import get_event_storage
 from ..autoregressive import build_autoregressive
+from ..autoregressive.vt_attention import prefetch_p2_images
 from ..autoregressive.vt_utils import slice_and_context, subscale_order
 from .build import META_ARCH_REGISTRY
 from .common import init_weights, stack_to_device
@@ -142,6 +143,7 @@ class VideoTransformerModel(nn.Module):
         scan every weight matrix in one launch.  A no-op in the other math modes."""
         L.bump_epoch()
         L.prefetch_module_weights(self)
+        prefetch_p2_images(self)
 
     def compute_supervised_loss(self, context, slice, slice_idx, ignore_mask, iter=0, class_idx=None):
         self._begin_pass()
