@@ -8,10 +8,11 @@
 // removing its global stores changes 0.7 us -- the epilogue is bound by its own instruction stream, not by memory.  The K = 512
 // products of a transformer layer are one such tile per CU and launch: a third of their time.
 //
-// Here, for the plain forms (row-major C, flags in {BIAS, RESIDUAL, RELU, MASK}, or the split-K partial store):
+// Here, for the plain forms (row-major C or the pixel permutation of the frame-resident convolutions, flags in {BIAS, RESIDUAL,
+// RELU, MASK}, or the split-K partial store):
 //   * the flag set is a template parameter (the kernels switch over the six combinations the models use; anything else takes
 //     the run-time form of the same body);
-//   * a lane's column is fixed (bias loaded once), its rows step by 4: addresses are one 64-bit base + a running offset;
+//   * a lane's column is fixed (bias loaded once), its rows step by 4;
 //   * the residual / mask values of a 32-row round are requested before its first store;
 //   * the LDS turn-table of a wave is private to the wave and LDS executes a wave's instructions in order, so there is NO
 //     workgroup barrier inside: waves drain independently;
@@ -53,11 +54,14 @@ struct LvtEpi {
     const float *bias; const float *res; long long ldr; const float *mask; long long ldm;
 };
 
+// tile row -> row of C: identity for the GEMMs; the frame-resident convolutions permute the pixels of a frame (gemm_engine.hip)
+struct LvtRowIdentity { __device__ __forceinline__ long long operator()(int row) const { return row; } };
+
 // F >= 0: compile-time flag set; F < 0: the flags of `e` at run time.  Returns the wave's max |stored value|.
 // wave_tile: 32 x 64 floats of LDS private to the wave.  (m_w, n_w): first row / column of the wave's 64 x 64 sub-tile.
-template <int F, int TM, int TN>
+template <int F, int TM, int TN, class RM = LvtRowIdentity>
 __device__ __forceinline__ float lvt_epi_fast_wave(const LvtEpi &e, lvt_f32x16 (&acc)[TM][TN], float *wave_tile, int m_w, int n_w,
-                                                   int lane) {
+                                                   int lane, const RM rm = RM()) {
     static_assert(TM == 2 && TN == 2, "64 x 64 sub-tiles");
     constexpr int SW = TN * 32;
     const int flags = F >= 0 ? F : e.flags;
@@ -76,21 +80,23 @@ __device__ __forceinline__ float lvt_epi_fast_wave(const LvtEpi &e, lvt_f32x16 (
 #pragma unroll
             for (int r = 0; r < 16; ++r) wave_tile[((r & 3) + 8 * (r >> 2) + 4 * half) * SW + 32 * j + l31] = acc[i][j][r];
         const int row0 = m_w + i * 32 + r0;                                  // rows row0 + 4 u, u = 0 .. 7
-        const long long cbase = e.coff + (long long)row0 * e.ldc + col;
+        long long orow[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) orow[u] = rm(row0 + 4 * u);
         float4 rv[8], mv[8];
         if (f_res) {
-            const float *rp = e.res + e.coff + (long long)row0 * e.ldr + col;
+            const float *rp = e.res + e.coff + col;
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                rv[u] = (colok && row0 + 4 * u < e.M) ? *reinterpret_cast<const float4 *>(rp + (long long)(4 * u) * e.ldr) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rv[u] = (colok && row0 + 4 * u < e.M) ? *reinterpret_cast<const float4 *>(rp + orow[u] * e.ldr) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (f_mask) {
-            const float *mp = e.mask + e.coff + (long long)row0 * e.ldm + col;
+            const float *mp = e.mask + e.coff + col;
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                mv[u] = (colok && row0 + 4 * u < e.M) ? *reinterpret_cast<const float4 *>(mp + (long long)(4 * u) * e.ldm) : make_float4(0.f, 0.f, 0.f, 0.f);
+                mv[u] = (colok && row0 + 4 * u < e.M) ? *reinterpret_cast<const float4 *>(mp + orow[u] * e.ldm) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        float *cp = e.C + cbase;
+        float *cp = e.C + e.coff + col;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             float4 v = *reinterpret_cast<const float4 *>(&wave_tile[(r0 + 4 * u) * SW + 4 * c4]);
@@ -101,7 +107,7 @@ __device__ __forceinline__ float lvt_epi_fast_wave(const LvtEpi &e, lvt_f32x16 (
             if (f_mask) { v.x = mv[u].x > 0.f ? v.x : 0.f; v.y = mv[u].y > 0.f ? v.y : 0.f; v.z = mv[u].z > 0.f ? v.z : 0.f; v.w = mv[u].w > 0.f ? v.w : 0.f; }
             if (colok && row0 + 4 * u < e.M) {
                 am = fmaxf(am, fmaxf(fmaxf(lvt_absf(v.x), lvt_absf(v.y)), fmaxf(lvt_absf(v.z), lvt_absf(v.w))));
-                *reinterpret_cast<float4 *>(cp + (long long)(4 * u) * e.ldc) = v;
+                *reinterpret_cast<float4 *>(cp + orow[u] * e.ldc) = v;
             }
         }
     }
@@ -109,17 +115,22 @@ __device__ __forceinline__ float lvt_epi_fast_wave(const LvtEpi &e, lvt_f32x16 (
 }
 
 // the switch over the flag sets of the models' launches
-template <int TM, int TN>
-__device__ __forceinline__ float lvt_epi_fast_dispatch(const LvtEpi &e, lvt_f32x16 (&acc)[TM][TN], float *wave_tile, int m_w, int n_w, int lane) {
+template <int TM, int TN, class RM = LvtRowIdentity>
+__device__ __forceinline__ float lvt_epi_fast_dispatch(const LvtEpi &e, lvt_f32x16 (&acc)[TM][TN], float *wave_tile, int m_w, int n_w, int lane,
+                                                       const RM rm = RM()) {
+#define LVT_EPI_CASE(F) case (F): return lvt_epi_fast_wave<(F), TM, TN, RM>(e, acc, wave_tile, m_w, n_w, lane, rm)
     switch (e.flags & (LVT_EPI_BIAS | LVT_EPI_RESIDUAL | LVT_EPI_RELU | LVT_EPI_MASK)) {
-    case 0: return lvt_epi_fast_wave<0, TM, TN>(e, acc, wave_tile, m_w, n_w, lane);
-    case LVT_EPI_BIAS | LVT_EPI_RELU: return lvt_epi_fast_wave<LVT_EPI_BIAS | LVT_EPI_RELU, TM, TN>(e, acc, wave_tile, m_w, n_w, lane);
-    case LVT_EPI_BIAS | LVT_EPI_RESIDUAL: return lvt_epi_fast_wave<LVT_EPI_BIAS | LVT_EPI_RESIDUAL, TM, TN>(e, acc, wave_tile, m_w, n_w, lane);
-    case LVT_EPI_RESIDUAL: return lvt_epi_fast_wave<LVT_EPI_RESIDUAL, TM, TN>(e, acc, wave_tile, m_w, n_w, lane);
-    case LVT_EPI_MASK: return lvt_epi_fast_wave<LVT_EPI_MASK, TM, TN>(e, acc, wave_tile, m_w, n_w, lane);
-    case LVT_EPI_BIAS: return lvt_epi_fast_wave<LVT_EPI_BIAS, TM, TN>(e, acc, wave_tile, m_w, n_w, lane);
-    default: return lvt_epi_fast_wave<-1, TM, TN>(e, acc, wave_tile, m_w, n_w, lane);
+    LVT_EPI_CASE(0);
+    LVT_EPI_CASE(LVT_EPI_BIAS);
+    LVT_EPI_CASE(LVT_EPI_BIAS | LVT_EPI_RELU);
+    LVT_EPI_CASE(LVT_EPI_BIAS | LVT_EPI_RESIDUAL);
+    LVT_EPI_CASE(LVT_EPI_BIAS | LVT_EPI_RESIDUAL | LVT_EPI_RELU);
+    LVT_EPI_CASE(LVT_EPI_RESIDUAL);
+    LVT_EPI_CASE(LVT_EPI_MASK);
+    LVT_EPI_CASE(LVT_EPI_RESIDUAL | LVT_EPI_MASK);
+    default: return lvt_epi_fast_wave<-1, TM, TN, RM>(e, acc, wave_tile, m_w, n_w, lane, rm);
     }
+#undef LVT_EPI_CASE
 }
 
 // max |C| of the workgroup into the device scalar: `seen` is the scalar's value read by thread 0 at the start of the epilogue (a

@@ -728,6 +728,9 @@ __device__ __forceinline__ long long patcht_orow(int row, int cls) {
     return (long long)(row >> 8) * 1024 + (2 * y + (cls >> 1)) * 32 + 2 * x + (cls & 1);
 }
 
+struct PatchRows { __device__ __forceinline__ long long operator()(int row) const { return patch_orow(row); } };
+struct PatchTRows { int cls; __device__ __forceinline__ long long operator()(int row) const { return patcht_orow(row, cls); } };
+
 // ------------------------------------------------------------------------------------------------
 // epilogue shared by the kernels: alpha / bias / residual / ReLU / tanh / mask / accumulate, or split-K partials
 // ------------------------------------------------------------------------------------------------
@@ -1165,15 +1168,8 @@ __global__ __launch_bounds__(NTHREADS, (MATH == 2 ? 2 : LVT_MINWAVES)) void lvt_
         }
         __syncthreads();
     }
-    if constexpr (MATH == 2) {
-        // result = (hi hi + 2^-11 (hi lo + lo hi)) / (sa sb): one fma and one exact exponent shift per element
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = ldexpf(fmaf(acx[i][j][r], 1.f / 2048.f, acc[i][j][r]), unscale);
-    }
+    // result = (hi hi + 2^-11 (hi lo + lo hi)) / (sa sb)
+    if constexpr (MATH == 2) lvt_f16x2_finish<TM, TN>(acc, acx, unscale);
 
     if constexpr (COLSUM) {
         if (bl.sum_on) bl.write_colsum(lds, p.colsum_partial + (long long)split * p.N, n0, p.N, tid);   // staging LDS is free now
@@ -1181,6 +1177,29 @@ __global__ __launch_bounds__(NTHREADS, (MATH == 2 ? 2 : LVT_MINWAVES)) void lvt_
     if constexpr (COLSUM_A) {
         if (al.sum_on) al.write_colsum(lds, p.colsum_partial + ((long long)split * gridDim.y + z) * p.M, m0, p.M, tid);
     }
+#ifndef LVT_NO_FAST_EPILOGUE
+    if constexpr (AMODE != A_CONVT_K && TM == 2 && TN == 2 && LDS_FLOATS >= TURN_FLOATS + 16) {
+        if (p.vec_epi && !(p.flags & (LVT_EPI_PLANES | LVT_EPI_ACCUM | LVT_EPI_TANH))) {
+            // every form whose tile rows ARE the rows of C: epilogue_fast.h (same arithmetic, see there)
+            LvtEpi e;
+            e.M = p.M; e.N = p.N;
+            float *wave_tile = lds + wave * (32 * TN * 32);
+            if (COLSUM || COLSUM_A) __syncthreads();                 // (the column sums above went through the same LDS)
+            if (p.splits > 1) {
+                e.C = p.partial; e.ldc = p.N; e.coff = split * p.partial_stride + (long long)z * p.M * p.N; e.alpha = 1.f; e.flags = 0;
+                e.bias = nullptr; e.res = nullptr; e.ldr = 0; e.mask = nullptr; e.ldm = 0;
+                (void)lvt_epi_fast_wave<0, TM, TN>(e, acc, wave_tile, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+                return;
+            }
+            const unsigned seen = lvt_amax_peek(p.c_amax);
+            e.C = p.C; e.ldc = p.ldc; e.coff = coff; e.alpha = p.alpha; e.flags = p.flags;
+            e.bias = p.bias; e.res = p.res; e.ldr = p.ldr; e.mask = p.mask; e.ldm = p.ldm;
+            const float am_w = lvt_epi_fast_dispatch<TM, TN>(e, acc, wave_tile, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+            if (p.c_amax) lvt_block_amax_commit_seen(am_w, p.c_amax, lds + TURN_FLOATS, seen);
+            return;
+        }
+    }
+#endif
     if (p.vec_epi) lvt_epilogue_vec<AMODE, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, cls, coff, z, split);
     else lvt_epilogue<AMODE, BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, l31, half, cls, coff, z, split);
 }
@@ -1420,14 +1439,22 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
 #endif
         __syncthreads();
     }
-    if constexpr (MATH == 2) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = ldexpf(fmaf(acx[i][j][r], 1.f / 2048.f, acc[i][j][r]), unscale);
+    if constexpr (MATH == 2) lvt_f16x2_finish<TM, TN>(acc, acx, unscale);
+#ifndef LVT_NO_FAST_EPILOGUE
+    if (p.vec_epi && p.splits <= 1 && !(p.flags & (LVT_EPI_PLANES | LVT_EPI_ACCUM | LVT_EPI_TANH))) {
+        // epilogue_fast.h with the pixel permutation of the frame as its row map
+        const unsigned seen = lvt_amax_peek(p.c_amax);
+        LvtEpi e;
+        e.M = p.M; e.N = p.N; e.C = p.C; e.ldc = p.ldc; e.coff = 0; e.alpha = p.alpha; e.flags = p.flags;
+        e.bias = p.bias; e.res = p.res; e.ldr = p.ldr; e.mask = p.mask; e.ldm = p.ldm;
+        float *wave_tile = lds + wave * (32 * TN * 32);
+        float am_w;
+        if (MODE != 1) am_w = lvt_epi_fast_dispatch<TM, TN, PatchRows>(e, acc, wave_tile, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, PatchRows());
+        else am_w = lvt_epi_fast_dispatch<TM, TN, PatchTRows>(e, acc, wave_tile, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, PatchTRows{phase});
+        if (p.c_amax) lvt_block_amax_commit_seen(am_w, p.c_amax, lds + TURN_FLOATS, seen);
+        return;
     }
+#endif
     if (MODE != 1) lvt_epilogue_vec<A_PATCH, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, 0, 0, 0, 0);
     else lvt_epilogue_vec<A_PATCHT, BM, BN, WM, WN>(p, acc, lds, m0, n0, wm, wn, lane, phase, 0, 0, 0);
 }

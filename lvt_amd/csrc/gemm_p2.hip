@@ -183,17 +183,56 @@ __global__ __launch_bounds__(P2_THREADS, 2) void lvt_gemm_p2_kernel(const P2Para
     };
     auto dma_a = [&](int stage) {       // AP == 1
         char *dst = lds + stage * P2_A_STAGE + wave_s * 4096;
+#ifdef P2_X_IMMOFF       // (experiment: one M0 per stage, the chunk through the instruction offset -- it moves BOTH addresses)
+        __builtin_amdgcn_global_load_lds((p2_gl_void *)(Ak + agoff[0]), (p2_lds_void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((p2_gl_void *)(Ak + agoff[1] - 1024), (p2_lds_void *)dst, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds((p2_gl_void *)(Ak + agoff[2] - 2048), (p2_lds_void *)dst, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds((p2_gl_void *)(Ak + agoff[3] - 3072), (p2_lds_void *)dst, 16, 3072, 0);
+#else
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c) {
             __builtin_amdgcn_global_load_lds((p2_gl_void *)(Ak + agoff[c]), (p2_lds_void *)(dst + c * 1024), 16, 0, 0);
+#ifdef P2_X_NOPS
+            asm volatile("s_nop 7\n\ts_nop 7");
+#endif
+        }
+#endif
         Ak += 128;
     };
     auto dma_b = [&](int stage) {
         char *dst = lds + P2_B_BASE + stage * P2_B_STAGE + wave_s * 2048;
+#ifdef P2_X_IMMOFF
+        __builtin_amdgcn_global_load_lds((p2_gl_void *)(Bk + bgoff[0]), (p2_lds_void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((p2_gl_void *)(Bk + bgoff[1] - 1024), (p2_lds_void *)dst, 16, 1024, 0);
+#else
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c) {
             __builtin_amdgcn_global_load_lds((p2_gl_void *)(Bk + bgoff[c]), (p2_lds_void *)(dst + c * 1024), 16, 0, 0);
+#ifdef P2_X_NOPS
+            asm volatile("s_nop 7\n\ts_nop 7");
+#endif
+        }
+#endif
         Bk += 128;
+    };
+
+    // "Has my DMA landed?"  s_waitcnt vmcnt(0) is NOT enough on this part: with six LDS-DMA instructions per wave and k-tile in
+    // flight, waves passed vmcnt(0) + s_barrier and read stale LDS -- single 1 KB chunks of a tile still missing, 900 of 1536
+    // tiles of a 16384 x 3072 x 512 product wrong, fewer with a sleep behind the barrier, none with ONE LDS read by the issuing
+    // wave behind the wait (profiles/r06_lds_dma_visibility.txt): the LDS serves a wave's read after that wave's pending DMA
+    // writes.  So every wave reads one dword from each chunk it requested (one ds_read_b32: lane -> chunk lane % n) and waits for
+    // it before the barrier.  (The two-DMA form, AP == 0, never failed; it gets the same fence.)
+    constexpr int NPROBE = AP ? 6 : 2;
+    const int pc = lane % NPROBE;
+    const bool p_is_a = AP && pc < 4;
+    const unsigned probe0 = p_is_a ? (unsigned)(wave_s * 4096 + pc * 1024 + lane * 16)
+                                   : (unsigned)(P2_B_BASE + wave_s * 2048 + (pc - (AP ? 4 : 0)) * 1024 + lane * 16);
+    const unsigned probe_st = p_is_a ? P2_A_STAGE : P2_B_STAGE;
+    auto landed = [&](int stage) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int v = *reinterpret_cast<volatile int *>(lds + probe0 + stage * probe_st);
+        (void)v;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
     f32x16 acc[TM][TN], acx[TM][TN];
@@ -260,20 +299,29 @@ __global__ __launch_bounds__(P2_THREADS, 2) void lvt_gemm_p2_kernel(const P2Para
     }
     P2_STAMP(1);
     int kt = 0;
-    if (ntiles == 1) { __syncthreads(); P2_STAMP(2); }
+    if (ntiles == 1) { landed(0); __syncthreads(); P2_STAMP(2); }
     for (; kt + 2 < ntiles; ++kt) {
+        landed(kt & 1);
         __syncthreads();                // tile kt has landed (LDS-DMA: vmcnt(0) of every wave, then the barrier); stage (kt + 1) & 1 is free
+#ifdef P2_X_SLEEP
+        __builtin_amdgcn_s_sleep(20); __syncthreads();
+#endif
         if (AP) dma_a((kt + 1) & 1);
         dma_b((kt + 1) & 1);
+#ifdef P2_X_SLEEP2       // (experiment: delay only the compute of tile kt, after the next tile's DMA is issued)
+        __builtin_amdgcn_s_sleep(20);
+#endif
         tile(kt & 1, yes_t(), yes_t());
     }
     if (kt + 1 < ntiles) {
+        landed(kt & 1);
         __syncthreads();
         if (AP) dma_a((kt + 1) & 1);
         dma_b((kt + 1) & 1);
         tile(kt & 1, yes_t(), no_t());
         ++kt;
     }
+    landed(kt & 1);
     __syncthreads();
     tile(kt & 1, no_t(), no_t());
     __syncthreads();
@@ -283,7 +331,11 @@ __global__ __launch_bounds__(P2_THREADS, 2) void lvt_gemm_p2_kernel(const P2Para
 
     P2_STAMP(4);
     // ---- epilogue.  Plain forms: epilogue_fast.h (no workgroup barrier, compile-time flag sets, max |C| peeked up front)
+#ifndef P2_NO_FAST_EPI
     if (!p.Cp) {
+#ifdef P2_X_EPI_BARRIER
+        __syncthreads();
+#endif
         const unsigned seen = lvt_amax_peek(p.c_amax);
         LvtEpi e;
         e.M = p.M; e.N = p.N; e.C = p.C; e.ldc = p.ldc; e.coff = coff; e.alpha = p.alpha; e.flags = p.flags;
@@ -295,6 +347,7 @@ __global__ __launch_bounds__(P2_THREADS, 2) void lvt_gemm_p2_kernel(const P2Para
         P2_STAMP(6);
         return;
     }
+#endif
     // ---- epilogue: every wave turns its 64 x 64 sub-tile through LDS 32 rows at a time (lvt_epilogue_vec, gemm_engine.hip):
     // a lane then owns 4 consecutive columns, all global accesses are 16-byte ones
     constexpr int SW = TN * 32, C4 = SW / 4;

@@ -178,3 +178,29 @@ def test_gemm_p2_output_image():
     _, im = G.gemm_p2(a, _pack(w), out, M, N, K, flags=L.EPI_BIAS | L.EPI_RELU, bias=b, out_image=img, out_bound=bound)
     assert torch.equal(out, ref)
     assert torch.equal(_image_view(im.data), _image_ref(ref, float(bound)))
+
+
+@pytest.mark.parametrize("M", [2048, 16384])
+def test_gemm_p2_image_a_many_workgroups_fresh_outputs(M):
+    """Six LDS-DMA instructions per wave and k-tile in flight, several workgroups per CU one after the other, 24 workgroups
+    sharing every A line: the shape that exposed that `s_waitcnt vmcnt(0)` + barrier does not make another wave's LDS-DMA data
+    visible (profiles/r06_lds_dma_visibility.txt).  Outputs start as NaN (a stale correct value must not hide a tile that was
+    not computed), every launch is repeated, both the single-launch and the 24-batch form of the q/k/v product."""
+    from lvt_amd.hip import gemm as G
+    d, na, da = 512, 8, 128
+    hd = na * da
+    x, w = _rand(M, d), _rand(3 * hd, d, seed=1, scale=0.05)
+    ref = torch.empty(M, 3 * hd, device=_dev())
+    G.gemm(x, w, ref, M, 3 * hd, d)
+    xi, wi = _pack(x), _pack(w)
+    kw = dict(lda=d, ldb=d, ldc=hd, batch_outer=3, batch_inner=na, sB=(na * da * d, da * d), sC=(M * hd, da))
+    for _ in range(4):
+        c1 = torch.full((M, 3 * hd), float("nan"), device=_dev())
+        G.gemm_p2(xi, wi, c1, M, 3 * hd, d)
+        assert torch.equal(c1, ref)
+        c2 = torch.full((3, M, hd), float("nan"), device=_dev())
+        G.gemm_p2(xi, wi, c2, M, da, d, **kw)
+        assert torch.equal(c2.permute(1, 0, 2).reshape(M, 3 * hd), ref)
+        c3 = torch.full((3, M, hd), float("nan"), device=_dev())
+        G.gemm_p2(x, wi, c3, M, da, d, **kw)
+        assert torch.equal(c3, c2)
