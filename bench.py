@@ -69,8 +69,10 @@ MATH_NOTE = {
              "v_mfma_f32_32x32x16_f16 (hi hi | hi lo + lo hi in a second accumulator; dropped lo lo <= 2^-22 |a||b|, "
              "2^-24.6 rms); measured error against fp64 is not larger than the plain fp32 MFMA path's on seven operand "
              "classes (tests/test_gpu_engine.py::test_math_modes_accuracy) and every parity test runs in this mode at "
-             "unchanged tolerances; the flash attention kernels split per ROW (token x head) instead of per tensor, the VQ search "
-             "keeps the bf16x3 arithmetic",
+             "unchanged tolerances; the flash attention kernels split per ROW (token x head) instead of per tensor; the VQ search "
+             "runs argmax(x.e - |e|^2/2) on the same two fp16 planes with one scale per row and one per codebook group "
+             "(lvt_vq_nearest_f16x2_kernel, 0 of 524,288 indices differ from an fp64 search); the q/k/v and first-FFN forward "
+             "products take both operands as ready fp16 planes staged by LDS-DMA (csrc/gemm_p2.hip, bit-identical)",
 }
 PEAK_NOTE = {
     "f32": "dense fp32 MFMA peak (MI355X_MICROARCH.md)",
@@ -92,6 +94,10 @@ def parse(argv=None):
     ap.add_argument("--dp-single-rank", action="store_true",
                     help="with --gpus 1: join a ONE-rank RCCL group and keep the gradient reducers active (all-reduces are "
                          "identities there), so that `comm` reports the exposed communication of the data-parallel path")
+    ap.add_argument("--rccl-channels", type=int, default=0,
+                    help="cap RCCL's channels (NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS = n, set before the process group is made): "
+                         "every channel of an all-reduce is a workgroup that needs a CU while the backward pass runs one engine "
+                         "workgroup per CU; 0 = RCCL's default.  Reported under comm.rccl_channels")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batches", type=int, default=4, help="distinct synthetic batches rotated through the steps")
@@ -699,6 +705,8 @@ def run(args):
         os.environ.setdefault("MASTER_PORT", str(free_port()))
     if world > 1 or single:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.rccl_channels > 0:
+            os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_channels)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     from lvt_amd.hip import binding as L
@@ -739,7 +747,14 @@ def run(args):
             "allreduce_bytes_per_step": int(sum(r.bytes_per_backward for r in reducers if r in vq.model._reducers) * vq_per_step
                                             + sum(r.bytes_per_backward for r in reducers if r in ds.model._reducers))
             if reducers else 0,
-            "ema_allreduce_bytes_per_step": (4 * 512 * (64 + 1) * 4) * vq_per_step if world > 1 else 0}
+            "ema_allreduce_bytes_per_step": (4 * 512 * (64 + 1) * 4) * vq_per_step if world > 1 else 0,
+            # CU footprint of the collectives: each RCCL channel is a workgroup competing with the one-workgroup-per-CU engine
+            # launches of the backward pass; A/B it with --rccl-channels on the 8-GPU node (unmeasured here: one GPU per box)
+            "rccl_channels": {"requested": args.rccl_channels or None,
+                              "NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"),
+                              "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS")},
+            "bucket_order": ("arrival order measured in the first backward" if reducers and all(r._calibrated for r in reducers)
+                             else "reverse registration order") if reducers else None}
     if grouped:
         for r in reducers:
             r.enabled = False

@@ -55,7 +55,14 @@ int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long lon
  *       product is exact in fp32.  Half the matrix instructions of bf16x3.  The caller supplies the operands' max |.| as
  *       DEVICE scalars (any upper bound is safe; lvt_amax computes one, the engine's outputs can report theirs through
  *       c_amax / lvt_amax_io.c so that no extra pass is needed along a chain of launches).  Entry points without an
- *       f16x2 path (decode-time kernels, the VQ search, attention) ignore the flag and use bf16x3.                        */
+ *       f16x2 path (decode-time kernels) ignore the flag and use bf16x3; the VQ search and the flash attention kernels have
+ *       f16x2 forms of their own (one scale per row).
+ *       GUARANTEED ENVELOPE (tests/test_gpu_engine.py::test_f16x2_envelope_below_2_pow_minus_27, down to 2^-40 of the max): an
+ *       element a of an operand whose bound is A (max |.| <= A < 2 max |.| after the power-of-two rounding) enters every product
+ *       with an absolute error <= max(2^-22 |a|, 2^-50 A).  Full fp32-class precision for everything within 2^-28 of the
+ *       operand's max; below that the relative error of an element grows as 2^-50 A / |a| (2^-10 at |a| = 2^-40 A) and an
+ *       element below 2^-50 A is lost.  Kernels that keep the low term UNSCALED (the frame-resident weight gradient,
+ *       csrc/conv_wgrad.hip; the flash attention kernels, per row): absolute error <= max(2^-22 |a|, 2^-39 A).            */
 #define LVT_MATH_F16X2 (1 << 18)
 /* max |.| of the operands / result of one engine launch (device pointers; see LVT_MATH_F16X2).  a / b: inputs, required in
  * f16x2 mode, ignored otherwise.  c: optional in EVERY mode -- the launch folds max |C| into *c with an integer atomic max
@@ -129,6 +136,13 @@ typedef struct {
 } lvt_gemm_desc;
 size_t lvt_gemm_workspace_bytes(const lvt_gemm_desc *d);
 int lvt_gemm_f32(const lvt_gemm_desc *d, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- nearest code of ONE wide codebook (ABI 600; CODEBOOK.NUM == 1, vidgen/modeling/meta_arch/vqvae.py:25-27, vq_utils.py:13-20) -
+ * scores[r][k] = x_r . e_k (rows x K, row pitch ld; made by lvt_gemm_f32 from the (rows, D) inputs and the (K, D) codebook):
+ * idx[r] = argmax_k(scores[r][k] - |e_k|^2 / 2) = argmin_k |x_r - e_k|^2, lowest k on exact ties (torch.min).  K <= 2048.
+ * The product quantiser (num codebooks of 64 dims) has its own fused search: lvt_vq_nearest.                              */
+int lvt_vq_argmax_scores(const float *scores, long long rows, int K, long long ld, const float *codebook, int D,
+                         long long *idx, void *stream);
 
 /* ---- plane-fed GEMM of the f16x2 arithmetic (ABI 600, csrc/gemm_p2.hip; replaces the same torch linear / bmm products as
  * lvt_gemm_f32: vt_attention.py:120-128,138 and their autograd backward) ------------------------------------------------------

@@ -106,6 +106,7 @@ def _declare(lib):
         "lvt_device_info": (ci, [C.c_char_p, ci, P(ci), P(ci), P(cll)]),
         "lvt_gemm_workspace_bytes": (sz, [P(GemmDesc)]),
         "lvt_gemm_f32": (ci, [P(GemmDesc), vp, sz, vp]),
+        "lvt_vq_argmax_scores": (ci, [vp, cll, ci, cll, vp, ci, vp, vp]),
         "lvt_gemm_p2_f32": (ci, [P(GemmP2Desc), vp]),
         "lvt_p2_pack_multi": (ci, [P(P2PackEntry), ci, vp]),
         "lvt_layernorm_fwd_p2": (ci, [vp, cll, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

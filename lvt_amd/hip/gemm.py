@@ -64,9 +64,14 @@ class P2Image:
         self.data, self.amax = data, amax
 
 
-def p2_supported():
-    """The plane-fed GEMM path exists for the f16x2 arithmetic only (LVT_NO_P2=1: A/B switch, everything stays on lvt_gemm_f32)."""
-    return L.f16x2() and not os.environ.get("LVT_NO_P2")
+def p2_supported(force=None):
+    """The plane-fed GEMM path exists for the f16x2 arithmetic only, and the MODELS use it on request (LVT_P2=1, or
+    vt_attention.P2_IMAGES = True): bit-identical and 13 % faster per launch on the q/k/v product in isolation, but in the DSFVT
+    train step the second LayerNorm output, the image launch and the host work cancel the gain (same-box A/B, round 6:
+    28.98 ms without, 29.06-29.21 ms with -- DESIGN.md section 3.5)."""
+    if not L.f16x2():
+        return False
+    return bool(os.environ.get("LVT_P2")) if force is None else bool(force)
 
 
 def p2_pack(specs):

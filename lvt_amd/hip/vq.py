@@ -25,6 +25,25 @@ def nearest(z, codebooks, P, coarse=None):
     return idx
 
 
+def nearest_single(z, weight, chunk_rows=1 << 16):
+    """z (rows, D) channels-last rows, weight (K, D): ONE codebook as wide as the rows (CODEBOOK.NUM == 1) -> idx int64 (rows,).
+    Scores x E^T on the GEMM engine (rows are walked in chunks: the score matrix of a chunk is rows x K floats), then
+    lvt_vq_argmax_scores; see csrc/vq_single.hip."""
+    from . import gemm as G
+    L.require(z, weight)
+    rows, D = z.shape
+    K = weight.shape[0]
+    idx = torch.empty(rows, dtype=torch.int64, device=z.device)
+    w = weight.detach()
+    scores = torch.empty(min(rows, chunk_rows), K, dtype=torch.float32, device=z.device)
+    for r0 in range(0, rows, chunk_rows):
+        r1 = min(rows, r0 + chunk_rows)
+        G.gemm(z[r0:r1], w, scores, r1 - r0, K, D)
+        L.check(L.lib().lvt_vq_argmax_scores(L.ptr(scores), r1 - r0, K, K, L.ptr(w), D, L.ptr(idx[r0:r1]), L.stream_ptr()),
+                "lvt_vq_argmax_scores")
+    return idx
+
+
 def gather(idx, codebooks):
     """idx (n, num, P) int64 -> (n*P, num*D) channels-last rows of selected code vectors."""
     L.require(idx, codebooks)

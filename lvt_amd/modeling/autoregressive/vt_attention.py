@@ -104,16 +104,16 @@ def _splits(tiles, k):
     return max(1, min(s, k // 512 if k >= 1024 else 1))
 
 
-P2_IMAGES = None     # None: whenever the arithmetic is f16x2 (hip/gemm.py p2_supported); False: never (tests force either side)
+P2_IMAGES = None     # None: on request (LVT_P2=1, hip/gemm.py p2_supported); True / False: tests force either side
 
 
 def prefetch_p2_images(module):
     """Round 6: the P2 images (csrc/gemm_p2.hip) of the weights that meet a LayerNorm output in a forward product -- the packed
     q/k/v weights as (3 na da, d) rows and the first FFN weight -- for every attention layer of `module`, in ONE launch per 64
     matrices at the start of a pass (the weights change once per optimizer step).  Those two products then run with both
-    operands staged by LDS-DMA (no split, no registers): bit-identical results, -13 % on the q/k/v product.  The images ride on
-    the layers (`_p2`) and are dropped in the other arithmetic modes."""
-    use = G.p2_supported() and P2_IMAGES is not False
+    operands staged by LDS-DMA (no split, no registers): bit-identical results, -13 % on the q/k/v product alone, nothing in
+    the step (opt-in: LVT_P2=1).  The images ride on the layers (`_p2`) and are dropped in the other arithmetic modes."""
+    use = G.p2_supported(P2_IMAGES)
     specs, layers = [], []
     for m in module.modules():
         if not isinstance(m, BlockLocalAttention):
@@ -229,7 +229,7 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         # p2 = (image of the packed q/k/v weights, image of the first FFN weight) made by prefetch_p2_images: the two products
         # that read a LayerNorm output then take BOTH operands as P2 images (the LayerNorm writes its output a second time, as an
         # image under its a-priori bound) and stage them by LDS-DMA -- same bits as the engine's in-kernel split
-        p2 = p2 if (p2 is not None and not planes and G.p2_supported()) else None
+        p2 = p2 if (p2 is not None and not planes and L.f16x2()) else None
         if p2 is not None:
             xn, xn_img, mean1, rstd1 = ew.layernorm_fwd_p2(x, ln_w, ln_b)
         else:

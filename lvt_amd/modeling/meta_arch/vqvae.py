@@ -10,7 +10,7 @@ from ...solver import build_lr_scheduler, build_optimizer
 from ...utils.checkpoint import Checkpointer
 from ..loss import PixelLoss
 from ..loss.loss import mse
-from ..vq import DVQEmbedding
+from ..vq import DVQEmbedding, SingleVQEmbedding
 from .ae import AutoEncoderModel
 from .build import META_ARCH_REGISTRY
 
@@ -21,10 +21,10 @@ class VQVAEModel(AutoEncoderModel):
         super().__init__(cfg)
         cb = cfg.MODEL.CODEBOOK
         self.use_codebook_ema = cb.EMA
-        if cb.NUM == 1:
-            raise NotImplementedError("single-codebook VQEmbedding (CODEBOOK.NUM 1) is not used by the shipped "
-                                      "configs; the HIP quantiser handles the product form")
-        self.codebook = DVQEmbedding(cb.NUM, cb.SIZE, cb.DIM, self.use_codebook_ema)
+        if cb.NUM == 1:          # the default of the config tree: `VQEmbedding` used directly (vqvae.py:25-27)
+            self.codebook = SingleVQEmbedding(cb.SIZE, cb.DIM, self.use_codebook_ema)
+        else:
+            self.codebook = DVQEmbedding(cb.NUM, cb.SIZE, cb.DIM, self.use_codebook_ema)
         if self.use_codebook_ema:
             self._set_requires_grad(self.codebook.parameters(), False)
         self.pixel_loss = PixelLoss(cfg)

@@ -4,5 +4,6 @@ from . import vq_embedding as _impl
 
 VQEmbedding = _impl.VQEmbedding
 DVQEmbedding = _impl.DVQEmbedding
+SingleVQEmbedding = _impl.SingleVQEmbedding
 
-__all__ = ("VQEmbedding", "DVQEmbedding")
+__all__ = ("VQEmbedding", "DVQEmbedding", "SingleVQEmbedding")

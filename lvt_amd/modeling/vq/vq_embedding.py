@@ -78,6 +78,144 @@ class _GatherWithGradFn(torch.autograd.Function):
         return (None, None) + tuple(stats[i, :, :ctx.d].contiguous() for i in range(ctx.num))
 
 
+class _SingleStraightThroughFn(torch.autograd.Function):
+    """vq_st of ONE wide codebook (vq_utils.py:34-65, vq_embedding.py:35-38)."""
+
+    @staticmethod
+    def forward(ctx, z2d, owner, P):
+        w = owner.embedding.weight.detach()
+        idx = vq.nearest_single(z2d, w)                          # (rows,)
+        idx_g = owner._group_idx(idx, P)
+        z_q_st = vq.gather(idx_g, owner._grouped(w))             # from the PRE-update codebook
+        stats = work = None
+        if owner.ema:
+            stats = vq.ema_accumulate(idx_g, z2d, owner.K)       # (g, K, 65): the 64-d slices of the sums | the counts
+            work = all_reduce_sum_async_(stats)
+        owner._pending = (idx, idx_g, stats, work)
+        ctx.mark_non_differentiable(idx)
+        return z_q_st, idx
+
+    @staticmethod
+    def backward(ctx, g_st, g_idx):
+        return g_st, None, None
+
+
+class _SingleGatherWithGradFn(torch.autograd.Function):
+    """rows of the codebook selected by idx, differentiable w.r.t. the codebook (EMA False: vq_embedding.py:61-64, vq_utils.py:56-63)."""
+
+    @staticmethod
+    def forward(ctx, idx_g, owner, weight):
+        ctx.save_for_backward(idx_g)
+        ctx.owner = owner
+        return vq.gather(idx_g, owner._grouped(weight.detach()))
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx_g,) = ctx.saved_tensors
+        o = ctx.owner
+        stats = vq.ema_accumulate(idx_g, g.contiguous(), o.K)                      # (g, K, 65)
+        return None, None, stats[:, :, :64].permute(1, 0, 2).reshape(o.K, o.D).contiguous()
+
+
+class SingleVQEmbedding(VQEmbedding):
+    """`VQEmbedding` used directly as the quantiser: CODEBOOK.NUM == 1, the default of the config tree (config/defaults.py:79,
+    meta_arch/vqvae.py:25-27).  Same parameters, buffers and state_dict keys as the reference's class (`embedding.weight`,
+    `running_size`, `running_sum`); latents carry no codebook axis: (N, H, W).
+
+    The search runs as engine GEMM + lvt_vq_argmax_scores (hip/vq.py nearest_single).  Gather and the EMA statistics reuse the
+    product quantiser's kernels, which work on 64-d groups: the (K, D) codebook is viewed as D / 64 groups that all select with
+    the SAME index -- group g of code k is e_k[64 g : 64 g + 64] -- so the gathered rows, the per-code sums and the counts (equal
+    in every group) are exactly those of the wide codebook, and lvt_vq_ema_finalize applies the reference's update
+    (vq_embedding.py:48-59) to every group with the same counts."""
+
+    def __init__(self, K, D, ema):
+        super().__init__(K, D, ema)
+        if D % 64:
+            raise NotImplementedError("the HIP quantiser works on 64-d groups: CODEBOOK.DIM must be a multiple of 64 (got %d)" % D)
+        self.num, self.groups = 1, D // 64
+        self._pending = None
+
+    # ---- 64-d group views ------------------------------------------------------------------------------------------------
+    def _grouped(self, t):
+        """(K, D) -> (g, K, 64) contiguous; (K,) -> (g, K)."""
+        if t.dim() == 1:
+            return t.unsqueeze(0).expand(self.groups, self.K).contiguous()
+        out = t.view(self.K, self.groups, 64).permute(1, 0, 2).contiguous()
+        if L.f16x2() and L._valid_amax(t) is not None:
+            L.set_amax(out, L._valid_amax(t))
+        return out
+
+    def _ungrouped(self, t):
+        return t.permute(1, 0, 2).reshape(self.K, self.D)
+
+    def _group_idx(self, idx, P):
+        """(rows,) -> (rows / P, g, P): every group selects with the same index."""
+        return idx.view(-1, 1, P).expand(-1, self.groups, P).contiguous()
+
+    def _flat(self):
+        """The tensors a data-parallel run broadcasts from rank 0 (meta_arch/vqvae.py wrap_parallel)."""
+        return (self.embedding.weight.data, getattr(self, "running_size", None), getattr(self, "running_sum", None))
+
+    # ---- channels-last fast paths (the interface VQVAEModel uses: see DVQEmbedding) ---------------------------------------
+    def indices_cl(self, z_cl):
+        n, _, h, w, d = z_cl.shape
+        L.require(z_cl)
+        return vq.nearest_single(z_cl.view(n * h * w, d), self.embedding.weight).view(n, h, w)
+
+    def straight_through_cl(self, z_cl, defer=False):
+        n, _, h, w, d = z_cl.shape
+        L.require(z_cl)
+        if self._pending is not None:
+            raise L.LvtError("SingleVQEmbedding: the EMA update of the previous pass was never finished (finish_ema)")
+        z_q_st, idx = _SingleStraightThroughFn.apply(z_cl.view(n * h * w, d), self, h * w)
+        self.last_indices = idx.view(n, h, w)
+        self._pending_shape = (n, 1, h, w, d)
+        z_q_st = z_q_st.view(n, 1, h, w, d)
+        return z_q_st if defer else (z_q_st, self.finish_ema())
+
+    def finish_ema(self):
+        if self._pending is None:
+            raise L.LvtError("SingleVQEmbedding.finish_ema without a pending straight_through_cl")
+        idx, idx_g, stats, work = self._pending
+        self._pending = None
+        w = self.embedding.weight
+        if stats is not None:
+            if work is not None:
+                work.wait()
+            wg, rs, rsum = self._grouped(w.data), self._grouped(self.running_size), self._grouped(self.running_sum)
+            vq.ema_finalize(stats, rs, rsum, wg, self.decay, self.eps)
+            with torch.no_grad():
+                w.data.copy_(self._ungrouped(wg))
+                self.running_size.copy_(rs[0])
+                self.running_sum.copy_(self._ungrouped(rsum))
+            L.drop_amax(w)
+            return vq.gather(idx_g, wg).view(*self._pending_shape)               # from the POST-update codebook
+        return _SingleGatherWithGradFn.apply(idx_g, self, w).view(*self._pending_shape)
+
+    def abandon_ema(self):
+        pend, self._pending = self._pending, None
+        if pend is not None and pend[3] is not None:
+            pend[3].wait()
+
+    def embed_cl(self, latents):
+        """(N, H, W) int64 -> (N, 1, H, W, D) channels-last."""
+        n, h, w = latents.shape
+        L.require(latents)
+        out = vq.gather(self._group_idx(latents.contiguous().view(-1), h * w), self._grouped(self.embedding.weight.detach()))
+        return out.view(n, 1, h, w, self.D)
+
+    # ---- the reference's call contract (vq_embedding.py:23-33) -------------------------------------------------------------
+    def forward(self, z_e_x, mode=""):
+        if mode == "":
+            return self.indices_cl(convstack._LayoutIn.apply(z_e_x))
+        if mode == "st":
+            st, bar = self.straight_through_cl(convstack._LayoutIn.apply(z_e_x))
+            return convstack._LayoutOut.apply(st, self.D), convstack._LayoutOut.apply(bar, self.D)
+        if mode == "emb":
+            return self.embed_cl(z_e_x).squeeze(1)           # (N, H, W, D), as nn.Embedding yields
+        raise ValueError
+
+
 class DVQEmbedding(nn.Module):
     def __init__(self, num, K, D, ema):
         super().__init__()

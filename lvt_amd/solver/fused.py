@@ -25,15 +25,15 @@ def _entries(items):
 
 class _FusedBase(Optimizer):
     def zero_grad(self, set_to_none=True):
-        """torch semantics, except that gradients living in a data-parallel bucket (engine/grad_reducer.py) are
-        zeroed in place -- one memset per bucket -- and stay attached to it, so the next backward accumulates
-        straight into the buffer RCCL reduces."""
+        """torch semantics; gradients living in a data-parallel bucket (engine/grad_reducer.py) are always DROPPED
+        (`.grad = None`: `set_to_none=False` is not honoured for them -- a zeroed view that stays attached would make autograd
+        add every new gradient into it with a kernel of its own; the reducer moves fresh gradients into the bucket instead)."""
         bucketed, plain = {}, []
         for group in self.param_groups:
             for p in group["params"]:
                 ref = getattr(p, "_lvt_reducer", None)
                 red = ref() if ref is not None else None
-                if red is not None and red.world > 1:
+                if red is not None and red.active:
                     bucketed.setdefault(id(red), (red, set()))[1].add(p)
                 else:
                     plain.append(p)

@@ -235,6 +235,14 @@ def dvq_embed(state, latents, num=4):
     return torch.cat(parts, dim=-1)
 
 
+def single_codebook_state(state):
+    """CODEBOOK.NUM == 1 (meta_arch/vqvae.py:25-27): the model's quantiser IS one `VQEmbedding` (vq_embedding.py:9-66) whose state
+    has no `ve.i.` prefix.  It is the product quantiser with ONE part -- `split(D, dim=1)` of a D-channel tensor is the tensor,
+    `cat` / `stack` of one piece is the piece -- so every dvq_* function restates it with num = 1 on the re-keyed state; the
+    latents of the single form have no codebook axis (squeeze dim 1 of dvq_indices)."""
+    return {"ve.0." + k: v for k, v in state.items()}
+
+
 # --------------------------------------------------------------------------------------------
 # A8  VQ-VAE meta-architecture                 (meta_arch/vqvae.py:66-106, loss/loss.py:5-20)
 # --------------------------------------------------------------------------------------------

@@ -591,10 +591,61 @@ def golden_share_p():
          grad_U0_bias=cp.U[0].bias.grad, grad_yl=yl.grad, grad_ln_w=cp.layer_norm.weight.grad)
 
 
+def golden_single_codebook():
+    """G23: CODEBOOK.NUM == 1, the default of the config tree (config/defaults.py:79) and what configs/vqvae/Base-VQVAE.yaml
+    builds on its own: ONE 256-d codebook, `VQEmbedding` used directly (meta_arch/vqvae.py:25-27, vq_embedding.py:9-66)."""
+    from vidgen.modeling.meta_arch.build import build_model
+    import vidgen.modeling.meta_arch  # noqa: F401
+    from vidgen.utils.events import EventStorage
+    SEED = 1234
+    # (Base-VQVAE.yaml alone is a 1-channel model; PR-DVQVAE2 = Base + the 3-channel image ends and NUM 4: take it with NUM 1)
+    assert ref_cfg("configs/vqvae/Base-VQVAE.yaml").MODEL.CODEBOOK.NUM == 1
+    cfg = ref_cfg("configs/vqvae/PR-DVQVAE2.yaml", **{"MODEL.CODEBOOK.NUM": 1})
+    model = build_model(cfg)
+    assert type(model.codebook).__name__ == "VQEmbedding"
+    load_into(model.encoder, seeded.seeded_params(seeded.VQVAE_ENCODER_SHAPES, SEED, "enc."))
+    load_into(model.generator, seeded.seeded_params(seeded.VQVAE_DECODER_SHAPES, SEED, "dec."))
+    x = seeded.seeded_input("g1.x", (2, 3, 64, 64), SEED, -1.0, 1.0)
+    with torch.no_grad():
+        zstd = float(model.encoder(x.clone()).std())
+    st = seeded.seeded_codebook_state(SEED, num=1, K=512, D=256, scale=zstd)
+    state0 = {k[len("ve.0."):]: v for k, v in st.items()}
+
+    def dealias():
+        model.codebook.embedding.weight.data = state0["embedding.weight"].clone()
+        model.codebook.running_size = state0["running_size"].clone()
+        model.codebook.running_sum = state0["running_sum"].clone()
+    data = [{"image": seeded.seeded_input("g5.f%d" % i, (3, 64, 64), SEED).numpy()} for i in range(2)]
+    xin = model.normalizer(torch.stack([torch.from_numpy(d["image"]) for d in data]))
+    dealias()
+    with torch.no_grad():
+        z_e = model.encoder(xin.clone())
+        idx = model.codebook(z_e)                          # mode "": (N, 16, 16)
+        lat = model.encode(xin.clone())
+        dec = model.decode(lat)
+    assert torch.equal(idx, lat)
+    dealias()
+    model.train()
+    model.zero_grad()
+    with EventStorage(0):
+        losses = model(data, mode="supervised")
+    assert sorted(losses) == ["loss_commitment", "loss_reconstruction"]
+    sum(losses.values()).backward()
+    new = cb_state_of(model.codebook)
+    save("g23_single_codebook", seed=SEED, scale=zstd, state_keys=np.array(sorted(new.keys())), z_e=z_e, idx=idx,
+         decode_slice=dec[:, :, ::4, ::4],
+         loss_reconstruction=losses["loss_reconstruction"], loss_commitment=losses["loss_commitment"],
+         grad_enc_first=model.encoder.layers[0].weight.grad, grad_enc_first_bias=model.encoder.layers[0].bias.grad,
+         grad_dec_last=model.generator.layers[6].weight.grad, grad_dec_last_bias=model.generator.layers[6].bias.grad,
+         **{"new." + k: v for k, v in new.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["vqvae", "vt", "variants", "pins", "share_p"]
+    which = sys.argv[1:] or ["vqvae", "vt", "variants", "pins", "share_p", "single"]
     if "share_p" in which:
         golden_share_p()
+    if "single" in which:
+        golden_single_codebook()
     if "pins" in which:
         golden_pins()
     if "vqvae" in which:

@@ -430,6 +430,56 @@ def test_math_modes_accuracy(math_mode):
             assert err[mode][1] < 1e-5, (name, mode, err)
 
 
+def test_f16x2_envelope_below_2_pow_minus_27(math_mode):
+    """The guarantee of LVT_MATH_F16X2 for elements FAR below the operand's max (include/lvt_hip.h, next to the flag): an element
+    a of an operand with max |.| = A is represented with an absolute error <= max(2^-22 |a|, 2^-50 A) -- full fp32-class
+    precision down to 2^-28 A, a floor of 2^-50 A below.  For a row of A whose entries are rho A in size that is a relative error
+    of max(2^-22, 2^-50 / rho) on every product it takes part in.  Rows from 1 down to 2^-40 of the operand's max (a dead or
+    near-dead token beside a live one), three kernels: the plain engine tile, the wide tile, the plane-fed (P2) kernel."""
+    from lvt_amd.hip import gemm as G, binding as L
+    if math_mode != "f16x2":
+        pytest.skip("f16x2 only")
+    d = _dev()
+    g = torch.Generator().manual_seed(11)
+    steps = torch.arange(0, 41, 4)                                   # 2^0 .. 2^-40, 24 rows per step
+    rho = torch.exp2(-steps.float()).repeat_interleave(24).view(-1, 1)
+    a = torch.randn(rho.numel(), 1024, generator=g) * rho
+    a[0, 0] = 4.0                                                     # the max of the operand sits in the first (largest) row class
+    b = torch.randn(256, 1024, generator=g)
+    ref = a.double() @ b.double().t()
+    unit = a.double().abs() @ b.double().abs().t()
+    M, N, K = a.shape[0], 256, 1024
+    outs = {}
+    for name, m_pad in (("engine 128x128", 0), ("wide 256x128", 1)):
+        # M <= 128 keeps a product on lvt_gemm_kernel; the wide kernel takes M > 128: run both by slicing / not slicing
+        if m_pad:
+            out = torch.empty(M, N, device=d)
+            G.gemm(a.to(d), b.to(d), out, M, N, K)
+        else:
+            out = torch.empty(M, N, device=d)
+            ad = a.to(d)
+            L.set_amax(ad, L.amax_of(ad))
+            for r0 in range(0, M, 96):
+                r1 = min(M, r0 + 96)
+                G.gemm(ad[r0:r1], b.to(d), out[r0:r1], r1 - r0, N, K)
+        outs[name] = out
+    ad, bd = a.to(d), b.to(d)
+    ai, bi = torch.empty_like(ad), torch.empty_like(bd)
+    G.p2_pack([(ad, False, ai, L.amax_of(ad)), (bd, False, bi, L.amax_of(bd))])
+    out = torch.empty(M, N, device=d)
+    G.gemm_p2(G.P2Image(ai, L.amax_of(ad)), G.P2Image(bi, L.amax_of(bd)), out, M, N, K)
+    outs["plane-fed"] = out
+    assert torch.equal(outs["plane-fed"], outs["wide 256x128"])
+    amax_ratio = rho.view(-1) * (1.0 / 4.0)                           # row size relative to the operand's max (4.0)
+    for name, o in outs.items():
+        e = ((o.double().cpu() - ref).abs() / unit).max(1).values    # worst relative error per row, in units of sum |a||b|
+        bound = torch.maximum(torch.full_like(amax_ratio, 2.0 ** -21), 2.0 ** -48 / amax_ratio).double()
+        bad = (e > bound).nonzero().flatten()
+        assert bad.numel() == 0, (name, [(int(i), float(e[i]), float(bound[i])) for i in bad[:5]])
+        # and the rows within 2^-24 of the max are as good as the plain fp32 instruction: 4 ulp-class
+        assert float(e[amax_ratio >= 2.0 ** -26].max()) < 1e-6, name
+
+
 def test_f16x2_amax_bookkeeping(math_mode):
     """f16x2 operand scales: an engine launch reports max |C| through c_amax (bit-exact), a stale record is not used after
     an in-place torch op, a view inherits the bound of the tensor it was cut from, and a launch without operand scales is

@@ -204,3 +204,44 @@ def test_gemm_p2_image_a_many_workgroups_fresh_outputs(M):
         c3 = torch.full((3, M, hd), float("nan"), device=_dev())
         G.gemm_p2(x, wi, c3, M, da, d, **kw)
         assert torch.equal(c3, c2)
+
+
+def test_dsfvt_loss_with_p2_images_is_bit_identical():
+    """The model path on request (vt_attention.P2_IMAGES = True: LayerNorm outputs + q/k/v and first-FFN weights as images, both
+    operands of those products by LDS-DMA): the DSFVT training loss and every gradient equal the default path's bit for bit, on
+    fresh models from the same seed (the shape that caught the LDS-DMA visibility hole: 8 slices, 24 batches per q/k/v launch)."""
+    import lvt_amd.modeling.autoregressive.vt_attention as VA
+    from lvt_amd.data.dataset_mapper import prepare_slices_batch
+    from lvt_amd.modeling import build_model
+    from lvt_amd.utils.events import EventStorage
+    from util_models import dsfvt_cfg
+
+    def run(p2):
+        VA.P2_IMAGES = p2
+        try:
+            cfg = dsfvt_cfg("cuda:0")
+            cfg.OUTPUT_DIR = "/tmp/lvt_test_out"
+            torch.manual_seed(13)
+            model = build_model(cfg)
+            model.train()
+            v = cfg.MODEL.AUTOREGRESSIVE.VT
+            g = torch.Generator().manual_seed(7)
+            codes = torch.randint(0, v.NV, (8, 16, v.NC, 16, 16), generator=g).to("cuda:0")
+            abcs = [(int(a), 0, 0) for a in torch.randint(v.N_PRIME, 16, (8,), generator=g)]
+            ctx, sl, sidx, ign = prepare_slices_batch(codes, abcs, v.STRIDE, v.KERNEL, v.N_PRIME, v.PAD_VALUE)
+            with EventStorage(0):
+                loss = model.compute_supervised_loss(ctx, sl, sidx, ign)["loss_cross_entropy"]
+            loss.backward()
+            used = any(getattr(m, "_p2", None) is not None for m in model.modules())
+            return float(loss.detach()), {n: p.grad.clone() for n, p in model.model.named_parameters() if p.grad is not None}, used
+        finally:
+            VA.P2_IMAGES = None
+    l0, g0, u0 = run(False)
+    junk = torch.full((1 << 26,), float("nan"), device="cuda:0")      # dirty the allocator's free blocks between the runs
+    del junk
+    l1, g1, u1 = run(True)
+    assert u1 and not u0
+    assert l0 == l1
+    assert g0.keys() == g1.keys()
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n

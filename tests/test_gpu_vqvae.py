@@ -365,3 +365,97 @@ def test_g22_trained_codebook(golden):
     # the quantiser still serves the other modes
     lat = model.codebook(model.encoder(torch.zeros(1, 3, 64, 64, device=DEV)))
     assert tuple(lat.shape) == (1, 4, 16, 16)
+
+
+def _single_codebook_model(g, ema=True):
+    from lvt_amd.modeling import build_model
+    from util_models import vqvae_cfg
+    seed = int(g["seed"])
+    cfg = vqvae_cfg(DEV)
+    cfg.MODEL.CODEBOOK.NUM = 1
+    cfg.MODEL.CODEBOOK.EMA = ema
+    model = build_model(cfg)
+    model.encoder.load_state_dict(seeded.seeded_params(seeded.VQVAE_ENCODER_SHAPES, seed, "enc."))
+    model.generator.load_state_dict(seeded.seeded_params(seeded.VQVAE_DECODER_SHAPES, seed, "dec."))
+    st = seeded.seeded_codebook_state(seed, num=1, K=512, D=256, scale=float(g["scale"]))
+    st = {k[len("ve.0."):]: v for k, v in st.items()}
+    if not ema:
+        st = {"embedding.weight": st["embedding.weight"]}
+    model.codebook.load_state_dict(st)
+    return model, st
+
+
+def test_g23_single_codebook(golden):
+    """CODEBOOK.NUM == 1 -- `VQEmbedding` used directly, the default of the config tree (vqvae.py:25-27, config/defaults.py:79):
+    the reference's state_dict keys, indices (N, H, W) bit-exact on clear-margin rows, decode, one supervised step (losses,
+    four gradients, the EMA state after it) against fixture G23 captured from the reference."""
+    from lvt_amd.utils.events import EventStorage
+    g = golden("g23_single_codebook")
+    seed = int(g["seed"])
+    model, st = _single_codebook_model(g)
+    assert sorted(model.codebook.state_dict()) == [str(k) for k in g["state_keys"]]
+    assert not any(p.requires_grad for p in model.codebook.parameters())
+    x = torch.stack([seeded.seeded_input("g5.f%d" % i, (3, 64, 64), seed) for i in range(2)])
+    xn = O.normalize(x, MEAN, STD).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        lat = model.encode(xn)
+        z_e = model.encoder(xn)
+        assert rel_err(z_e, g["z_e"]) < 2e-5
+        d0, d1, _ = O.vq_margin_fp64(g["z_e"].permute(0, 2, 3, 1).reshape(-1, 256), st["embedding.weight"])
+        clear = ((d1 - d0) > 1e-5 * d0).view(2, 16, 16)
+        assert tuple(lat.shape) == (2, 16, 16) and lat.dtype == torch.int64
+        assert torch.equal(lat.cpu()[clear], g["idx"][clear]) and int((~clear).sum()) < 8
+        assert torch.equal(model.codebook(z_e), lat)
+        dec = model.decode(g["idx"].to(DEV))
+        assert rel_err(dec[:, :, ::4, ::4], g["decode_slice"]) < 2e-5
+        emb = model.codebook(g["idx"].to(DEV), mode="emb")
+        assert torch.equal(emb.cpu(), st["embedding.weight"][g["idx"]])
+    model.train()
+    data = [{"image": x[i].numpy()} for i in range(2)]
+    with EventStorage(0):
+        losses = model(data, mode="supervised")
+    assert set(losses) == {"loss_reconstruction", "loss_commitment"}
+    sum(losses.values()).backward()
+    assert abs(float(losses["loss_reconstruction"]) - float(g["loss_reconstruction"])) < 1e-5 * float(g["loss_reconstruction"])
+    assert abs(float(losses["loss_commitment"]) - float(g["loss_commitment"])) < 2e-4 * float(g["loss_commitment"])
+    assert torch.equal(model.codebook.last_indices.cpu()[clear], g["idx"][clear])
+    assert rel_err(model.encoder.layers[0].weight.grad, g["grad_enc_first"]) < 1e-3
+    assert rel_err(model.encoder.layers[0].bias.grad, g["grad_enc_first_bias"]) < 1e-3
+    assert rel_err(model.generator.layers[6].weight.grad, g["grad_dec_last"]) < 1e-4
+    assert rel_err(model.generator.layers[6].bias.grad, g["grad_dec_last_bias"]) < 1e-4
+    new = model.codebook.state_dict()
+    for k in ("embedding.weight", "running_size", "running_sum"):
+        assert rel_err(new[k], g["new." + k]) < 1e-5, k
+
+
+def test_single_codebook_trained_and_against_the_oracle(golden):
+    """CODEBOOK.NUM 1 with EMA False: the codebook takes the gradient index_add_ of the rows (vq_utils.py:56-63); compared with
+    the oracle (no reference fixture for this combination), plus 64 frames of searches against an fp64 search."""
+    from lvt_amd.hip import vq
+    from lvt_amd.utils.events import EventStorage
+    g = golden("g23_single_codebook")
+    seed = int(g["seed"])
+    model, st = _single_codebook_model(g, ema=False)
+    assert sorted(model.codebook.state_dict()) == ["embedding.weight"] and all(p.requires_grad for p in model.codebook.parameters())
+    x = torch.stack([seeded.seeded_input("g5.f%d" % i, (3, 64, 64), seed) for i in range(2)])
+    model.train()
+    with EventStorage(0):
+        losses = model([{"image": x[i].numpy()} for i in range(2)], mode="supervised")
+    assert set(losses) == {"loss_reconstruction", "loss_commitment", "loss_dict"}
+    sum(losses.values()).backward()
+    enc = seeded.seeded_params(seeded.VQVAE_ENCODER_SHAPES, seed, "enc.")
+    dec = seeded.seeded_params(seeded.VQVAE_DECODER_SHAPES, seed, "dec.")
+    w = st["embedding.weight"].clone().requires_grad_(True)
+    ref, _, _ = O.vqvae_supervised_loss(enc, dec, {"ve.0.embedding.weight": w}, O.normalize(x, MEAN, STD), num=1, ema=False,
+                                        force_idx=model.codebook.last_indices.cpu().view(2, 1, 16, 16))
+    sum(ref.values()).backward()
+    for k in ref:
+        assert abs(float(losses[k]) - float(ref[k])) < 2e-4 * abs(float(ref[k])), k
+    assert rel_err(model.codebook.embedding.weight.grad, w.grad) < 2e-5
+    # many searches: 64 frames of random rows at the codebook's scale against an fp64 search
+    rows = torch.randn(64 * 256, 256, generator=torch.Generator().manual_seed(3)) * float(g["scale"])
+    idx = vq.nearest_single(rows.to(DEV), st["embedding.weight"].to(DEV)).cpu()
+    d0, d1, i64 = O.vq_margin_fp64(rows, st["embedding.weight"])
+    clear = (d1 - d0) > 1e-5 * d0
+    assert torch.equal(idx[clear], i64[clear]) and int((~clear).sum()) < 64

@@ -332,3 +332,17 @@ def test_channel_predictor_share_p_is_the_config_default_and_constructs():
     assert len(ChannelPredictor(64, 3, 16, 8, share_p=False).P) == 3
     with pytest.raises(NotImplementedError):
         ChannelPredictor(64, 3, 16, 8, share_p=False, share_embeddings=True)
+
+
+def test_single_codebook_is_the_config_default_and_constructs():
+    """CODEBOOK.NUM defaults to 1 (vidgen/config/defaults.py:79): a VQVAEModel config that does not set it builds `VQEmbedding`
+    as its quantiser (vqvae.py:25-27) with the reference's state_dict keys."""
+    from lvt_amd.config import get_cfg
+    from lvt_amd.modeling.vq import SingleVQEmbedding
+    assert get_cfg().MODEL.CODEBOOK.NUM == 1
+    cb = SingleVQEmbedding(512, 256, True)
+    assert sorted(cb.state_dict()) == ["embedding.weight", "running_size", "running_sum"]
+    assert tuple(cb.embedding.weight.shape) == (512, 256) and cb.groups == 4
+    assert sorted(SingleVQEmbedding(128, 64, False).state_dict()) == ["embedding.weight"]
+    with pytest.raises(NotImplementedError):
+        SingleVQEmbedding(512, 100, True)

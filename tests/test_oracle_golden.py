@@ -110,6 +110,32 @@ def test_g22_vqvae_trained_codebook(golden):
     assert int(g["generator_param_count"]) == len(enc) + len(dec) + 4        # the codebooks join the generator's optimizer
 
 
+def test_g23_single_codebook(golden):
+    """CODEBOOK.NUM == 1 (the config tree's default; vqvae.py:25-27): indices, one EMA step, losses, four gradients."""
+    g = golden("g23_single_codebook")
+    seed = int(g["seed"])
+    enc, dec = _vqvae_params(seed)
+    for p in list(enc.values()) + list(dec.values()):
+        p.requires_grad_(True)
+    st = seeded.seeded_codebook_state(seed, num=1, K=512, D=256, scale=float(g["scale"]))
+    assert sorted(k[len("ve.0."):] for k in st) == [str(k) for k in g["state_keys"]]
+    x = O.normalize(torch.stack([seeded.seeded_input("g5.f%d" % i, (3, 64, 64), seed) for i in range(2)]), MEAN, STD)
+    idx = O.dvq_indices(st, g["z_e"], num=1).squeeze(1)
+    d0, d1, _ = O.vq_margin_fp64(g["z_e"].permute(0, 2, 3, 1).reshape(-1, 256), st["ve.0.embedding.weight"])
+    clear = ((d1 - d0) > 1e-5 * d0).view(2, 16, 16)
+    assert torch.equal(idx[clear], g["idx"][clear]) and int((~clear).sum()) < 8
+    losses, new, aux = O.vqvae_supervised_loss(enc, dec, st, x, num=1)
+    sum(losses.values()).backward()
+    assert abs(float(losses["loss_reconstruction"]) - float(g["loss_reconstruction"])) < 1e-6
+    assert abs(float(losses["loss_commitment"]) - float(g["loss_commitment"])) < 1e-6 * float(g["loss_commitment"]) + 1e-6
+    assert rel_err(enc["layers.0.weight"].grad, g["grad_enc_first"]) < 1e-4
+    assert rel_err(enc["layers.0.bias"].grad, g["grad_enc_first_bias"]) < 1e-4
+    assert rel_err(dec["layers.6.weight"].grad, g["grad_dec_last"]) < 1e-4
+    assert rel_err(dec["layers.6.bias"].grad, g["grad_dec_last_bias"]) < 1e-4
+    for k in ("embedding.weight", "running_size", "running_sum"):
+        assert rel_err(new["ve.0." + k], g["new." + k]) < 1e-5, k
+
+
 def test_g6_inference_on_example_frames(golden):
     g = golden("g6_inference")
     seed = int(g["seed"])
