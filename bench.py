@@ -189,7 +189,7 @@ def timed_steps(step, steps, first_iter, world, device):
 
 def traffic_from_profile(name, launches_per_step=None):
     """HBM bytes per engine launch from this round's committed PMC passes (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in
-    separate runs of scratch/bench_leg.py, summarised by scratch/pmc_summary.py / scratch/profile_r05.sh): counters cannot be
+    separate runs of tools/profile/bench_leg.py, summarised by tools/profile/pmc_summary.py / tools/profile/round_profiles.sh): counters cannot be
     read inside the run.  -> (bytes per launch or None, file name, stale?): the figure is STALE when the profiled code issued
     another number of engine launches per step than the run that quotes it (the kernels changed since the pass)."""
     try:
@@ -197,7 +197,7 @@ def traffic_from_profile(name, launches_per_step=None):
             d = json.load(f)
     except Exception:
         return None, None, None
-    # `engine_calls_per_step`: engine wrapper calls of one step of the profiled code, counted by scratch/bench_leg.py exactly as
+    # `engine_calls_per_step`: engine wrapper calls of one step of the profiled code, counted by tools/profile/bench_leg.py exactly as
     # the KernelTimer of this run counts them (a wrapper call may be several kernel dispatches, which is what the counters see)
     prof = d.get("engine_calls_per_step")
     stale = None if (prof is None or launches_per_step is None) else bool(abs(prof - launches_per_step) > 0.5)
@@ -770,12 +770,12 @@ def run(args):
     extra = {}
     if not args.no_legs:
         nl = max(10, args.steps)
-        extra["vqvae"] = leg_alone("vqvae", vq, nl, 3, world, device, "clips", "r05_vqvae_pmc_hbm_traffic.json",
+        extra["vqvae"] = leg_alone("vqvae", vq, nl, 3, world, device, "clips", "r06_vqvae_pmc_hbm_traffic.json",
                                    "lvt_conv_patch_kernel<0,1,2> / lvt_conv_wgrad_frames_kernel<0,1> (frame-resident 3x3 and "
                                    "4x4/stride-2 layers) + lvt_gemm_kernel<*> (1x1 and image-side layers)",
                                    not args.no_strict_f32)
         extra["dsfvt"] = leg_alone("dsfvt", ds, max(10, args.steps // 2), 2, world, device, "samples",
-                                   "r05_dsfvt_pmc_hbm_traffic.json",
+                                   "r06_dsfvt_pmc_hbm_traffic.json",
                                    "lvt_gemm_wide_kernel<*> (QKV / proj / FFN products, their data and weight gradients; f16x2) + "
                                    "lvt_attn_fwd_flash_kernel / lvt_attn_bwd_flash_a / _b (flash attention on fp32 operands, per-row f16x2)", not args.no_strict_f32)
         v1, v2 = extra["vqvae"]["clips_per_s"], extra["dsfvt"]["samples_per_s"]
@@ -823,7 +823,7 @@ def run(args):
                                    % (clips_per_step, vq_per_step, args.batch_clips, args.dsfvt_batch, args.batches),
                        "global_batch_clips": clips_per_step * world, "parallelism": "dp%d" % world},
             "roofline": roofline_block(
-                es, math_mode, "r05_combined_pmc_hbm_traffic.json",
+                es, math_mode, "r06_combined_pmc_hbm_traffic.json",
                 "the matrix-core engine launches of the step: lvt_gemm_wide_kernel<*>, lvt_gemm_kernel<*>, lvt_conv_patch_kernel<*>, "
                 "lvt_conv_wgrad_frames_kernel<*>, lvt_attn_fwd/bwd kernels; %d launches per step, event-timed in a second "
                 "pass of the same %d steps: %.2f ms of engine time in a %.2f ms instrumented step (unperturbed: %.2f ms)"

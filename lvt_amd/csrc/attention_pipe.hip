@@ -49,7 +49,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // (HIP's uint4
 
 // A fragment TRANSPOSED (the reduction index is the LDS row): lane column ctile*32 + l31, k slots = rows r0 .. r0+3 and
 // r1 .. r1+3.  Lane li of a 16-lane group supplies the address of row (li >> 2), columns 4 (li & 3) .. +3 of its group's
-// [4 rows][16 columns] block and receives column li, rows 0..3 (scratch/ubench/tr_probe.hip).
+// [4 rows][16 columns] block and receives column li, rows 0..3 (tools/ubench/tr_probe.hip).
 __device__ __forceinline__ bf16x8 ap_tr(const unsigned short *p, int hi_off) {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + hi_off));

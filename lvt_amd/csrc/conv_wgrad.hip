@@ -251,7 +251,7 @@ __global__ __launch_bounds__(WG_THREADS) void lvt_conv_wgrad_frames_kernel(const
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     // fragment addressing of the transposing read: lane i of a 16-lane group supplies the address of row (i >> 2),
-    // columns 4 * (i & 3) .. +3 of its group's [4][16] block and receives column i, rows 0..3 (scratch/ubench/tr_probe.hip)
+    // columns 4 * (i & 3) .. +3 of its group's [4][16] block and receives column i, rows 0..3 (tools/ubench/tr_probe.hip)
     const int li = lane & 15, g1 = (lane >> 4) & 1, half = lane >> 5;
     const int rowoff = 8 * half + (li >> 2), coloff = 16 * g1 + 4 * (li & 3);
     const int boff = rowoff * WG_QP + wave * 32 + coloff;

@@ -130,7 +130,7 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 // so the full 22 + sign bits hold for every element down to 2^-27 max |a| and degrade gradually below that.  A block is
 // three v_mfma_f32_32x32x16_f16: hi hi into one accumulator, hi lo + lo hi into a second one that is added with weight 2^-11
 // at the end (dropped: lo lo <= 2^-22 |a||b| worst case, 2^-24.6 rms -- the size of one fp32 rounding).
-// Instruction choice (scratch/ubench/valu_rate_f16.hip, issue cost relative to v_add_f32): v_fma_mixlo/hi_f16 3.3, v_fma_mix_f32
+// Instruction choice (tools/ubench/valu_rate_f16.hip, issue cost relative to v_add_f32): v_fma_mixlo/hi_f16 3.3, v_fma_mix_f32
 // 1.7, v_cvt_pk_f16_f32 1.7 (two elements), v_pk_mul_f32 1.75 (two elements).  Per PAIR of elements: t = v s (v_pk_mul_f32),
 // hi = RN16(t) (v_cvt_pk_f16_f32), t2 = v (2048 s) (v_pk_mul_f32), r = t2 - 2048 hi exactly (v_fma_mix_f32 reads the fp16 half
 // of hi directly), lo = RN16(r) (v_cvt_pk_f16_f32): 5.2 units per element; the first version (three v_fma_mix*_f16 forms per
@@ -1620,7 +1620,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void lvt_gemm_wide_kernel(const KP
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const f16x8 *>(cur + fb[j] + q * PSB + ks);
             }
-#ifdef LVT_WX_NOMFMA        // (timing experiments, scratch/build_variant.sh: what the main loop costs without one of its parts)
+#ifdef LVT_WX_NOMFMA        // (timing experiments, tools/profile/build_variant.sh: what the main loop costs without one of its parts)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll

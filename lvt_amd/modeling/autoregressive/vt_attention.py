@@ -99,7 +99,7 @@ class MultiHeadAttention(nn.Module):
 
 def _splits(tiles, k):
     """split-K factor: one full wave of workgroups (2 resident per CU -> 512 slots), >= 512 rows each.  Measured on
-    the 16384-row weight gradients: 512 slots beat 1024 by 12-14 % (scratch/bench_tn.py)."""
+    the 16384-row weight gradients: 512 slots beat 1024 by 12-14 % (tools/ubench/bench_tn.py)."""
     s = max(1, 512 // max(1, tiles))
     return max(1, min(s, k // 512 if k >= 1024 else 1))
 

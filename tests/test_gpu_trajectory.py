@@ -9,7 +9,7 @@ against the CPU oracle stepped by torch.optim with the same hyperparameters on t
     level, so single entries of ANY two fp32 trajectories differ by up to 2 lr there and a max-norm bound would test luck.
     The DSFVT oracle runs (fp32 and fp64) take their ReLU decisions from the device (binding.RELU_TRACE, tests/util_relu.py):
     among the 4 M units of a forward pass one or two sit within round-off of zero, and a unit resolved differently moves whole
-    gradient tensors by 1e-4 .. 1e-3 (scratch/grad_accuracy_dsfvt.py: 300 x the CPU fp32 oracle's distance from fp64 at step 0,
+    gradient tensors by 1e-4 .. 1e-3 (tools/ubench/grad_accuracy_dsfvt.py: 300 x the CPU fp32 oracle's distance from fp64 at step 0,
     with the plane and the flash attention kernels alike) -- a fork of the trajectories that says nothing about the arithmetic;
   * code indices: no flip against the oracle's own search on rows with a clear margin, at every step (the oracle trajectory is
     run with the device's indices forced, so that a sub-margin row cannot fork the two trajectories)."""

@@ -1,0 +1,28 @@
+"""t(K) of lvt_gemm_p2_f32 with both operands as images (M = 16384, N = 512): fixed cost and per-k-tile cost.  usage: python tools/profile/p2_curve.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from lvt_amd.hip import binding as L
+from lvt_amd.hip import gemm as G
+dev = torch.device("cuda:0")
+L.set_math_mode("f16x2")
+def timeit(fn, n=40):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+def pack(x):
+    dst = torch.empty_like(x); am = L.amax_of(x); G.p2_pack([(x, False, dst, am)]); return G.P2Image(dst, am)
+M = 16384
+out = []
+for N in (512, 3072):
+    for K in (32, 64, 128, 256, 512, 1024, 2048):
+        A, W, C = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) * 0.05, torch.empty(M, N, device=dev)
+        Ai, Wi = pack(A), pack(W)
+        t_eng = timeit(lambda: G.gemm(A, W, C, M, N, K))
+        t_p2 = timeit(lambda: G.gemm_p2(Ai, Wi, C, M, N, K))
+        out.append("N=%d K=%d: engine %.1f us, p2 %.1f us" % (N, K, t_eng, t_p2))
+print(os.path.basename(os.environ.get("LVT_HIP_LIB", "default")) + "\n" + "\n".join(out))
