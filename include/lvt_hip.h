@@ -349,6 +349,12 @@ int lvt_mse_fwd(const float *a, const float *b, long long n, double denom, float
 /* out = add + gout[0] * (2*scale/denom) * (a-b) [* (1-a^2) if tanh_of_a]; gout/add may be NULL        */
 int lvt_mse_bwd(const float *a, const float *b, long long n, double denom, float scale,
                 const float *gout_dev, const float *add, int tanh_of_a, float *out, float *out_amax, void *stream);
+/* the same pair for F.l1_loss (ABI 600; LOSS.PIXEL.MODE "l1", vidgen/modeling/loss/loss.py:11-12): scale * sum |a - b| / denom, and
+ * out = add + g (scale / denom) sign(a - b) (0 where a == b, as torch)                                    */
+int lvt_l1_fwd(const float *a, const float *b, long long n, double denom, float scale, float *out,
+               void *workspace, size_t workspace_bytes, void *stream);
+int lvt_l1_bwd(const float *a, const float *b, long long n, double denom, float scale,
+               const float *gout_dev, const float *add, int tanh_of_a, float *out, float *out_amax, void *stream);
 int lvt_tanh_bwd(const float *g, const float *y, long long n, float *out, float *out_amax, void *stream);
 /* out = alpha * alpha_dev[0] * x (+ add)                                                              */
 int lvt_axpy(const float *x, const float *add, long long n, const float *alpha_dev, float alpha,

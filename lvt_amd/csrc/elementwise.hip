@@ -86,6 +86,7 @@ extern "C" int lvt_to_channels_first(const float *in, int B, int C, long long R,
 // squared-error loss (F.mse_loss; vqvae.py:79,86 / loss.py:19) -- fixed-order two-stage sum
 // ------------------------------------------------------------------------------------------------
 #define RED_BLOCKS 1024
+template <int L1>          // L1 = 1: sum |a - b| (F.l1_loss, loss.py:11-12)
 __global__ void lvt_sqdiff_partial_kernel(const float *__restrict__ a, const float *__restrict__ b, long long n4,
                                           float *__restrict__ partial) {
     __shared__ float red[256];
@@ -95,7 +96,8 @@ __global__ void lvt_sqdiff_partial_kernel(const float *__restrict__ a, const flo
         const float4 x = reinterpret_cast<const float4 *>(a)[i];
         const float4 y = reinterpret_cast<const float4 *>(b)[i];
         const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
-        s += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        if (L1) s += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+        else s += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
     }
     red[threadIdx.x] = s;
     __syncthreads();
@@ -131,8 +133,22 @@ extern "C" int lvt_mse_fwd(const float *a, const float *b, long long n, double d
     LVT_REQUIRE(workspace && workspace_bytes >= lvt_reduce_workspace_bytes(), "mse_fwd: workspace");
     hipStream_t s = (hipStream_t)stream;
     const int blocks = grid_for(n / 4, 256 * 4, RED_BLOCKS);
-    hipLaunchKernelGGL(lvt_sqdiff_partial_kernel, dim3(blocks), dim3(256), 0, s, a, b, n / 4, (float *)workspace);
+    hipLaunchKernelGGL(lvt_sqdiff_partial_kernel<0>, dim3(blocks), dim3(256), 0, s, a, b, n / 4, (float *)workspace);
     LVT_CHECK_LAUNCH("lvt_sqdiff_partial_kernel");
+    hipLaunchKernelGGL(lvt_scalar_finish_kernel, dim3(1), dim3(256), 0, s, (const float *)workspace, blocks,
+                       (float)((double)scale / denom), (const float *)nullptr, out);
+    LVT_CHECK_LAUNCH("lvt_scalar_finish_kernel");
+    return LVT_OK;
+}
+// out[0] = scale * sum(|a-b|) / denom      (F.l1_loss, vidgen/modeling/loss/loss.py:11-12)
+extern "C" int lvt_l1_fwd(const float *a, const float *b, long long n, double denom, float scale, float *out,
+                          void *workspace, size_t workspace_bytes, void *stream) {
+    LVT_REQUIRE(a && b && out && n > 0 && n % 4 == 0 && denom > 0, "l1_fwd: bad args");
+    LVT_REQUIRE(workspace && workspace_bytes >= lvt_reduce_workspace_bytes(), "l1_fwd: workspace");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = grid_for(n / 4, 256 * 4, RED_BLOCKS);
+    hipLaunchKernelGGL(lvt_sqdiff_partial_kernel<1>, dim3(blocks), dim3(256), 0, s, a, b, n / 4, (float *)workspace);
+    LVT_CHECK_LAUNCH("lvt_sqdiff_partial_kernel<l1>");
     hipLaunchKernelGGL(lvt_scalar_finish_kernel, dim3(1), dim3(256), 0, s, (const float *)workspace, blocks,
                        (float)((double)scale / denom), (const float *)nullptr, out);
     LVT_CHECK_LAUNCH("lvt_scalar_finish_kernel");
@@ -140,6 +156,7 @@ extern "C" int lvt_mse_fwd(const float *a, const float *b, long long n, double d
 }
 
 // out = add + g * (2*scale/denom) * (a - b) [* (1 - a^2)]      g = gout_dev[0] (or 1)
+template <int L1>          // L1 = 1: sign(a - b) instead of (a - b) (torch's l1_loss backward: 0 at a == b)
 __global__ void lvt_mse_bwd_kernel(const float *__restrict__ a, const float *__restrict__ b, long long n4, float c,
                                    const float *__restrict__ gout, const float *__restrict__ add, int tanh_of_a,
                                    float *__restrict__ out, float *__restrict__ out_amax) {
@@ -150,7 +167,10 @@ __global__ void lvt_mse_bwd_kernel(const float *__restrict__ a, const float *__r
          i += (long long)gridDim.x * blockDim.x) {
         const float4 x = reinterpret_cast<const float4 *>(a)[i];
         const float4 y = reinterpret_cast<const float4 *>(b)[i];
-        float4 r = make_float4(g * (x.x - y.x), g * (x.y - y.y), g * (x.z - y.z), g * (x.w - y.w));
+        float4 r = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+        if (L1) r = make_float4((float)((r.x > 0.f) - (r.x < 0.f)), (float)((r.y > 0.f) - (r.y < 0.f)), (float)((r.z > 0.f) - (r.z < 0.f)),
+                                (float)((r.w > 0.f) - (r.w < 0.f)));
+        r.x *= g; r.y *= g; r.z *= g; r.w *= g;
         if (tanh_of_a) {
             r.x *= 1.f - x.x * x.x; r.y *= 1.f - x.y * x.y; r.z *= 1.f - x.z * x.z; r.w *= 1.f - x.w * x.w;
         }
@@ -166,9 +186,18 @@ __global__ void lvt_mse_bwd_kernel(const float *__restrict__ a, const float *__r
 extern "C" int lvt_mse_bwd(const float *a, const float *b, long long n, double denom, float scale,
                            const float *gout_dev, const float *add, int tanh_of_a, float *out, float *out_amax, void *stream) {
     LVT_REQUIRE(a && b && out && n > 0 && n % 4 == 0 && denom > 0, "mse_bwd: bad args");
-    hipLaunchKernelGGL(lvt_mse_bwd_kernel, dim3(grid_for(n / 4, 256, out_amax ? 2048 : 8192)), dim3(256), 0, (hipStream_t)stream, a, b,
+    hipLaunchKernelGGL(lvt_mse_bwd_kernel<0>, dim3(grid_for(n / 4, 256, out_amax ? 2048 : 8192)), dim3(256), 0, (hipStream_t)stream, a, b,
                        n / 4, (float)(2.0 * (double)scale / denom), gout_dev, add, tanh_of_a, out, out_amax);
     LVT_CHECK_LAUNCH("lvt_mse_bwd_kernel");
+    return LVT_OK;
+}
+// out = add + g * (scale/denom) * sign(a - b) [* (1 - a^2)]
+extern "C" int lvt_l1_bwd(const float *a, const float *b, long long n, double denom, float scale,
+                          const float *gout_dev, const float *add, int tanh_of_a, float *out, float *out_amax, void *stream) {
+    LVT_REQUIRE(a && b && out && n > 0 && n % 4 == 0 && denom > 0, "l1_bwd: bad args");
+    hipLaunchKernelGGL(lvt_mse_bwd_kernel<1>, dim3(grid_for(n / 4, 256, out_amax ? 2048 : 8192)), dim3(256), 0, (hipStream_t)stream, a, b,
+                       n / 4, (float)((double)scale / denom), gout_dev, add, tanh_of_a, out, out_amax);
+    LVT_CHECK_LAUNCH("lvt_mse_bwd_kernel<l1>");
     return LVT_OK;
 }
 

@@ -1,5 +1,5 @@
-from .evaluator import (BitsEvaluator, CodesExtractor, DatasetEvaluator, DatasetEvaluators, MSEEvaluator,
+from .evaluator import (BitsEvaluator, CodesExtractor, DatasetEvaluator, DatasetEvaluators, MSEEvaluator, VTSampler,
                         build_evaluator, inference_on_dataset)
 
-__all__ = ["BitsEvaluator", "CodesExtractor", "DatasetEvaluator", "DatasetEvaluators", "MSEEvaluator",
+__all__ = ["BitsEvaluator", "CodesExtractor", "DatasetEvaluator", "DatasetEvaluators", "MSEEvaluator", "VTSampler",
            "build_evaluator", "inference_on_dataset"]

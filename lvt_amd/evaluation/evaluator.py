@@ -146,6 +146,66 @@ class BitsEvaluator(_SumEvaluator):
         return results
 
 
+class VTSampler(DatasetEvaluator):
+    """Decodes and saves the videos `VideoTransformerModel` sampled in inference mode (reference:
+    vidgen/evaluation/vt_sampler.py:18-81): builds the VQ-VAE named by cfg.TEST.VT_SAMPLER.VQ_VAE.*, and for every input writes
+    `<output_dir>/samples/<dataset>/video_<sample>_<video_idx>/{codes.npy, <frame>.png}`.  The decode runs on the HIP path
+    (`vqvae.decode` -> gather + ResDecoder); an empty weight path keeps the initialised weights, as fvcore's Checkpointer does."""
+
+    def __init__(self, cfg, dataset_name, distributed=True, output_dir=None, vqvae=None):
+        from ..config import get_cfg
+        from ..modeling import build_model
+        from ..utils.checkpoint import Checkpointer
+        self._logger = logging.getLogger(__name__)
+        self._dataset_name, self._distributed, self._output_dir = dataset_name, distributed, output_dir
+        vs = cfg.TEST.VT_SAMPLER.VQ_VAE
+        vq_cfg = get_cfg()
+        vq_cfg.merge_from_file(vs.CFG)
+        vq_cfg.MODEL.DEVICE = cfg.MODEL.DEVICE
+        vq_cfg.OUTPUT_DIR = cfg.OUTPUT_DIR
+        self.vqvae = vqvae if vqvae is not None else build_model(vq_cfg)
+        for module, path in ((self.vqvae.encoder, vs.ENCODER_WEIGHTS), (self.vqvae.generator, vs.GENERATOR_WEIGHTS),
+                             (self.vqvae.codebook, vs.CODEBOOK_WEIGHTS)):
+            if path:
+                Checkpointer(module).resume_or_load(path, resume=False)
+        self.vqvae.set_generator_requires_grad(False)
+        self.vqvae.eval()
+        self.scale_to_zeroone = vq_cfg.INPUT.SCALE_TO_ZEROONE
+
+    @torch.no_grad()
+    def process(self, inputs, outputs):
+        from PIL import Image
+        for inp, out in zip(inputs, outputs):
+            v_idx = inp["video_idx"]
+            for sample_idx, sample in enumerate(out["samples"]):        # each (nc, T, h, w), or (1, T, h, w) -> (T, h, w)
+                sample = sample.squeeze(0)
+                if sample.dim() == 4:
+                    sample = sample.transpose(0, 1).contiguous()         # (T, nc, h, w)
+                code = sample.detach().cpu().numpy()
+                frames = self.vqvae.back_normalizer(self.vqvae.decode(sample))           # (T, 3, H, W)
+                if self.scale_to_zeroone:
+                    frames = frames * 255
+                frames = frames.clamp_(0.0, 255.0).permute(0, 2, 3, 1).contiguous().cpu().numpy().astype(np.uint8)
+                video_dir = os.path.join(self._output_dir, "samples", self._dataset_name, "video_%d_%s" % (sample_idx, v_idx))
+                os.makedirs(video_dir, exist_ok=True)
+                np.save(os.path.join(video_dir, "codes.npy"), code)
+                for frame_idx in range(len(frames)):
+                    path = os.path.join(video_dir, "%d.png" % frame_idx)
+                    for attempt in range(10):                            # (vt_sampler.py:74-81: shared file systems hiccup)
+                        try:
+                            Image.fromarray(frames[frame_idx]).save(path)
+                            break
+                        except OSError:
+                            if attempt == 9:
+                                raise
+                            time.sleep(3)
+
+    def evaluate(self):
+        if self._distributed:
+            comm.synchronize()
+        return None
+
+
 def build_evaluator(cfg, dataset_name, output_folder=None):
     """Substring dispatch on cfg.TEST.EVALUATORS like tools/train_net.py:35-57 of the reference."""
     if output_folder is None:
@@ -157,6 +217,8 @@ def build_evaluator(cfg, dataset_name, output_folder=None):
         evs.append(MSEEvaluator(dataset_name, True, output_folder))
     if "BitsEvaluator" in cfg.TEST.EVALUATORS:
         evs.append(BitsEvaluator(dataset_name, True, output_folder))
+    if "VTSampler" in cfg.TEST.EVALUATORS:
+        evs.append(VTSampler(cfg, dataset_name, True, output_folder))
     if not evs:
         raise NotImplementedError(cfg.TEST.EVALUATORS)
     return evs[0] if len(evs) == 1 else DatasetEvaluators(evs)

@@ -147,6 +147,8 @@ def _declare(lib):
         "lvt_reduce_workspace_bytes": (sz, []),
         "lvt_mse_fwd": (ci, [vp, vp, cll, C.c_double, cf, vp, vp, sz, vp]),
         "lvt_mse_bwd": (ci, [vp, vp, cll, C.c_double, cf, vp, vp, ci, vp, vp, vp]),
+        "lvt_l1_fwd": (ci, [vp, vp, cll, C.c_double, cf, vp, vp, sz, vp]),
+        "lvt_l1_bwd": (ci, [vp, vp, cll, C.c_double, cf, vp, vp, ci, vp, vp, vp]),
         "lvt_tanh_bwd": (ci, [vp, vp, cll, vp, vp, vp]),
         "lvt_axpy": (ci, [vp, vp, cll, vp, cf, vp, vp]),
         "lvt_add_periodic": (ci, [vp, vp, cll, ci, ci, vp]),

@@ -35,19 +35,19 @@ def _red_ws(dev):
     return L.workspace(n, dev, "reduce"), n
 
 
-def mse_fwd(a, b, denom, scale=1.0):
+def mse_fwd(a, b, denom, scale=1.0, l1=False):
     L.require(a, b)
     out = _f32(1, like=a)
     ws, n = _red_ws(a.device)
-    L.check(L.lib().lvt_mse_fwd(L.ptr(a), L.ptr(b), a.numel(), float(denom), scale, L.ptr(out), L.ptr(ws), n,
+    L.check((L.lib().lvt_l1_fwd if l1 else L.lib().lvt_mse_fwd)(L.ptr(a), L.ptr(b), a.numel(), float(denom), scale, L.ptr(out), L.ptr(ws), n,
                                 L.stream_ptr()), "lvt_mse_fwd")
     return out.view(())
 
 
-def mse_bwd(a, b, denom, scale=1.0, gout=None, add=None, tanh_of_a=False):
+def mse_bwd(a, b, denom, scale=1.0, gout=None, add=None, tanh_of_a=False, l1=False):
     L.require(a, b, gout, add)
     out = torch.empty_like(a)
-    L.check(L.lib().lvt_mse_bwd(L.ptr(a), L.ptr(b), a.numel(), float(denom), scale, L.ptr(gout), L.ptr(add),
+    L.check((L.lib().lvt_l1_bwd if l1 else L.lib().lvt_mse_bwd)(L.ptr(a), L.ptr(b), a.numel(), float(denom), scale, L.ptr(gout), L.ptr(add),
                                 1 if tanh_of_a else 0, L.ptr(out), L.out_amax(out), L.stream_ptr()), "lvt_mse_bwd")
     return out
 

@@ -325,22 +325,59 @@ def _permute_cols(uw, d, ncols):
     return out
 
 
+class _TiedOutputFn(torch.autograd.Function):
+    """SHARE_EMBEDDINGS (videotransformer.py:152-154, 174-176): logits = x E^T with E a channel embedding table of the decoder
+    (`F.linear(out, weight=ch_embedder[k].weight, bias=None)`), token-major (rows, de) -> (rows, nv)."""
+
+    @staticmethod
+    def forward(ctx, x, table):
+        L.require(x, table)
+        ctx.save_for_backward(x, table)
+        out = torch.empty(x.shape[0], table.shape[0], dtype=torch.float32, device=x.device)
+        G.gemm(x, table, out, x.shape[0], table.shape[0], x.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, table = ctx.saved_tensors
+        g = g.contiguous()
+        rows, nv, de = x.shape[0], table.shape[0], table.shape[1]
+        dx = torch.empty(rows, de, dtype=torch.float32, device=x.device)
+        G.gemm(g, table, dx, rows, de, nv, ta=0, tb=1, ldb=de)
+        return dx, linear_wgrad(g, x, nv, de, rows)
+
+
 class ChannelPredictor(nn.Module):
     def __init__(self, d, nc, nv, de, share_p=True, share_embeddings=False):
         super().__init__()
-        if share_embeddings:
-            raise NotImplementedError("the SHARE_EMBEDDINGS variant (videotransformer.py:124-125) is not used by the shipped configs")
         self.nc, self.nv, self.share_p, self.share_embeddings = nc, nv, share_p, share_embeddings
+        self._tied = None                  # SHARE_EMBEDDINGS: the decoder's channel embedding tables (set by tie_embeddings)
         self.layer_norm = nn.LayerNorm(d)
         self.U = nn.ModuleList([nn.Linear(d + k * nv, d, bias=True) for k in range(nc)])
         self.relu = nn.ReLU(inplace=True)
         if share_p:         # the reference's config default (defaults.py:50; videotransformer.py:121-123): ONE output layer for all channels
+            assert not share_embeddings, "does not make sense"                     # (videotransformer.py:122)
             self.P = nn.Linear(d, nv, bias=True)
+        elif share_embeddings:  # ONE layer d -> de; the decoder's channel embedding table E_k is the output matrix (:124-125,152-154)
+            self.P = nn.Linear(d, de, bias=True)
         else:
             self.P = nn.ModuleList([nn.Linear(d, nv, bias=True) for _ in range(nc)])
 
     def _P(self, k):
-        return self.P if self.share_p else self.P[k]
+        return self.P if (self.share_p or self.share_embeddings) else self.P[k]
+
+    def tie_embeddings(self, ch_embedder):
+        """SHARE_EMBEDDINGS: remember the decoder's embedding modules WITHOUT registering them here (their parameters stay
+        the decoder's: state_dict keys as the reference's, whose forward receives them as an argument)."""
+        object.__setattr__(self, "_tied", ch_embedder)
+
+    def _tables(self, ch_embedder=None):
+        if not self.share_embeddings:
+            return None
+        emb = ch_embedder if ch_embedder is not None else self._tied
+        if emb is None:
+            raise L.LvtError("ChannelPredictor(share_embeddings=True) needs the decoder's ch_embedder (videotransformer.py:236)")
+        return [e.weight for e in emb]
 
     def _flat_params(self):
         """(U_k.weight, U_k.bias, P_k.weight, P_k.bias) per channel; with a shared P the same two tensors appear nc times and
@@ -350,10 +387,14 @@ class ChannelPredictor(nn.Module):
             flat += [self.U[k].weight, self.U[k].bias, self._P(k).weight, self._P(k).bias]
         return flat
 
-    def logits_tokens(self, sl, yl_tok):
+    def logits_tokens(self, sl, yl_tok, ch_embedder=None):
         """-> tuple of nc (rows, nv) token-major logits."""
-        return _ChannelPredictorFn.apply(yl_tok, sl.contiguous(), self.layer_norm.weight, self.layer_norm.bias,
+        outs = _ChannelPredictorFn.apply(yl_tok, sl.contiguous(), self.layer_norm.weight, self.layer_norm.bias,
                                          self.nv, *self._flat_params())
+        tables = self._tables(ch_embedder)
+        if tables is not None:
+            outs = tuple(_TiedOutputFn.apply(o, tables[k]) for k, o in enumerate(outs))
+        return outs
 
     def sample_pixel_tokens(self, yl_tok, b, P, pos, temp=1.0, forced_codes=None, return_probs=False):
         """One pixel of every sample: sequentially draw the nc channels (videotransformer.py:161-185).
@@ -380,6 +421,7 @@ class ChannelPredictor(nn.Module):
         (a table filled once per slice: the decode graphs contain no random-number generator)."""
         b, d = rows.shape
         cached = getattr(self, "_ut", None)
+        tables = self._tables()
         y, _, _ = ew.layernorm_fwd(rows, self.layer_norm.weight, self.layer_norm.bias, save_stats=False)
         codes = torch.zeros(b, self.nc, 1, dtype=torch.int64, device=rows.device)
         probs = []
@@ -398,8 +440,11 @@ class ChannelPredictor(nn.Module):
             # recorded into a hipGraph: incremental.GraphedSliceSampler passes the decoder's own)
             G.gemm_small(y, uw, u_, b, d, d, ldb=uw.shape[1], flags=L.EPI_BIAS | L.EPI_RELU | (L.EPI_RESIDUAL if k else 0),
                          bias=self.U[k].bias, res=res, split_ws=split_ws)
-            o = torch.empty(b, self.nv, dtype=torch.float32, device=y.device)
-            G.gemm_small(u_, pw, o, b, self.nv, d, flags=L.EPI_BIAS, bias=self._P(k).bias, split_ws=split_ws)
+            o = torch.empty(b, pw.shape[0], dtype=torch.float32, device=y.device)
+            G.gemm_small(u_, pw, o, b, pw.shape[0], d, flags=L.EPI_BIAS, bias=self._P(k).bias, split_ws=split_ws)
+            if tables is not None:      # SHARE_EMBEDDINGS: (b, de) -> (b, nv) through the tied table (videotransformer.py:174-176)
+                o_de, o = o, torch.empty(b, self.nv, dtype=torch.float32, device=y.device)
+                G.gemm_small(o_de, tables[k].detach(), o, b, self.nv, pw.shape[0], split_ws=split_ws)
             if forced_codes is None:
                 # writes codes[:, k, 0] (element stride nc between samples)
                 if uniforms is not None:
@@ -419,8 +464,10 @@ class ChannelPredictor(nn.Module):
     def forward(self, slice, yl, mode="logits", pixel=None, temp=1.0, ch_embedder=None, target=None):
         b, d, t, h, w = yl.shape
         tok = convstack._TokensIn.apply(yl)
+        if ch_embedder is not None and self.share_embeddings:
+            self.tie_embeddings(ch_embedder)
         if mode == "logits":
-            outs = self.logits_tokens(slice, tok)
+            outs = self.logits_tokens(slice, tok, ch_embedder)
             return [convstack._TokensOut.apply(o, b, self.nv, t, h, w) for o in outs]
         if mode == "sample_pixel":
             ti, hi, wi = pixel
@@ -445,6 +492,8 @@ class VideoTransformer(Autoregressive):
         self.encoder = VTEncoder(nc, nv, da, de, d, blocks_e, n_head_e, kernel_size, stride, pad_value, class_num)
         self.decoder = VTDecoder(nc, nv, da, de, d, blocks_d, n_head_d)
         self.ch_predictor = ChannelPredictor(d, nc, nv, de, share_p=share_p, share_embeddings=share_embeddings)
+        if share_embeddings:
+            self.ch_predictor.tie_embeddings(self.decoder.ch_embedder)       # (videotransformer.py:236, 245)
 
     # token-major fast path used by VideoTransformerModel -----------------------------------------------
     def logits_tokens(self, context, slice, slice_idx, class_idx=None):

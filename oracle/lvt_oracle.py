@@ -259,7 +259,7 @@ class _StraightThrough(torch.autograd.Function):
 
 
 def vqvae_supervised_loss(enc, dec, cb_state, x, beta=1.0, lam=1.0, num=4, all_reduce=None,
-                          alias_running_sum=False, force_idx=None, n_layers=2, ema=True):
+                          alias_running_sum=False, force_idx=None, n_layers=2, ema=True, pixel_mode="l2"):
     """compute_supervised_loss (vqvae.py:66-91).  x already normalised, (N,3,H,W) or (B,T,3,H,W).
     n_layers = residual blocks per side (2: PR-DVQVAE2, 4: K-DVQVAE).
 
@@ -274,7 +274,8 @@ def vqvae_supervised_loss(enc, dec, cb_state, x, beta=1.0, lam=1.0, num=4, all_r
     z_q_st = _StraightThrough.apply(z_e, z_q_st_val)
     x_tilde = res_decoder(dec, z_q_st, n_layers)
     losses = {
-        "loss_reconstruction": lam * F.mse_loss(x_tilde, x),
+        # PixelLoss (loss/loss.py:10-19): LOSS.PIXEL.MODE "l2" -> mse_loss, "l1" -> l1_loss, times LAMBDA
+        "loss_reconstruction": lam * (F.l1_loss if pixel_mode == "l1" else F.mse_loss)(x_tilde, x),
         "loss_commitment": beta * F.mse_loss(z_e, z_q_bar.detach()),
     }
     if not ema:
@@ -525,9 +526,11 @@ def vt_decoder(p, sl, zl, blocks):
     return x
 
 
-def channel_predictor_logits(p, sl, yl, nv=512):
+def channel_predictor_logits(p, sl, yl, nv=512, ch_embedder=None):
     """ChannelPredictor 'logits' (videotransformer.py:139-160): per-channel output layers P.k (SHARE_P False) or, when the
     parameter dict holds `ch_predictor.P.weight`, the ONE shared layer of SHARE_P True (:121-123,150-151).
+    ch_embedder (list of nc (nv, de) tables): SHARE_EMBEDDINGS (:124-125,152-154) -- the shared P maps d -> de and the
+    decoder's channel embedding table is the output matrix, `F.linear(out, weight=ch_embedder[k].weight)`.
     Returns list of nc tensors (b, nv, t, h, w)."""
     pre = "ch_predictor."
     b, d, t, h, w = yl.shape
@@ -541,6 +544,8 @@ def channel_predictor_logits(p, sl, yl, nv=512):
         u = F.linear(inp, p[pre + "U.%d.weight" % k], p[pre + "U.%d.bias" % k])
         pk = "P." if (pre + "P.weight") in p else "P.%d." % k
         o = F.linear(torch.relu(u), p[pre + pk + "weight"], p[pre + pk + "bias"])
+        if ch_embedder is not None:
+            o = F.linear(o, ch_embedder[k])
         out.append(o.transpose(1, 2).contiguous().view(b, nv, t, h, w))
     return out
 

@@ -640,12 +640,41 @@ def golden_single_codebook():
          **{"new." + k: v for k, v in new.items()})
 
 
+def golden_share_embeddings():
+    """G24: ChannelPredictor with SHARE_EMBEDDINGS (videotransformer.py:124-125,152-154): ONE layer P: d -> de whose output meets
+    the decoder's channel embedding table E_k as the output matrix (logits_k = P(relu(u_k)) E_k^T).  Logits, and the gradients of P,
+    of the tied tables, of U_2 and of the input, at reduced width (d = 128, nv = 64, nc = 3, de = 32)."""
+    from vidgen.modeling.autoregressive.videotransformer import ChannelPredictor
+    SEED = 2424
+    d, nc, nv, de = 128, 3, 64, 32
+    cp = ChannelPredictor(d, nc, nv, de, share_p=False, share_embeddings=True)
+    shapes = {"layer_norm.weight": (d,), "layer_norm.bias": (d,), "P.weight": (de, d), "P.bias": (de,)}
+    for k in range(nc):
+        shapes["U.%d.weight" % k] = (d, d + k * nv)
+        shapes["U.%d.bias" % k] = (d,)
+    assert set(shapes) == set(cp.state_dict().keys())
+    load_into(cp, seeded.seeded_params(shapes, SEED, "g24."))
+    emb = torch.nn.ModuleList([torch.nn.Embedding(nv, de) for _ in range(nc)])
+    load_into(emb, seeded.seeded_params({"%d.weight" % k: (nv, de) for k in range(nc)}, SEED, "g24.emb."))
+    sl = seeded.seeded_codes("g24.slice", (2, nc, 2, 8, 8), SEED, nv=nv)
+    yl = seeded.seeded_input("g24.yl", (2, d, 2, 8, 8), SEED, -2.0, 2.0).requires_grad_(True)
+    gys = [seeded.seeded_input("g24.gy%d" % k, (2, nv, 2, 8, 8), SEED, -1.0, 1.0) for k in range(nc)]
+    pred = cp(sl, yl, mode="logits", ch_embedder=emb)
+    sum((o * g).sum() for o, g in zip(pred, gys)).backward()
+    save("g24_share_embeddings", seed=SEED, dims=np.array([d, nc, nv, de]), slice=sl, yl=yl,
+         **{"logits_%d" % k: pred[k] for k in range(nc)}, **{"gy_%d" % k: gys[k] for k in range(nc)},
+         grad_P_weight=cp.P.weight.grad, grad_P_bias=cp.P.bias.grad, grad_U2_weight=cp.U[2].weight.grad,
+         grad_yl=yl.grad, **{"grad_emb_%d" % k: emb[k].weight.grad for k in range(nc)})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["vqvae", "vt", "variants", "pins", "share_p", "single"]
+    which = sys.argv[1:] or ["vqvae", "vt", "variants", "pins", "share_p", "single", "share_emb"]
     if "share_p" in which:
         golden_share_p()
     if "single" in which:
         golden_single_codebook()
+    if "share_emb" in which:
+        golden_share_embeddings()
     if "pins" in which:
         golden_pins()
     if "vqvae" in which:

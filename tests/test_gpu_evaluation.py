@@ -48,3 +48,42 @@ def test_bits_evaluator_matches_oracle():
     nll = F.cross_entropy(lg.permute(1, 0, 2, 3, 4)[None], codes.transpose(0, 1)[None], reduction="none")[0]
     ref = float(nll[:, 1:].sum()) / math.log(2) / nll[:, 1:].numel()            # first frame (N_PRIME=1) ignored
     assert abs(res["likelihood"]["bits_per_dim"] - ref) < 2e-5 * ref
+
+
+def test_vt_sampler_writes_decoded_samples(tmp_path):
+    """TEST.EVALUATORS "VTSampler" (vt_sampler.py:18-81, tools/train_net.py:52-53): the transformer's inference output carries
+    `samples`, the evaluator decodes them with the configured VQ-VAE and writes codes.npy + one PNG per frame per sample; the
+    saved frames equal a direct decode of the saved codes."""
+    from PIL import Image
+    from lvt_amd.evaluation import VTSampler, build_evaluator, inference_on_dataset
+    from lvt_amd.modeling import build_model
+    from util_models import ROOT
+    cfg = dsfvt_cfg()
+    cfg.OUTPUT_DIR = str(tmp_path)
+    cfg.TEST.EVALUATORS = "VTSampler"
+    cfg.TEST.VT_SAMPLER.NUM_SAMPLES = 2
+    cfg.TEST.VT_SAMPLER.N_PRIME = 14                              # two frames to sample: 512 positions
+    cfg.TEST.VT_SAMPLER.VQ_VAE.CFG = os.path.join(ROOT, "configs/vqvae/PR-DVQVAE2.yaml")
+    with pytest.raises(FileNotFoundError):                       # the configured checkpoints are not in the tree: an error, as in the reference
+        build_evaluator(cfg, "prdvqvae_test")
+    vs = cfg.TEST.VT_SAMPLER.VQ_VAE
+    vs.ENCODER_WEIGHTS = vs.GENERATOR_WEIGHTS = vs.CODEBOOK_WEIGHTS = ""         # initialised weights
+    model = build_model(cfg)
+    model.model.load_state_dict(seeded.seeded_params(seeded.dsfvt_shapes(), 21), strict=False)
+    ev = build_evaluator(cfg, "prdvqvae_test")
+    assert isinstance(ev, VTSampler)
+    codes = seeded.seeded_codes("vts", (16, 4, 16, 16), 21)
+    inference_on_dataset(model, [[{"image_sequence": codes, "video_idx": 7}]], ev)
+    root = os.path.join(str(tmp_path), "inference", "samples", "prdvqvae_test")
+    assert sorted(os.listdir(root)) == ["video_0_7", "video_1_7"]
+    for s_ in range(2):
+        d = os.path.join(root, "video_%d_7" % s_)
+        saved = np.load(os.path.join(d, "codes.npy"))
+        assert saved.shape == (16, 4, 16, 16) and saved.dtype == np.int64
+        assert np.array_equal(saved[:14], codes.numpy()[:14])                      # the priming frames are kept
+        assert sorted(os.listdir(d)) == sorted(["codes.npy"] + ["%d.png" % i for i in range(16)])
+        with torch.no_grad():
+            fr = ev.vqvae.back_normalizer(ev.vqvae.decode(torch.from_numpy(saved).to("cuda:0"))) * 255
+        fr = fr.clamp(0, 255).permute(0, 2, 3, 1).cpu().numpy().astype(np.uint8)
+        png = np.asarray(Image.open(os.path.join(d, "9.png")))
+        assert png.shape == (64, 64, 3) and np.array_equal(png, fr[9])

@@ -214,3 +214,35 @@ def test_g21_share_p_channel_predictor(golden):
         codes, probs = cp.sample_from_rows(torch.randn(4, d, device=DEV), forced_codes=torch.zeros(4, nc, dtype=torch.int64),
                                            return_probs=True)
     assert tuple(probs.shape) == (4, nc, nv) and torch.isfinite(probs).all()
+
+
+def test_g24_share_embeddings_channel_predictor(golden):
+    """SHARE_EMBEDDINGS (videotransformer.py:124-125,152-154,174-176): ONE layer P: d -> de, the decoder's channel embedding
+    table E_k as the output matrix.  Logits and gradients (P, the tied tables, U_2, the input) against the reference's own
+    ChannelPredictor(share_embeddings=True), fixture G24; the sampling path goes through the same tables."""
+    import seeded
+    from lvt_amd.modeling.autoregressive.videotransformer import ChannelPredictor
+    g = golden("g24_share_embeddings")
+    d, nc, nv, de = [int(x) for x in g["dims"]]
+    cp = ChannelPredictor(d, nc, nv, de, share_p=False, share_embeddings=True)
+    shapes = {k: tuple(v.shape) for k, v in cp.state_dict().items()}
+    assert shapes["P.weight"] == (de, d) and not any(k.startswith("P.0") or "emb" in k for k in shapes)
+    cp.load_state_dict(seeded.seeded_params(shapes, int(g["seed"]), "g24."))
+    emb = torch.nn.ModuleList([torch.nn.Embedding(nv, de) for _ in range(nc)])
+    emb.load_state_dict(seeded.seeded_params({"%d.weight" % k: (nv, de) for k in range(nc)}, int(g["seed"]), "g24.emb."))
+    cp, emb = cp.to(DEV), emb.to(DEV)
+    yl = g["yl"].to(DEV).requires_grad_(True)
+    pred = cp(g["slice"].to(DEV), yl, mode="logits", ch_embedder=emb)
+    sum((o * g["gy_%d" % k].to(DEV)).sum() for k, o in enumerate(pred)).backward()
+    for k in range(nc):
+        assert rel_err(pred[k], g["logits_%d" % k]) < 2e-5
+        assert rel_err(emb[k].weight.grad, g["grad_emb_%d" % k]) < 1e-4
+    assert rel_err(cp.P.weight.grad, g["grad_P_weight"]) < 1e-4
+    assert rel_err(cp.P.bias.grad, g["grad_P_bias"]) < 1e-4
+    assert rel_err(cp.U[2].weight.grad, g["grad_U2_weight"]) < 1e-4
+    assert rel_err(yl.grad, g["grad_yl"]) < 1e-4
+    with torch.no_grad():
+        rows = torch.randn(4, d, device=DEV)
+        codes, probs = cp.sample_from_rows(rows, forced_codes=torch.zeros(4, nc, dtype=torch.int64), return_probs=True)
+        ref = torch.softmax(cp.P(torch.relu(cp.U[0](cp.layer_norm(rows)))) @ emb[0].weight.t(), 1)
+    assert tuple(probs.shape) == (4, nc, nv) and rel_err(probs[:, 0], ref) < 1e-4

@@ -459,3 +459,42 @@ def test_single_codebook_trained_and_against_the_oracle(golden):
     d0, d1, i64 = O.vq_margin_fp64(rows, st["embedding.weight"])
     clear = (d1 - d0) > 1e-5 * d0
     assert torch.equal(idx[clear], i64[clear]) and int((~clear).sum()) < 64
+
+
+def test_pixel_loss_l1_mode():
+    """LOSS.PIXEL.MODE "l1" (loss.py:11-12): lvt_l1_fwd / lvt_l1_bwd against torch, then the VQ-VAE step against the oracle."""
+    from lvt_amd.hip import ew
+    from lvt_amd.modeling import build_model
+    from lvt_amd.utils.events import EventStorage
+    from util_models import vqvae_cfg
+    g = torch.Generator().manual_seed(2)
+    a, b = torch.randn(8, 1000, generator=g), torch.randn(8, 1000, generator=g)
+    b[0, :10] = a[0, :10]                                                       # exact ties: gradient 0, as torch
+    ar = a.clone().requires_grad_(True)
+    ref = 0.7 * torch.nn.functional.l1_loss(ar, b)
+    ref.backward()
+    out = ew.mse_fwd(a.to(DEV), b.to(DEV), a.numel(), 0.7, l1=True)
+    assert abs(float(out) - float(ref)) < 1e-6 * float(ref)
+    gr = ew.mse_bwd(a.to(DEV), b.to(DEV), a.numel(), 0.7, gout=torch.ones(1, device=DEV), l1=True)
+    assert torch.allclose(gr.cpu(), ar.grad, rtol=1e-6, atol=0)
+    seed = 1234
+    cfg = vqvae_cfg(DEV)
+    cfg.LOSS.PIXEL.MODE = "l1"
+    model = build_model(cfg)
+    enc = seeded.seeded_params(seeded.VQVAE_ENCODER_SHAPES, seed, "enc.")
+    dec = seeded.seeded_params(seeded.VQVAE_DECODER_SHAPES, seed, "dec.")
+    st = seeded.seeded_codebook_state(seed, scale=0.05)
+    model.encoder.load_state_dict(enc), model.generator.load_state_dict(dec), model.codebook.load_state_dict(st)
+    model.train()
+    x = torch.stack([seeded.seeded_input("g5.f%d" % i, (3, 64, 64), seed) for i in range(2)])
+    with EventStorage(0):
+        losses = model([{"image": x[i].numpy()} for i in range(2)], mode="supervised")
+    sum(losses.values()).backward()
+    for p in list(enc.values()) + list(dec.values()):
+        p.requires_grad_(True)
+    ref, _, _ = O.vqvae_supervised_loss(enc, dec, st, O.normalize(x, MEAN, STD), pixel_mode="l1",
+                                        force_idx=model.codebook.last_indices.cpu())
+    sum(ref.values()).backward()
+    assert abs(float(losses["loss_reconstruction"]) - float(ref["loss_reconstruction"])) < 1e-5 * float(ref["loss_reconstruction"])
+    assert rel_err(model.generator.layers[6].bias.grad, dec["layers.6.bias"].grad) < 1e-3
+    assert rel_err(model.generator.layers[6].weight.grad, dec["layers.6.weight"].grad) < 1e-3

@@ -320,8 +320,8 @@ def test_relu_decision_matching_helper_on_a_toy_network():
 
 def test_channel_predictor_share_p_is_the_config_default_and_constructs():
     """SHARE_P defaults to True in the reference's config (vidgen/config/defaults.py:50): a config that does not set it must
-    build, with ONE output layer whose state_dict keys are the reference's (`P.weight`, `P.bias`); SHARE_EMBEDDINGS stays a
-    documented error."""
+    build, with ONE output layer whose state_dict keys are the reference's (`P.weight`, `P.bias`); SHARE_EMBEDDINGS (one layer d -> de, the decoder's tables as
+    output matrices) constructs with the reference's keys."""
     from lvt_amd.config import get_cfg
     from lvt_amd.modeling.autoregressive.videotransformer import ChannelPredictor
     assert get_cfg().MODEL.AUTOREGRESSIVE.VT.SHARE_P is True
@@ -330,8 +330,10 @@ def test_channel_predictor_share_p_is_the_config_default_and_constructs():
     assert {"P.weight", "P.bias", "U.2.weight", "layer_norm.bias"} <= keys and not any(k.startswith("P.0") for k in keys)
     assert tuple(cp.P.weight.shape) == (16, 64)
     assert len(ChannelPredictor(64, 3, 16, 8, share_p=False).P) == 3
-    with pytest.raises(NotImplementedError):
-        ChannelPredictor(64, 3, 16, 8, share_p=False, share_embeddings=True)
+    se = ChannelPredictor(64, 3, 16, 8, share_p=False, share_embeddings=True)       # (videotransformer.py:124-125): P maps d -> de
+    assert tuple(se.P.weight.shape) == (8, 64) and set(se.state_dict()) == {k for k in keys if not k.startswith("P.")} | {"P.weight", "P.bias"}
+    with pytest.raises(AssertionError):
+        ChannelPredictor(64, 3, 16, 8, share_p=True, share_embeddings=True)
 
 
 def test_single_codebook_is_the_config_default_and_constructs():

@@ -259,6 +259,27 @@ def test_g21_share_p_channel_predictor(golden):
     assert rel_err(yl.grad, g["grad_yl"]) < 1e-4
 
 
+def test_g24_share_embeddings_channel_predictor(golden):
+    """SHARE_EMBEDDINGS (videotransformer.py:124-125,152-154): the oracle against the reference's own module (fixture G24)."""
+    g = golden("g24_share_embeddings")
+    d, nc, nv, de = [int(x) for x in g["dims"]]
+    shapes = {"layer_norm.weight": (d,), "layer_norm.bias": (d,), "P.weight": (de, d), "P.bias": (de,)}
+    for k in range(nc):
+        shapes["U.%d.weight" % k] = (d, d + k * nv)
+        shapes["U.%d.bias" % k] = (d,)
+    params = {"ch_predictor." + k: v.clone().requires_grad_(True) for k, v in seeded.seeded_params(shapes, int(g["seed"]), "g24.").items()}
+    emb = [v.clone().requires_grad_(True) for v in seeded.seeded_params({"%d.weight" % k: (nv, de) for k in range(nc)}, int(g["seed"]), "g24.emb.").values()]
+    yl = g["yl"].clone().requires_grad_(True)
+    pred = O.channel_predictor_logits(params, g["slice"], yl, nv=nv, ch_embedder=emb)
+    sum((o * g["gy_%d" % k]).sum() for k, o in enumerate(pred)).backward()
+    for k in range(nc):
+        assert rel_err(pred[k], g["logits_%d" % k]) < FTOL
+        assert rel_err(emb[k].grad, g["grad_emb_%d" % k]) < 1e-4
+    assert rel_err(params["ch_predictor.P.weight"].grad, g["grad_P_weight"]) < 1e-4
+    assert rel_err(params["ch_predictor.U.2.weight"].grad, g["grad_U2_weight"]) < 1e-4
+    assert rel_err(yl.grad, g["grad_yl"]) < 1e-4
+
+
 def test_g12_full_dsfvt_loss(golden, vtp):
     g = golden("g12_dsfvt_loss")
     p = {k: v.clone().requires_grad_(True) for k, v in vtp.items()}
