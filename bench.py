@@ -326,6 +326,58 @@ class DsfvtLeg:
         return loss
 
 
+def host_fed(vq, ds, steps, world, device):
+    """The same bench step fed from HOST memory the way a training loop feeds the models: per-sample numpy arrays in list[dict]
+    (the reference's DataLoader output; ae.py:151-168, vt.py:284-299), staged by lvt_amd.data.prefetch.DevicePrefetcher -- one
+    pinned buffer and one asynchronous H2D copy per key and batch, issued while the previous step computes -- and handed to
+    `model(data, mode="supervised")`.  2 x 25.2 MB (PR-DVQVAE2, 32 clips) + 4.3 MB (DSFVT, 64 slices) cross PCIe per step.
+    Reported beside `value` (whose inputs are resident in HBM), never as `value`."""
+    import itertools
+    import numpy as np
+    from lvt_amd.data.prefetch import DevicePrefetcher
+    from lvt_amd.utils.events import EventStorage
+    vq_host = [[{"image_sequence": c.cpu().numpy()} for c in clips] for clips in vq.clips]
+    ds_host = []
+    for ctx, sl, sidx, ign in ds.batches:
+        c, s_, i_, g_ = ctx.cpu().numpy(), sl.cpu().numpy(), sidx.cpu().numpy(), ign.cpu().numpy()
+        ds_host.append([{"context": c[j], "slice": s_[j], "slice_idx": i_[j], "ignore_mask": g_[j]} for j in range(c.shape[0])])
+    n_vq = max(1, ds.batch // vq.batch)              # VQ-VAE train steps per DSFVT train step (2)
+
+    def run(n):
+        vq_it = iter(DevicePrefetcher(itertools.islice(itertools.cycle(vq_host), n * n_vq), device))
+        ds_it = iter(DevicePrefetcher(itertools.islice(itertools.cycle(ds_host), n), device))
+        for i in range(n):
+            for j in range(n_vq):
+                with EventStorage(i):
+                    losses = vq.model(next(vq_it), mode="supervised")
+                sum(losses.values()).backward()
+                for o in vq.optimizers:
+                    o["optimizer"].step()
+                for o in vq.optimizers:
+                    o["optimizer"].zero_grad()
+            with EventStorage(i):
+                loss = ds.model(next(ds_it), mode="supervised")["loss_cross_entropy"]
+            loss.backward()
+            for o in ds.optimizers:
+                o["optimizer"].step()
+            for o in ds.optimizers:
+                o["optimizer"].zero_grad()
+    run(2)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    h2d = (n_vq * vq.batch * CLIP_FRAMES * 3 * 64 * 64 * 4 + sum(v.nbytes for v in ds_host[0][0].values() if hasattr(v, "nbytes")) * ds.batch)
+    return {"clips_per_s": round(ds.batch * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "h2d_bytes_per_step": int(h2d),
+            "note": "per-GPU rate of the bench step with every batch coming from host memory as list[dict] of per-sample numpy "
+                    "arrays through DevicePrefetcher (pinned staging, asynchronous copy on a side stream, overlapped with the "
+                    "previous step) and model(data, mode='supervised'); PCIe-inclusive, reported beside `value`, never as it"}
+
+
 def leg_alone(name, leg, steps, warmup, world, device, units, traffic_file, kernel_note, strict_f32):
     """One leg in its own timed region + instrumented pass -> the `extra.<leg>` block."""
     from lvt_amd.hip import binding as L
@@ -778,6 +830,7 @@ def run(args):
                                    "r06_dsfvt_pmc_hbm_traffic.json",
                                    "lvt_gemm_wide_kernel<*> (QKV / proj / FFN products, their data and weight gradients; f16x2) + "
                                    "lvt_attn_fwd_flash_kernel / lvt_attn_bwd_flash_a / _b (flash attention on fp32 operands, per-row f16x2)", not args.no_strict_f32)
+        extra["host_fed"] = host_fed(vq, ds, max(6, args.steps // 2), world, device)
         v1, v2 = extra["vqvae"]["clips_per_s"], extra["dsfvt"]["samples_per_s"]
         extra["legs_combined_harmonic"] = {"clips_per_s": round(1.0 / (1.0 / v1 + 1.0 / v2), 3),
                                            "note": "1/(1/vqvae + 1/dsfvt) of the two legs timed alone: cross-check of `value`"}

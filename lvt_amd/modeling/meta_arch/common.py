@@ -45,6 +45,13 @@ def stack_to_device(items, device):
     (the reference does one `torch.as_tensor(..., device)` per sample, ae.py:153, vt.py:285-292)."""
     first = items[0]
     if isinstance(first, torch.Tensor):
+        want = torch.device(device)
+        if first._base is not None and first.device.type == want.type and want.index in (None, first.device.index):
+            # per-sample views of ONE batched device tensor, in order (data/prefetch.py DevicePrefetcher): that tensor is the batch
+            base, n = first._base, len(items)
+            if (base.is_contiguous() and base.shape[0] == n and tuple(base.shape[1:]) == tuple(first.shape)
+                    and all(t._base is base and t.data_ptr() == base[i].data_ptr() for i, t in enumerate(items))):
+                return base
         if first.device.type == "cpu":
             return torch.stack(items, dim=0).to(device, non_blocking=True)
         return torch.stack([t.to(device) for t in items], dim=0)

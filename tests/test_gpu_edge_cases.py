@@ -127,3 +127,31 @@ def test_slice_context_kernel_equals_reference_mapper(golden, tag, stride, kerne
         host = prepare_slices_batch(vids, [abc] * 3, stride, kernel, 3, -7)
         for a_, b_ in zip(dev, host):
             assert a_.shape == b_.shape and torch.equal(a_.cpu(), b_), abc
+
+
+def test_device_prefetcher_feeds_the_model_from_pinned_memory():
+    """data/prefetch.py on the device: batches staged in pinned buffers by the worker thread, one asynchronous copy per key, handed
+    over as per-sample views that `stack_to_device` takes without a second copy; the VQ-VAE step on them equals the step on the
+    same arrays passed directly (ae.py:151-168), also when the pinned slots are being reused (more batches than slots)."""
+    import numpy as np
+    import torch
+    from lvt_amd.data.prefetch import DevicePrefetcher
+    from lvt_amd.modeling.meta_arch.common import stack_to_device
+    from lvt_amd.utils.events import EventStorage
+    from util_models import vqvae_seeded
+    rng = np.random.default_rng(3)
+    loader = [[{"image": rng.random((3, 64, 64), dtype=np.float32), "video_idx": 10 * b + i} for i in range(4)] for b in range(7)]
+    model, _, _, _ = vqvae_seeded(5, scale=0.05)
+    model.eval()
+    pf = DevicePrefetcher(loader, "cuda:0")
+    n = 0
+    for data, ref in zip(pf, loader):
+        x = stack_to_device([d["image"] for d in data], "cuda:0")
+        assert x.is_cuda and x.data_ptr() == data[0]["image"].data_ptr() and [d["video_idx"] for d in data] == [d["video_idx"] for d in ref]
+        assert torch.equal(x.cpu(), torch.from_numpy(np.stack([d["image"] for d in ref])))
+        with torch.no_grad():
+            a = model(data, mode="inference")
+            b = model(ref, mode="inference")
+        assert all(torch.equal(p["latent"], q["latent"]) and torch.equal(p["reconstruction"], q["reconstruction"]) for p, q in zip(a, b))
+        n += 1
+    assert n == 7 and all(buf.is_pinned() for bufs in pf._pinned.values() for buf in bufs if buf is not None)

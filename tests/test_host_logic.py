@@ -348,3 +348,20 @@ def test_single_codebook_is_the_config_default_and_constructs():
     assert sorted(SingleVQEmbedding(128, 64, False).state_dict()) == ["embedding.weight"]
     with pytest.raises(NotImplementedError):
         SingleVQEmbedding(512, 100, True)
+
+
+def test_device_prefetcher_keeps_the_input_contract():
+    """data/prefetch.py on CPU (the staging logic; the pinned buffers and the side stream need a GPU): batches come out in order as
+    list[dict] whose array values are per-sample views of ONE batched tensor, which stack_to_device takes as it is."""
+    import numpy as np
+    from lvt_amd.data.prefetch import DevicePrefetcher
+    from lvt_amd.modeling.meta_arch.common import stack_to_device
+    loader = [[{"image": np.full((3, 4, 4), 10 * b + i, dtype=np.float32), "video_idx": i} for i in range(3)] for b in range(5)]
+    seen = []
+    for data in DevicePrefetcher(loader, "cpu"):
+        assert isinstance(data, list) and data[2]["video_idx"] == 2
+        x = stack_to_device([d["image"] for d in data], "cpu")
+        assert x.shape == (3, 3, 4, 4) and x.data_ptr() == data[0]["image"].data_ptr()         # no second copy
+        seen.append(float(x[:, 0, 0, 0].sum()))
+    assert seen == [3.0 + 30 * b for b in range(5)]
+    assert list(DevicePrefetcher([], "cpu")) == []
