@@ -607,6 +607,40 @@ def generation_kv_bytes(vt_cfg, batch, n_prime, tokens=256):
     return int(batch) * (16 - int(n_prime)) * layers * rows * 2 * hd * 4
 
 
+def smallm_gemm_roofline(vt):
+    """The second kernel of the decode steps (45 % of the steady-state window): lvt_gemm_smallm_mfma_kernel<2>, one token per video
+    through the decoder's weights.  Its algorithmic traffic is the WEIGHTS (every launch streams its matrix once, the 256 activation
+    rows are a few hundred KB): bytes per decode step from the model, launches per step and the average launch time from the
+    kernel trace of the steady replay (profiles/r06_generation_kernel_mix.txt -- the launches run inside a replayed hipGraph, where
+    event timing is not available)."""
+    import re
+    dec = vt.model.decoder
+    wbytes = 0
+    for layer in dec.block_local_attention:
+        m, f = layer.mha, layer.ffn
+        wbytes += 4 * (3 * m.w_q.numel() + m.proj.weight.numel() + f[1].weight.numel() + f[3].weight.numel())
+    cp = vt.model.ch_predictor
+    wbytes += 4 * sum(u.weight.shape[0] * u.weight.shape[0] for u in cp.U)            # the dense d x d part; the one-hot columns are gathers
+    wbytes += 4 * sum(cp._P(k).weight.numel() for k in range(cp.nc))
+    try:
+        txt = open(os.path.join(ROOT, "profiles", "r06_generation_kernel_mix.txt")).read()
+        m1 = re.search(r"lvt_gemm_smallm_mfma_kernel<2>\s+(\d+)\s+([\d.]+) us total\s+([\d.]+) us avg", txt)
+        m2 = re.search(r"lvt_decode_commit_kernel\s+(\d+)", txt)
+        launches, total_us, avg_us, steps = int(m1.group(1)), float(m1.group(2)), float(m1.group(3)), int(m2.group(1))
+    except Exception:
+        return {"weight_bytes_per_decode_step": wbytes, "note": "profiles/r06_generation_kernel_mix.txt not found"}
+    per_launch = wbytes * steps / launches
+    gbs = per_launch / avg_us / 1e3
+    return {"kernel": "lvt_gemm_smallm_mfma_kernel<2>", "launches_per_decode_step": round(launches / steps, 1), "avg_us": avg_us,
+            "weight_bytes_per_decode_step": wbytes, "weight_bytes_per_launch": int(per_launch),
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)},
+            "note": "weights streamed per launch / average launch time of the steady replay (three decode groups on three streams: "
+                    "launch times overlap).  %.0f MB of weights per step stay in the 256 MB last-level cache from step to step, "
+                    "so HBM is not what binds these launches: 256 rows x N columns are 4 x N / 32 workgroups of one wave "
+                    "quartet each (16 .. 128 workgroups on 256 CUs) and a launch is its latency chain -- a fused per-layer decode "
+                    "kernel is the lever, not bandwidth" % (wbytes / 1e6)}
+
+
 def bench_generate(device, batch):
     """End-to-end generation: VQ encode of 5 priming frames, DSFVT autoregressive sampling of the remaining 11 frames
     (incremental K/V-cache decode: 2816 single-token steps, one replayed hipGraph per decode group, position held in a
@@ -652,7 +686,8 @@ def bench_generate(device, batch):
         dec = {}
     import lvt_amd.modeling.meta_arch.vt as vtmod
     ngroups = (batch + vtmod.DECODE_GROUP_ROWS - 1) // vtmod.DECODE_GROUP_ROWS
-    return {"frames_per_s": round(16 * batch / dt, 2), "videos_per_s": round(batch / dt, 3), "batch_videos": batch,
+    smallm = smallm_gemm_roofline(vt)
+    return {"smallm_gemm": smallm, "frames_per_s": round(16 * batch / dt, 2), "videos_per_s": round(batch / dt, 3), "batch_videos": batch,
             "seconds": round(dt, 3), "decoder_steps": 11 * 256, "decode_groups": ngroups,
             "group_streams": bool(vtmod.DECODE_GROUP_STREAMS) and ngroups > 1,
             "roofline": {"bound": "hbm", "achieved": round(kv_bytes / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -667,7 +702,7 @@ def bench_generate(device, batch):
                          "kernel": "lvt_attn_decode_kernel (K/V-cache reads of the single-token decode attention); "
                                    "`achieved` = algorithmic K/V bytes of the whole run / END-TO-END wall time (encode, "
                                    "%d decode steps of ~110 launches each replayed as one hipGraph, decode of 16 frames); "
-                                   "kernel mix of the steady replay: profiles/r05_generation_kernel_mix.txt"
+                                   "kernel mix of the steady replay: profiles/r06_generation_kernel_mix.txt"
                                    % (11 * 256)},
             "note": "5 priming + 11 generated frames per video; random-init weights; sampling is sequential (2816 "
                     "single-token decoder steps per group of <= 256 videos); videos are replicas across GPUs"}

@@ -388,7 +388,14 @@ extern "C" int lvt_layernorm_fwd_p2(const float *x, long long rows, int d, float
 }
 
 // dx = rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat)) (+ add);  partial dw/db per workgroup
-#define LN_BWD_BLOCKS 1024
+// 512 workgroups (2 per CU): measured at 16384 x 512, bwd+add 28.0 us against 32.7 us at 1024 and 33 us at 256; more rows in flight
+// per wave (LN_BWD_ROWS 2 / 4) measured 28.6 / 39.1 us (tools/profile/ln_time.py)
+#ifndef LN_BWD_BLOCKS
+#define LN_BWD_BLOCKS 512
+#endif
+#ifndef LN_BWD_ROWS
+#define LN_BWD_ROWS 1
+#endif
 __global__ __launch_bounds__(256) void lvt_layernorm_bwd_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ mean,
     const float *__restrict__ rstd, const float *__restrict__ w, long long rows, int d, const float *__restrict__ add,
@@ -405,40 +412,65 @@ __global__ __launch_bounds__(256) void lvt_layernorm_bwd_kernel(
     const long long rows_per_block = lvt_cdiv(rows, gridDim.x);
     const long long r0 = blockIdx.x * rows_per_block;
     const long long r1 = min(rows, r0 + rows_per_block);
-    for (long long row = r0 + wave; row < r1; row += 4) {
-        const float m = mean[row], rs = rstd[row];
-        const float4 *xp = reinterpret_cast<const float4 *>(x + row * d);
-        const float4 *gp = reinterpret_cast<const float4 *>(dy + row * d);
-        float4 xh[LN_MAXV], gw[LN_MAXV];
-        float s1 = 0.f, s2 = 0.f;
+    // LN_BWD_ROWS rows of a wave are in flight together: their loads are all requested before the first row reduction, and the column
+    // partials still take the rows in ascending order (the sums do not depend on LN_BWD_ROWS)
+    for (long long row0 = r0 + wave; row0 < r1; row0 += 4 * LN_BWD_ROWS) {
+        float4 xh[LN_BWD_ROWS][LN_MAXV], gw[LN_BWD_ROWS][LN_MAXV], zv[LN_BWD_ROWS][LN_MAXV];
+        float rs[LN_BWD_ROWS], s1[LN_BWD_ROWS], s2[LN_BWD_ROWS];
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < d4) {
-                const float4 xv = xp[c], gv = gp[c], ww = reinterpret_cast<const float4 *>(w)[c];
-                xh[i] = make_float4((xv.x - m) * rs, (xv.y - m) * rs, (xv.z - m) * rs, (xv.w - m) * rs);
-                gw[i] = make_float4(gv.x * ww.x, gv.y * ww.y, gv.z * ww.z, gv.w * ww.w);
-                s1 += (gw[i].x + gw[i].y) + (gw[i].z + gw[i].w);
-                s2 += (gw[i].x * xh[i].x + gw[i].y * xh[i].y) + (gw[i].z * xh[i].z + gw[i].w * xh[i].w);
-                adw[i].x += gv.x * xh[i].x; adw[i].y += gv.y * xh[i].y; adw[i].z += gv.z * xh[i].z; adw[i].w += gv.w * xh[i].w;
-                adb[i].x += gv.x; adb[i].y += gv.y; adb[i].z += gv.z; adb[i].w += gv.w;
+        for (int u = 0; u < LN_BWD_ROWS; ++u) {
+            const long long row = row0 + 4 * u;
+            if (row >= r1) continue;
+            // the residual row is requested with the other two (it is only needed after the row reductions: loading it there put a
+            // third dependent memory round trip into every row of an HBM-bound kernel)
+            if (add) {
+#pragma unroll
+                for (int i = 0; i < LN_MAXV; ++i)
+                    if (lane + 64 * i < d4) zv[u][i] = reinterpret_cast<const float4 *>(add + row * d)[lane + 64 * i];
+            }
+            const float m = mean[row];
+            rs[u] = rstd[row];
+            const float4 *xp = reinterpret_cast<const float4 *>(x + row * d);
+            const float4 *gp = reinterpret_cast<const float4 *>(dy + row * d);
+            s1[u] = 0.f; s2[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < LN_MAXV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < d4) {
+                    const float4 xv = xp[c], gv = gp[c], ww = reinterpret_cast<const float4 *>(w)[c];
+                    const float r = rs[u];
+                    xh[u][i] = make_float4((xv.x - m) * r, (xv.y - m) * r, (xv.z - m) * r, (xv.w - m) * r);
+                    gw[u][i] = make_float4(gv.x * ww.x, gv.y * ww.y, gv.z * ww.z, gv.w * ww.w);
+                    const float4 h = xh[u][i], g = gw[u][i];
+                    s1[u] += (g.x + g.y) + (g.z + g.w);
+                    s2[u] += (g.x * h.x + g.y * h.y) + (g.z * h.z + g.w * h.w);
+                    adw[i].x += gv.x * h.x; adw[i].y += gv.y * h.y; adw[i].z += gv.z * h.z; adw[i].w += gv.w * h.w;
+                    adb[i].x += gv.x; adb[i].y += gv.y; adb[i].z += gv.z; adb[i].w += gv.w;
+                }
             }
         }
-        const float m1 = wave_sum(s1) / d, m2 = wave_sum(s2) / d;
-        float4 *op = reinterpret_cast<float4 *>(dx + row * d);
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < d4) {
-                float4 o;
-                o.x = rs * (gw[i].x - m1 - xh[i].x * m2); o.y = rs * (gw[i].y - m1 - xh[i].y * m2);
-                o.z = rs * (gw[i].z - m1 - xh[i].z * m2); o.w = rs * (gw[i].w - m1 - xh[i].w * m2);
-                if (add) {
-                    const float4 z = reinterpret_cast<const float4 *>(add + row * d)[c];
-                    o.x += z.x; o.y += z.y; o.z += z.z; o.w += z.w;
+        for (int u = 0; u < LN_BWD_ROWS; ++u) {
+            const long long row = row0 + 4 * u;
+            if (row >= r1) continue;
+            const float m1 = wave_sum(s1[u]) / d, m2 = wave_sum(s2[u]) / d;
+            float4 *op = reinterpret_cast<float4 *>(dx + row * d);
+#pragma unroll
+            for (int i = 0; i < LN_MAXV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < d4) {
+                    const float4 h = xh[u][i], g = gw[u][i];
+                    const float r = rs[u];
+                    float4 o;
+                    o.x = r * (g.x - m1 - h.x * m2); o.y = r * (g.y - m1 - h.y * m2);
+                    o.z = r * (g.z - m1 - h.z * m2); o.w = r * (g.w - m1 - h.w * m2);
+                    if (add) {
+                        const float4 z = zv[u][i];
+                        o.x += z.x; o.y += z.y; o.z += z.z; o.w += z.w;
+                    }
+                    op[c] = o;
+                    am = fmaxf(am, fmaxf(fmaxf(lvt_absf(o.x), lvt_absf(o.y)), fmaxf(lvt_absf(o.z), lvt_absf(o.w))));
                 }
-                op[c] = o;
-                am = fmaxf(am, fmaxf(fmaxf(lvt_absf(o.x), lvt_absf(o.y)), fmaxf(lvt_absf(o.z), lvt_absf(o.w))));
             }
         }
     }
