@@ -1813,15 +1813,19 @@ __global__ void lvt_pack_weight_parity_kernel(const float *__restrict__ w, float
 // store per element -- 34-48 us for the 75 MB of partials of a 3x3 256-channel layer; this one is bound by reading them.)
 #define UW_CO 64
 #define UW_CI 4
-__global__ __launch_bounds__(256) void lvt_unpack_wgrad_tiled_kernel(const float *__restrict__ partial, long long stride, int splits,
-                                                                     float *__restrict__ dw, int taps, int Ci, int Co) {
+#ifndef UW_WAVES
+#define UW_WAVES 16                      // (tap, ci) rows in flight per pass: with 4 a CU held 4 waves, each waiting on its own loads
+#endif
+__global__ __launch_bounds__(64 * UW_WAVES) void lvt_unpack_wgrad_tiled_kernel(const float *__restrict__ partial, long long stride,
+                                                                               int splits, float *__restrict__ dw, int taps, int Ci,
+                                                                               int Co) {
     extern __shared__ float tile[];                       // [UW_CO][UW_CI * taps + 1]
     const int ld = UW_CI * taps + 1;
     const int nco = Co / UW_CO;
     const int co0 = (blockIdx.x % nco) * UW_CO, ci0 = (blockIdx.x / nco) * UW_CI;
-    const int lane_co = threadIdx.x & (UW_CO - 1), r0 = threadIdx.x >> 6;          // 4 (tap, ci) rows in flight per pass
+    const int lane_co = threadIdx.x & (UW_CO - 1), r0 = threadIdx.x >> 6;
     const int rows = taps * UW_CI;
-    for (int r = r0; r < rows; r += 4) {
+    for (int r = r0; r < rows; r += UW_WAVES) {
         const int tap = r / UW_CI, cil = r % UW_CI;
         const float *src = partial + ((long long)tap * Ci + ci0 + cil) * Co + co0 + lane_co;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -1834,7 +1838,7 @@ __global__ __launch_bounds__(256) void lvt_unpack_wgrad_tiled_kernel(const float
     }
     __syncthreads();
     const int per_co = UW_CI * taps;                      // contiguous floats of dw per output channel
-    for (int e = threadIdx.x; e < UW_CO * per_co; e += 256) {
+    for (int e = threadIdx.x; e < UW_CO * per_co; e += 64 * UW_WAVES) {
         const int col = e / per_co, off = e % per_co;
         dw[((long long)(co0 + col) * Ci + ci0) * taps + off] = tile[col * ld + off];
     }
@@ -2412,7 +2416,7 @@ static void unpack_plain_wgrad(const float *partial, long long stride, int split
     const int taps = g->Kt * g->Kh * g->Kw;
     const long long total = (long long)taps * g->Ci * g->Co;
     if (unpack_tiled_ok(g, Ci_real, Co_real)) {
-        hipLaunchKernelGGL(lvt_unpack_wgrad_tiled_kernel, dim3((unsigned)((g->Co / UW_CO) * (g->Ci / UW_CI))), dim3(256),
+        hipLaunchKernelGGL(lvt_unpack_wgrad_tiled_kernel, dim3((unsigned)((g->Co / UW_CO) * (g->Ci / UW_CI))), dim3(64 * UW_WAVES),
                            (size_t)UW_CO * (UW_CI * taps + 1) * sizeof(float), s, partial, stride, splits, dw, taps, g->Ci, g->Co);
         return;
     }
@@ -2494,7 +2498,7 @@ extern "C" int lvt_conv3d_bwd_weight(const lvt_conv_geom *g, const float *x, con
     while (L < 64 && L * 4 <= p.splits) L <<= 1;                     // ~4 splits per lane
     if (unpack_tiled_ok(g, Ci_real, Co_real)) {
         // the weight part on the tiled kernel; the generic kernel then only reduces the bias gradient (taps = 0: no elements)
-        hipLaunchKernelGGL(lvt_unpack_wgrad_tiled_kernel, dim3((unsigned)((g->Co / UW_CO) * (g->Ci / UW_CI))), dim3(256),
+        hipLaunchKernelGGL(lvt_unpack_wgrad_tiled_kernel, dim3((unsigned)((g->Co / UW_CO) * (g->Ci / UW_CI))), dim3(64 * UW_WAVES),
                            (size_t)UW_CO * (UW_CI * taps + 1) * sizeof(float), s, (const float *)p.partial, p.partial_stride, p.splits,
                            dw, taps, g->Ci, g->Co);
         if (db)
