@@ -365,12 +365,15 @@ __global__ void lvt_layernorm_fwd_kernel(const float *__restrict__ x, long long 
     }
     if (y_amax) lvt_block_amax_commit(am, y_amax, amax_scratch);
 }
+#ifndef LN_FWD_MAX_BLOCKS
+#define LN_FWD_MAX_BLOCKS 16384
+#endif
 extern "C" int lvt_layernorm_fwd(const float *x, long long rows, int d, float eps, const float *w, const float *b,
                                  float *y, float *mean, float *rstd, float *y_amax, const float *w_amax, const float *b_amax,
                                  void *stream) {
     LVT_REQUIRE(x && w && b && y && rows > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "layernorm_fwd: bad args (d=%d)", d);
     LVT_REQUIRE(!w_amax == !b_amax, "layernorm_fwd: w_amax and b_amax come together");
-    hipLaunchKernelGGL(lvt_layernorm_fwd_kernel<0>, dim3(grid_for(rows, 4, (y_amax && !w_amax) ? 2048 : 16384)), dim3(256), 0,
+    hipLaunchKernelGGL(lvt_layernorm_fwd_kernel<0>, dim3(grid_for(rows, 4, (y_amax && !w_amax) ? 2048 : LN_FWD_MAX_BLOCKS)), dim3(256), 0,
                        (hipStream_t)stream, x, rows, d, eps, w, b, y, mean, rstd, y_amax, w_amax, b_amax, (char *)nullptr);
     LVT_CHECK_LAUNCH("lvt_layernorm_fwd_kernel");
     return LVT_OK;
@@ -381,7 +384,7 @@ extern "C" int lvt_layernorm_fwd_p2(const float *x, long long rows, int d, float
     LVT_REQUIRE(x && w && b && y && yp && rows > 0 && d % 32 == 0 && d <= 256 * LN_MAXV, "layernorm_fwd_p2: bad args (d=%d)", d);
     LVT_REQUIRE(y_amax && w_amax && b_amax, "layernorm_fwd_p2: the image is scaled by the a-priori bound: y_amax, w_amax, b_amax are required");
     LVT_REQUIRE(((uintptr_t)yp & 127) == 0, "layernorm_fwd_p2: the image must be 128-byte aligned");
-    hipLaunchKernelGGL(lvt_layernorm_fwd_kernel<1>, dim3(grid_for(rows, 4, 16384)), dim3(256), 0,
+    hipLaunchKernelGGL(lvt_layernorm_fwd_kernel<1>, dim3(grid_for(rows, 4, LN_FWD_MAX_BLOCKS)), dim3(256), 0,
                        (hipStream_t)stream, x, rows, d, eps, w, b, y, mean, rstd, y_amax, w_amax, b_amax, (char *)yp);
     LVT_CHECK_LAUNCH("lvt_layernorm_fwd_kernel<p2>");
     return LVT_OK;
