@@ -33,7 +33,7 @@ extern "C" {
 #define LVT_ENODEVICE   (-4)   /* no gfx950 device visible                             */
 
 const char *lvt_last_error(void);
-int lvt_version(void);          /* 600 = round 6 (ABI changes are listed in INTEGRATION.md) */
+int lvt_version(void);          /* 610 = round 6 (ABI changes are listed in INTEGRATION.md) */
 /* Device probe: name, CU count, clock (kHz), HBM bytes.  Returns LVT_ENODEVICE without a GPU. */
 int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long long *hbm_bytes);
 
@@ -233,6 +233,20 @@ int lvt_conv3d_pack_weight(const lvt_conv_geom *g, const float *w, int Ci_real, 
  * taps = Kt*Kh*Kw (16 for kinds 2, 3), Ci / Co the padded channel counts of the geometry.                                  */
 typedef struct { const float *w; float *dst; int kind, taps, Ci, Co, Ci_real, Co_real; } lvt_pack_entry;
 int lvt_conv3d_pack_weights_multi(const lvt_pack_entry *entries, int n, void *stream);
+/* Weight tiles as ready LDS images (ABI 610; f16x2 arithmetic, frame-resident kernels only).  A packed weight wp[rows][cols] of any
+ * of the packs above (rows % 32 == 0, cols % 128 == 0) gets, RIGHT BEHIND its rows * cols floats in the same buffer,
+ * lvt_conv3d_weight_image_bytes(rows, cols) bytes holding every 32 x 128 tile as the two fp16 planes of LVT_MATH_F16X2 under the
+ * weight's own scale (`amax`: the device scalar the consuming launch also gets as lvt_amax_io.b), in the order the kernel keeps
+ * them in LDS.  lvt_conv3d_fwd / lvt_conv3d_fwd_parity / lvt_conv3d_bwd_data_phases called with LVT_CONV_WEIGHT_IMAGE in `flags`
+ * then stage the weight tiles by LDS-DMA (global memory -> LDS, no registers, no split arithmetic) instead of splitting the fp32
+ * tile in every workgroup: same bits in LDS, bit-identical results.  The flag is ignored by launches that do not run on the
+ * frame-resident kernels or not in f16x2 mode (the fp32 pack in front of the image stays valid for them).
+ * Replaces nothing of the reference on its own: it is a staging format of the conv2d weights (vidgen/modeling/encoder/resencoder.py:
+ * 25-76, generator/resdecoder.py:25-75).  `entries` is a HOST array; 64 per launch.                                          */
+#define LVT_CONV_WEIGHT_IMAGE (1 << 21)
+typedef struct { const float *wp; int rows, cols; const float *amax; } lvt_weight_image_entry;
+size_t lvt_conv3d_weight_image_bytes(int rows, int cols);     /* 0 when rows % 32 or cols % 128 */
+int lvt_conv3d_weight_images(const lvt_weight_image_entry *entries, int n, void *stream);
 /* Packed weights of the convolution that IS the backward-data pass of a stride-1 convolution: channels swapped, taps
  * reversed: wt[taps-1-tap][co][ci] = w[co][ci][tap].  `lvt_conv3d_fwd` on the swapped geometry (Ci <-> Co, same kernel
  * and padding k-1-p) with these weights computes dx; for 3x3 / pad 1 layers of 16x16 frames that launch runs on the

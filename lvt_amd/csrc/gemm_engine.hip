@@ -55,6 +55,7 @@ struct KParams {
     const float *a_amax2, *b_amax2; // optional second bound per operand (the larger one counts)
     float *c_amax;                  // any arithmetic: when non-NULL, max |C| is folded in (integer atomic max on the bit pattern)
     lvt_conv_geom g;
+    const char *b_img;       // frame-resident convolutions, f16x2: the weight tiles as ready LDS images (lvt_conv3d_weight_images), or NULL
     int Tq, Hq, Wq;          // A_CONVT_K: per-phase output extents
     int jT, jH, jW;          // A_CONVT_K: taps per phase and dimension
     // A_ONEHOT_M: A(m = slot*V + code, k = row) = (idx[b*bstride + off[slot] + pos*pstride] == code),
@@ -1229,8 +1230,16 @@ __global__ __launch_bounds__(NTHREADS, (MATH == 2 ? 2 : LVT_MINWAVES)) void lvt_
 //         (chunk, class): one staging per four tap steps.  Weights packed [class][tap][Cin][Cout]
 //         (lvt_conv3d_pack_weight_parity).
 // MATH: 1 = bf16x3 planes (six MFMAs per block), 2 = f16x2 planes (three, two accumulators; lvt_gemm_kernel above).
-template <int MODE, int MATH>
+// BIMG (f16x2 only, round 6): the weight tile of a step arrives as a ready LDS image -- the two fp16 planes of the 32 x 128 tile in
+//         the hrow<128> order, pads included, 20992 contiguous bytes per tile, made once per pass by lvt_conv3d_weight_images -- and
+//         goes global memory -> LDS by LDS-DMA (global_load_lds_dwordx4, lane-linear on both sides): no registers, no split, no
+//         ds_write, and no longer the work of the first four waves only.  Same bits in LDS as the in-kernel split.
+typedef __attribute__((address_space(3))) void pt_lds_void;
+typedef __attribute__((address_space(1))) const void pt_gl_void;
+#define PT_BIMG_BYTES (2 * HPlane<128>::SIZE * 2)
+template <int MODE, int MATH, int BIMG = 0>
 __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParams p) {
+    static_assert(!BIMG || MATH == 2, "weight images are f16x2 planes");
     constexpr int BM = 256, BN = 128, WM = 4, WN = 2, TM = 2, TN = 2;
     constexpr int NTAPS = MODE == 0 ? 9 : 4;
     constexpr int NP = MATH == 2 ? 2 : 3;
@@ -1344,6 +1353,30 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
         if (MATH == 2) store_split2_block<BN>(dst, bnq * 4, bkk0 * 4, bv, sb);
         else store_split_block<BN>(dst, bnq * 4, bkk0 * 4, bv);
     };
+    // BIMG: unit u (16 bytes) of the tile image -> LDS byte 16 u of the buffer; thread t moves units t, t + 512 and (t < 288) t + 1024
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    constexpr int B_UNITS = PT_BIMG_BYTES / 16;                       // 1312
+    static_assert(PT_BIMG_BYTES == NP * PSB * 2 || !BIMG, "image = the LDS buffer");
+    const char *bimg0 = BIMG ? p.b_img + (long long)(n0 / BN) * PT_BIMG_BYTES + tid * 16 : nullptr;
+    auto b_dma = [&](int step, unsigned short *dst) {
+        const int cc = step / NTAPS, tap = step - cc * NTAPS;
+        const int wrow = MODE == 2 ? ((cc & 3) * NTAPS + tap) * Ci + (cc >> 2) * 32 : (phase * NTAPS + tap) * Ci + cc * 32;
+        const char *src = bimg0 + (long long)(wrow >> 5) * ntn * PT_BIMG_BYTES;
+        char *d = reinterpret_cast<char *>(dst) + wave_s * 1024;
+        __builtin_amdgcn_global_load_lds((pt_gl_void *)src, (pt_lds_void *)d, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((pt_gl_void *)(src + 8192), (pt_lds_void *)(d + 8192), 16, 0, 0);
+        if (tid + 1024 < B_UNITS) __builtin_amdgcn_global_load_lds((pt_gl_void *)(src + 16384), (pt_lds_void *)(d + 16384), 16, 0, 0);
+    };
+    // the LDS-DMA landing fence of gemm_p2.hip (profiles/r06_lds_dma_visibility.txt): vmcnt(0), then ONE LDS read by the issuing wave
+    // from each chunk it requested (lane -> chunk lane % 3, or % 2 for the waves without a third one), before the barrier
+    const int b_nprobe = wave_s * 64 + 1024 < B_UNITS ? 3 : 2;
+    const unsigned b_probe = (unsigned)((lane % b_nprobe) * 8192 + wave_s * 1024 + (lane & 31) * 16);
+    auto b_landed = [&](const unsigned short *dst) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int v = *reinterpret_cast<const volatile int *>(reinterpret_cast<const char *>(dst) + b_probe);
+        (void)v;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
 
     // A operand rows of this lane: MFMA tile i of the wave covers image rows 2*(2*wm + i) + {0, 1}
     int arow[TM];
@@ -1359,16 +1392,20 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
 
     const int nchunks = (Ci / 32) * (MODE == 2 ? 4 : 1), nsteps = nchunks * NTAPS;
     patch_fetch(0);
-    if (bact) b_fetch(0);
+    if (BIMG) b_dma(0, Bh0);
+    else if (bact) b_fetch(0);
     patch_store(Ah);
-    if (bact) b_store(Bh0);
+    if (BIMG) b_landed(Bh0);
+    else if (bact) b_store(Bh0);
     __syncthreads();
 
     for (int step = 0; step < nsteps; ++step) {
         const int cc = step / NTAPS, tap = step - cc * NTAPS;
         const bool has_next = step + 1 < nsteps;
         const bool new_chunk = has_next && tap == NTAPS - 1;
-        if (has_next && bact) b_fetch(step + 1);
+        // (BIMG: the other weight buffer was last read in step - 1, which every wave has left)
+        if (BIMG) { if (has_next) b_dma(step + 1, Bh0 + ((step + 1) & 1) * (NP * PSB)); }
+        else if (has_next && bact) b_fetch(step + 1);
         if (DBLA ? (cc + 1 < nchunks && tap == NTAPS - 2) : new_chunk) patch_fetch(cc + 1);
         const unsigned short *Bh = Bh0 + (step & 1) * (NP * PSB);
         const unsigned short *Acur = Ah + (DBLA ? (cc & 1) * A_IMG : 0);
@@ -1428,12 +1465,13 @@ __global__ __launch_bounds__(PT_THREADS) void lvt_conv_patch_kernel(const KParam
         }
         // the other weight buffer was last read in the previous step, which every wave has left (barrier below)
 #ifndef LVT_PX_NOBSPLIT      // (timing experiment: the weight tile is split + stored for step 0 only)
-        if (has_next && bact) b_store(Bh0 + ((step + 1) & 1) * (NP * PSB));
+        if (!BIMG && has_next && bact) b_store(Bh0 + ((step + 1) & 1) * (NP * PSB));
 #endif
         if (!DBLA && new_chunk) {
             __syncthreads();              // every wave is done with the old patch
             patch_store(Ah);
         }
+        if (BIMG && has_next) b_landed(Bh0 + ((step + 1) & 1) * (NP * PSB));
 #ifdef LVT_PX_HALFBARRIERS   // (timing experiment, wrong results: a barrier every second step)
         if ((step & 1) || new_chunk)
 #endif
@@ -2157,6 +2195,57 @@ extern "C" int lvt_conv3d_pack_weights_multi(const lvt_pack_entry *entries, int 
     return LVT_OK;
 }
 
+// ---- weight tiles as ready LDS images (round 6; lvt_conv_patch_kernel<*, 2, BIMG = 1>) ----------------------------------
+// A packed weight wp[rows][cols] (rows % 32 == 0, cols % 128 == 0; any kind of the packs above) -> for every 32 x 128 tile (kt, nt)
+// the 20992 bytes the kernel keeps in LDS for it: plane hi, plane lo of the f16x2 split under the weight's own scale, rows placed by
+// hrow<128>, pads included (never read).  Same split function as the in-kernel path (store_split2_k), so the bytes in LDS are equal.
+struct WImgTable { const float *wp[64]; char *img[64]; const float *amax[64]; int rows[64], cols[64]; };
+__global__ __launch_bounds__(256) void lvt_weight_images_kernel(const WImgTable t) {
+    const int e = blockIdx.y;
+    const float *__restrict__ wp = t.wp[e];
+    const int rows = t.rows[e], cols = t.cols[e];
+    const int ntn = cols / 128, ntiles = (rows / 32) * ntn;
+    int unscale = 0;
+    const float sb = lvt_f16_scale(t.amax[e], unscale);
+    const int n = threadIdx.x & 127, q0 = threadIdx.x >> 7;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int kt = tile / ntn, nt = tile - kt * ntn;
+        unsigned short *img = reinterpret_cast<unsigned short *>(t.img[e] + (long long)tile * PT_BIMG_BYTES);
+        const float *src = wp + (long long)(kt * 32) * cols + nt * 128 + n;
+#pragma unroll
+        for (int kq = q0; kq < 8; kq += 2) {
+            const float4 v = make_float4(src[(long long)(4 * kq) * cols], src[(long long)(4 * kq + 1) * cols],
+                                         src[(long long)(4 * kq + 2) * cols], src[(long long)(4 * kq + 3) * cols]);
+            store_split2_k<128>(img, n, 4 * kq, v, sb);
+        }
+    }
+}
+extern "C" size_t lvt_conv3d_weight_image_bytes(int rows, int cols) {
+    if (rows <= 0 || cols <= 0 || rows % 32 || cols % 128) return 0;
+    return (size_t)(rows / 32) * (cols / 128) * PT_BIMG_BYTES;
+}
+extern "C" int lvt_conv3d_weight_images(const lvt_weight_image_entry *entries, int n, void *stream) {
+    LVT_REQUIRE(entries && n > 0, "weight_images: bad args");
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = n - base < 64 ? n - base : 64;
+        WImgTable t;
+        int most = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const lvt_weight_image_entry &e = entries[base + i];
+            LVT_REQUIRE(e.wp && e.amax && e.rows > 0 && e.cols > 0 && e.rows % 32 == 0 && e.cols % 128 == 0,
+                        "weight_images: entry %d: rows %% 32 / cols %% 128 / pointers", base + i);
+            // the image sits right behind the packed weight (lvt_conv3d_weight_image_bytes more bytes in the same buffer)
+            t.wp[i] = e.wp; t.img[i] = (char *)(e.wp + (size_t)e.rows * e.cols); t.amax[i] = e.amax; t.rows[i] = e.rows; t.cols[i] = e.cols;
+            LVT_REQUIRE(lvt_aligned16(t.img[i]), "weight_images: entry %d: the packed weight must be 16-byte aligned", base + i);
+            const int tiles = (e.rows / 32) * (e.cols / 128);
+            if (tiles > most) most = tiles;
+        }
+        hipLaunchKernelGGL(lvt_weight_images_kernel, dim3((unsigned)(most < 256 ? most : 256), (unsigned)cnt), dim3(256), 0, (hipStream_t)stream, t);
+        LVT_CHECK_LAUNCH("lvt_weight_images_kernel");
+    }
+    return LVT_OK;
+}
+
 static int check_geom(const lvt_conv_geom *g, const char *who) {
     LVT_REQUIRE(g, "%s: null geometry", who);
     LVT_REQUIRE(g->N > 0 && g->Ti > 0 && g->Hi > 0 && g->Wi > 0 && g->To > 0 && g->Ho > 0 && g->Wo > 0,
@@ -2226,6 +2315,8 @@ extern "C" int lvt_conv3d_fwd_parity(const lvt_conv_geom *g, const float *x, con
                                      const float *res, const float *mask, float *y, int flags, const lvt_amax_io *ax,
                                      void *stream) {
     int rc = check_geom(g, "conv3d_fwd_parity"); if (rc) return rc;
+    const bool wimg = (flags & LVT_CONV_WEIGHT_IMAGE) != 0;
+    flags &= ~LVT_CONV_WEIGHT_IMAGE;
     LVT_REQUIRE(x && wq && y, "conv3d_fwd_parity: null pointer");
     LVT_REQUIRE(conv2x_eligible(g, flags), "conv3d_fwd_parity: geometry not served (see lvt_conv3d_fwd_uses_parity_kernel)");
     LVT_REQUIRE(!(flags & LVT_EPI_BIAS) || bias, "conv3d_fwd_parity: BIAS without bias");
@@ -2240,7 +2331,11 @@ extern "C" int lvt_conv3d_fwd_parity(const lvt_conv_geom *g, const float *x, con
     p.alpha = 1.f; p.flags = flags; p.bias = bias; p.res = res; p.ldr = g->Co; p.mask = mask; p.ldm = g->Co;
     p.splits = 1; p.vec_epi = 1; p.g = *g;
     LVT_REQUIRE_AMAX(flags, ax, "conv3d_fwd_parity"); set_amax(p, ax);
-    if (math_of(flags) == 2)
+    if (math_of(flags) == 2 && wimg) {
+        p.b_img = (const char *)(wq + (size_t)p.K * p.N);
+        hipLaunchKernelGGL((lvt_conv_patch_kernel<2, 2, 1>), dim3((unsigned)(g->N * (g->Co / 128))), dim3(PT_THREADS), 0,
+                           (hipStream_t)stream, p);
+    } else if (math_of(flags) == 2)
         hipLaunchKernelGGL((lvt_conv_patch_kernel<2, 2>), dim3((unsigned)(g->N * (g->Co / 128))), dim3(PT_THREADS), 0,
                            (hipStream_t)stream, p);
     else
@@ -2258,6 +2353,8 @@ int lvt_conv4s2_img_launch(const lvt_conv_geom *g, const float *x, const float *
 extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const float *wp, const float *bias,
                               const float *res, const float *mask, float *y, int flags, const lvt_amax_io *ax, void *stream) {
     int rc = check_geom(g, "conv3d_fwd"); if (rc) return rc;
+    const bool wimg = (flags & LVT_CONV_WEIGHT_IMAGE) != 0;       // (only the frame-resident f16x2 launch reads the image)
+    flags &= ~LVT_CONV_WEIGHT_IMAGE;
     LVT_REQUIRE(x && wp && y, "conv3d_fwd: null pointer");
     LVT_REQUIRE(!(flags & LVT_EPI_BIAS) || bias, "conv3d_fwd: BIAS without bias");
     LVT_REQUIRE(!(flags & LVT_EPI_RESIDUAL) || res, "conv3d_fwd: RESIDUAL without res");
@@ -2283,7 +2380,11 @@ extern "C" int lvt_conv3d_fwd(const lvt_conv_geom *g, const float *x, const floa
         if (flags & LVT_EPI_MASK) ok = ok && al16(mask);
         if (ok) {
             p.vec_epi = 1;
-            if (math_of(flags) == 2)
+            if (math_of(flags) == 2 && wimg) {
+                p.b_img = (const char *)(wp + (size_t)p.K * p.N);
+                hipLaunchKernelGGL((lvt_conv_patch_kernel<0, 2, 1>), dim3((unsigned)(g->N * (g->Co / 128))), dim3(PT_THREADS), 0,
+                                   (hipStream_t)stream, p);
+            } else if (math_of(flags) == 2)
                 hipLaunchKernelGGL((lvt_conv_patch_kernel<0, 2>), dim3((unsigned)(g->N * (g->Co / 128))), dim3(PT_THREADS), 0,
                                    (hipStream_t)stream, p);
             else
@@ -2335,6 +2436,8 @@ extern "C" int lvt_conv3d_bwd_data_phases(const lvt_conv_geom *g, const float *d
                                           const float *res, const float *mask, float *dx, int flags, const lvt_amax_io *ax,
                                           void *stream) {
     int rc = check_geom(g, "conv3d_bwd_data_phases"); if (rc) return rc;
+    const bool wimg = (flags & LVT_CONV_WEIGHT_IMAGE) != 0;
+    flags &= ~LVT_CONV_WEIGHT_IMAGE;
     LVT_REQUIRE(dy && wph && dx, "conv3d_bwd_data_phases: null pointer");
     LVT_REQUIRE(convt2x_eligible(g, flags), "conv3d_bwd_data_phases: geometry not served (see lvt_conv3d_bwd_data_uses_phase_kernel)");
     LVT_REQUIRE(!(flags & LVT_EPI_BIAS) || bias, "conv3d_bwd_data_phases: BIAS without bias");
@@ -2350,7 +2453,11 @@ extern "C" int lvt_conv3d_bwd_data_phases(const lvt_conv_geom *g, const float *d
     p.splits = 1; p.vec_epi = 1;
     p.g = *g; p.g.Ci = g->Co;                                   // the kernel's input channel count
     LVT_REQUIRE_AMAX(flags, ax, "conv3d_bwd_data_phases"); set_amax(p, ax);
-    if (math_of(flags) == 2)
+    if (math_of(flags) == 2 && wimg) {
+        p.b_img = (const char *)(wph + (size_t)16 * g->Co * g->Ci);
+        hipLaunchKernelGGL((lvt_conv_patch_kernel<1, 2, 1>), dim3((unsigned)(g->N * 4 * (g->Ci / 128))), dim3(PT_THREADS), 0,
+                           (hipStream_t)stream, p);
+    } else if (math_of(flags) == 2)
         hipLaunchKernelGGL((lvt_conv_patch_kernel<1, 2>), dim3((unsigned)(g->N * 4 * (g->Ci / 128))), dim3(PT_THREADS), 0,
                            (hipStream_t)stream, p);
     else

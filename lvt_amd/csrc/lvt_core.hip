@@ -12,7 +12,7 @@ void lvt_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *lvt_last_error(void) { return g_err; }
-extern "C" int lvt_version(void) { return 600; }
+extern "C" int lvt_version(void) { return 610; }
 
 extern "C" int lvt_device_info(char *name, int name_len, int *cus, int *clock_khz, long long *hbm_bytes) {
     int n = 0;

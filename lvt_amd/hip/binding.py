@@ -14,11 +14,12 @@ _LIB_PATH = os.environ.get("LVT_HIP_LIB") or os.path.join(os.path.dirname(_HERE)
 
 EPI_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_TANH, EPI_MASK, EPI_ACCUM, EPI_PLANES = 1, 2, 4, 8, 16, 32, 64
 CAUSAL_KMAX, CAUSAL_KMIN, CAUSAL_TILE = 1 << 8, 1 << 9, 1 << 10      # causal attention products (include/lvt_hip.h)
-ABI_VERSION = 600           # lvt_version() of the library this module binds (argument lists below)
+ABI_VERSION = 610           # lvt_version() of the library this module binds (argument lists below)
 MATH_F32 = 1 << 16          # per-call arithmetic selectors of the engine entry points (include/lvt_hip.h)
 MATH_F16X2 = 1 << 18
 ONEHOT_DENSE = 1 << 19
 WGRAD_DB_OF_X = 1 << 20
+CONV_WEIGHT_IMAGE = 1 << 21   # the packed weight carries its f16x2 tile images behind it (lvt_conv3d_weight_images)
 
 
 class LvtError(RuntimeError):
@@ -75,6 +76,10 @@ class PackEntry(C.Structure):
                 ("Ci_real", C.c_int), ("Co_real", C.c_int)]
 
 
+class WeightImageEntry(C.Structure):
+    _fields_ = [("wp", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("amax", C.c_void_p)]
+
+
 class AmaxIO(C.Structure):
     """lvt_amax_io: device scalars with max |.| of the two operands (f16x2 mode) and of the result (optional)."""
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p)]
@@ -123,6 +128,8 @@ def _declare(lib):
         "lvt_amax": (ci, [vp, cll, vp, vp]),
         "lvt_amax_multi": (ci, [P(AmaxEntry), ci, vp]),
         "lvt_conv3d_pack_weights_multi": (ci, [P(PackEntry), ci, vp]),
+        "lvt_conv3d_weight_image_bytes": (sz, [ci, ci]),
+        "lvt_conv3d_weight_images": (ci, [P(WeightImageEntry), ci, vp]),
         "lvt_amax_merge": (ci, [vp, vp, vp, vp]),
         "lvt_conv3d_fwd_parity": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, P(AmaxIO), vp]),
         "lvt_conv3d_fwd": (ci, [P(ConvGeom), vp, vp, vp, vp, vp, vp, ci, P(AmaxIO), vp]),

@@ -246,35 +246,57 @@ class PackBatch:
 
     SINGLE = bool(os.environ.get("LVT_NO_PACK_BATCH"))        # A/B switch: one launch per pack, as before round 4
 
-    def __init__(self):
-        self.entries, self.keep = [], []
+    # f16x2: the packs that a frame-resident launch will read also get their tiles as ready LDS images, right behind the fp32
+    # pack in the same buffer (lvt_conv3d_weight_images, one more launch per stack); the conv wrappers below then pass
+    # CONV_WEIGHT_IMAGE and the kernel stages the weight tiles by LDS-DMA.  LVT_NO_WEIGHT_IMAGES=1: the in-kernel split (A/B switch).
+    IMAGES = not os.environ.get("LVT_NO_WEIGHT_IMAGES")
 
-    def _add(self, kind, g, w, Ci_real, Co_real, shape, taps):
+    def __init__(self):
+        self.entries, self.keep, self.images = [], [], []
+
+    def _add(self, kind, g, w, Ci_real, Co_real, shape, taps, image=False):
         if self.SINGLE:
             return (pack_weight, pack_weight_t, pack_weight_phases, pack_weight_parity)[kind](g, w, Ci_real, Co_real)
         L.require(w)
-        dst = torch.empty(*shape, dtype=torch.float32, device=w.device)
+        n = 1
+        for d in shape:
+            n *= d
+        cols = shape[-1]
+        rows = n // cols
+        extra = L.lib().lvt_conv3d_weight_image_bytes(rows, cols) if (image and self.IMAGES and L.f16x2()) else 0
+        if extra:
+            buf = torch.empty(n + extra // 4, dtype=torch.float32, device=w.device)
+            dst = buf[:n].view(*shape)
+        else:
+            dst = torch.empty(*shape, dtype=torch.float32, device=w.device)
         e = L.PackEntry()
         e.w, e.dst, e.kind, e.taps, e.Ci, e.Co, e.Ci_real, e.Co_real = w.data_ptr(), dst.data_ptr(), kind, taps, g.Ci, g.Co, Ci_real, Co_real
         self.entries.append(e)
         self.keep.append(w)
-        return _same_amax(dst, w)
+        _same_amax(dst, w)
+        if extra:
+            ie = L.WeightImageEntry()
+            ie.wp, ie.rows, ie.cols, ie.amax = dst.data_ptr(), rows, cols, L.amax_of(dst).data_ptr()
+            self.images.append(ie)
+            self.keep.append(dst)
+            dst._lvt_wimg = True
+        return dst
 
     def plain(self, g, w, Ci_real, Co_real):
         taps = g.Kt * g.Kh * g.Kw
-        return self._add(0, g, w, Ci_real, Co_real, (taps, g.Ci, g.Co), taps)
+        return self._add(0, g, w, Ci_real, Co_real, (taps, g.Ci, g.Co), taps, image=uses_patch_kernel(g))
 
     def t(self, g, w, Ci_real, Co_real):
         if (g.st, g.sh, g.sw) != (1, 1, 1):
             raise L.LvtError("pack_weight_t: stride-1 convolutions only")
         taps = g.Kt * g.Kh * g.Kw
-        return self._add(1, g, w, Ci_real, Co_real, (taps, g.Co, g.Ci), taps)
+        return self._add(1, g, w, Ci_real, Co_real, (taps, g.Co, g.Ci), taps, image=True)      # (asked for by bwd_data_as_conv)
 
     def phases(self, g, w, Ci_real, Co_real):
-        return self._add(2, g, w, Ci_real, Co_real, (4, 4, g.Co, g.Ci), self._taps16(g))
+        return self._add(2, g, w, Ci_real, Co_real, (4, 4, g.Co, g.Ci), self._taps16(g), image=True)
 
     def parity(self, g, w, Ci_real, Co_real):
-        return self._add(3, g, w, Ci_real, Co_real, (4, 4, g.Ci, g.Co), self._taps16(g))
+        return self._add(3, g, w, Ci_real, Co_real, (4, 4, g.Ci, g.Co), self._taps16(g), image=True)
 
     @staticmethod
     def _taps16(g):
@@ -286,7 +308,19 @@ class PackBatch:
         if self.entries:
             arr = (L.PackEntry * len(self.entries))(*self.entries)
             L.check(L.lib().lvt_conv3d_pack_weights_multi(arr, len(self.entries), L.stream_ptr()), "lvt_conv3d_pack_weights_multi")
-        self.entries, self.keep = [], []
+        if self.images:
+            arr = (L.WeightImageEntry * len(self.images))(*self.images)
+            L.check(L.lib().lvt_conv3d_weight_images(arr, len(self.images), L.stream_ptr()), "lvt_conv3d_weight_images")
+        self.entries, self.keep, self.images = [], [], []
+
+
+def uses_patch_kernel(g):
+    """True when the forward pass of `g` runs on the frame-resident kernel (3x3 / pad 1 on 16x16 frames)."""
+    return bool(L.lib().lvt_conv3d_uses_patch_kernel(C.byref(g), L.math_flag()))
+
+
+def _wimg(wp):
+    return L.CONV_WEIGHT_IMAGE if getattr(wp, "_lvt_wimg", False) else 0
 
 
 def swapped_geom(g):
@@ -330,10 +364,10 @@ def conv_fwd(g, x, wp, bias=None, res=None, mask=None, flags=0, timer_key="conv_
     t0 = L.TIMER.begin() if L.TIMER is not None else None
     if wq is not None:
         L.check(L.lib().lvt_conv3d_fwd_parity(C.byref(g), L.ptr(x), L.ptr(wq), L.ptr(bias), L.ptr(res), L.ptr(mask), L.ptr(y),
-                                              flags | L.math_flag(), L.io_ref(io), L.stream_ptr()), "lvt_conv3d_fwd_parity")
+                                              flags | L.math_flag() | _wimg(wq), L.io_ref(io), L.stream_ptr()), "lvt_conv3d_fwd_parity")
     else:
         L.check(L.lib().lvt_conv3d_fwd(C.byref(g), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(mask), L.ptr(y),
-                                       flags | L.math_flag(), L.io_ref(io), L.stream_ptr()), "lvt_conv3d_fwd")
+                                       flags | L.math_flag() | _wimg(wp), L.io_ref(io), L.stream_ptr()), "lvt_conv3d_fwd")
     if t0 is not None:
         L.TIMER.end(timer_key, conv_flops(g), t0)
     return y
@@ -367,7 +401,7 @@ def conv_bwd_data(g, dy, wp, bias=None, res=None, mask=None, flags=0, wt=None, w
         io = L.amax_io(dy, wph, dx)
         t0 = L.TIMER.begin() if L.TIMER is not None else None
         L.check(L.lib().lvt_conv3d_bwd_data_phases(C.byref(g), L.ptr(dy), L.ptr(wph), L.ptr(bias), L.ptr(res), L.ptr(mask),
-                                                   L.ptr(dx), flags | L.math_flag(), L.io_ref(io), L.stream_ptr()),
+                                                   L.ptr(dx), flags | L.math_flag() | _wimg(wph), L.io_ref(io), L.stream_ptr()),
                 "lvt_conv3d_bwd_data_phases")
         if t0 is not None:
             L.TIMER.end("conv_bwd_data", conv_flops(g), t0)
