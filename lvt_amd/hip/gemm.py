@@ -64,14 +64,27 @@ class P2Image:
         self.data, self.amax = data, amax
 
 
-def p2_supported(force=None):
-    """The plane-fed GEMM path exists for the f16x2 arithmetic only, and the MODELS use it on request (LVT_P2=1, or
-    vt_attention.P2_IMAGES = True): bit-identical and 13 % faster per launch on the q/k/v product in isolation, but in the DSFVT
-    train step the second LayerNorm output, the image launch and the host work cancel the gain (same-box A/B, round 6:
-    28.98 ms without, 29.06-29.21 ms with -- DESIGN.md section 3.5)."""
+def p2_mode(force=None):
+    """How the MODELS use the plane-fed GEMM (f16x2 arithmetic only; bit-identical to the engine in every mode):
+      "off"  (default; LVT_P2 unset or 0; force=False; any other arithmetic);
+      "qkv"  (LVT_P2=qkv): the packed q/k/v weights of every attention layer get a P2 image per pass and the q/k/v projection runs
+             as lvt_gemm_p2_f32 with its fp32 A through registers and the weight tile by LDS-DMA.  Alone, on random operands, that
+             launch goes 218 -> 198 us and the seven other data products of a layer +-1 us (tools/profile/p2_bonly.py); in the
+             step the same launch takes 211 us against the engine's 207 and the free-running step 27.71-27.78 ms against 27.57-27.62;
+      "full" (LVT_P2=1, or force=True): also the LayerNorm outputs and the first FFN weight as images, both operands of those two
+             products by LDS-DMA: 27.52-27.63 ms -- nothing."""
     if not L.f16x2():
-        return False
-    return bool(os.environ.get("LVT_P2")) if force is None else bool(force)
+        return "off"
+    if force is not None:
+        return "full" if force else "off"
+    env = os.environ.get("LVT_P2", "")
+    if env == "qkv":
+        return "qkv"
+    return "full" if env not in ("", "0") else "off"
+
+
+def p2_supported(force=None):
+    return p2_mode(force) == "full"
 
 
 def p2_pack(specs):

@@ -104,16 +104,17 @@ def _splits(tiles, k):
     return max(1, min(s, k // 512 if k >= 1024 else 1))
 
 
-P2_IMAGES = None     # None: on request (LVT_P2=1, hip/gemm.py p2_supported); True / False: tests force either side
+P2_IMAGES = None     # None: hip/gemm.py p2_mode() (default "off"; LVT_P2=1 "full", LVT_P2=qkv); True / False: tests force full / off
 
 
 def prefetch_p2_images(module):
-    """Round 6: the P2 images (csrc/gemm_p2.hip) of the weights that meet a LayerNorm output in a forward product -- the packed
-    q/k/v weights as (3 na da, d) rows and the first FFN weight -- for every attention layer of `module`, in ONE launch per 64
-    matrices at the start of a pass (the weights change once per optimizer step).  Those two products then run with both
-    operands staged by LDS-DMA (no split, no registers): bit-identical results, -13 % on the q/k/v product alone, nothing in
-    the step (opt-in: LVT_P2=1).  The images ride on the layers (`_p2`) and are dropped in the other arithmetic modes."""
-    use = G.p2_supported(P2_IMAGES)
+    """Round 6: P2 images (csrc/gemm_p2.hip) of the weights of every attention layer of `module`, in ONE launch per 64 matrices at
+    the start of a pass (the weights change once per optimizer step): the packed q/k/v weights as (3 na da, d) rows -- the q/k/v
+    projection then stages its weight tiles by LDS-DMA -- and, in the "full" mode, the first FFN weight too (both operands of the
+    two products that read a LayerNorm output by LDS-DMA).  Bit-identical, nothing in the step: opt-in (LVT_P2=qkv / LVT_P2=1).  The images ride on the layers (`_p2`) and are
+    dropped in the other arithmetic modes."""
+    mode = G.p2_mode(P2_IMAGES)
+    use, full = mode != "off", mode == "full"
     specs, layers = [], []
     for m in module.modules():
         if not isinstance(m, BlockLocalAttention):
@@ -128,12 +129,16 @@ def prefetch_p2_images(module):
         if buf is None or buf[0].device != wqkv.device or buf[0].shape != (3 * na * da, d) or buf[1].shape != f1.weight.shape:
             buf = m._p2_buf = (torch.empty(3 * na * da, d, dtype=torch.float32, device=wqkv.device),
                                torch.empty_like(f1.weight, dtype=torch.float32))
-        aq, a1 = L.amax_of(wqkv), L.amax_of(f1.weight)
+        aq = L.amax_of(wqkv)
         # (3 na) blocks of (d, da) -> image rows (p, h, j), k = d: one batched entry (building 24 views per layer cost the host
         # 1.7 ms per pass, more than the launches gain)
         specs.append((wqkv.view(3 * na * d, da)[:d], True, buf[0][:da], aq, 3 * na, d * da, da * d))
-        specs.append((f1.weight.detach(), False, buf[1], a1))
-        layers.append((m, G.P2Image(buf[0], aq), G.P2Image(buf[1], a1)))
+        i1 = None
+        if full:
+            a1 = L.amax_of(f1.weight)
+            specs.append((f1.weight.detach(), False, buf[1], a1))
+            i1 = G.P2Image(buf[1], a1)
+        layers.append((m, G.P2Image(buf[0], aq), i1))
     if specs:
         G.p2_pack(specs)
     for m, iq, i1 in layers:
@@ -230,7 +235,8 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         # that read a LayerNorm output then take BOTH operands as P2 images (the LayerNorm writes its output a second time, as an
         # image under its a-priori bound) and stage them by LDS-DMA -- same bits as the engine's in-kernel split
         p2 = p2 if (p2 is not None and not planes and L.f16x2()) else None
-        if p2 is not None:
+        p2_full = p2 is not None and p2[1] is not None      # else: the q/k/v weight image only, A stays fp32 (hip/gemm.py p2_mode)
+        if p2_full:
             xn, xn_img, mean1, rstd1 = ew.layernorm_fwd_p2(x, ln_w, ln_b)
         else:
             xn, mean1, rstd1 = ew.layernorm_fwd(x, ln_w, ln_b)
@@ -245,9 +251,12 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
             # q, k, v of all heads in ONE launch: 3 x na batches of (M x da x d) against the packed weights, C = (3, M, hd)
             qkv = torch.empty(3, M, hd, dtype=torch.float32, device=dev)
             if p2 is not None:
-                G.gemm_p2(G.P2Image(xn_img, L.amax_of(xn)), p2[0], qkv, M, da, d, lda=d, ldb=d, ldc=hd, batch_outer=3,
-                          batch_inner=na, sB=(na * da * d, da * d), sC=(M * hd, da))
-                del xn_img
+                # (the image rows are (projection, head, j): a projection's heads are ONE (hd, d) matrix -- three batches of N = hd,
+                # whose n-tiles share their A panel in one L2, instead of 3 na batches of N = da)
+                G.gemm_p2(G.P2Image(xn_img, L.amax_of(xn)) if p2_full else xn, p2[0], qkv, M, hd, d, lda=d, ldb=d, ldc=hd,
+                          batch_outer=3, batch_inner=1, sB=(hd * d, 0), sC=(M * hd, 0))
+                if p2_full:
+                    del xn_img
             else:
                 G.gemm(xn, wqkv, qkv, M, da, d, ta=0, tb=1, lda=d, ldb=da, ldc=hd, batch_outer=3, batch_inner=na,
                        sB=(na * d * da, d * da), sC=(M * hd, da))
@@ -269,7 +278,7 @@ class _BlockLocalAttentionFn(torch.autograd.Function):
         y1 = torch.empty(M, d, dtype=torch.float32, device=dev)
         G.gemm(o, proj_w, y1, M, d, hd, flags=L.EPI_RESIDUAL, res=x)
         h1 = torch.empty(M, f1w.shape[0], dtype=torch.float32, device=dev)
-        if p2 is not None:
+        if p2_full:
             fn, fn_img, mean2, rstd2 = ew.layernorm_fwd_p2(y1, f0w, f0b)
             G.gemm_p2(G.P2Image(fn_img, L.amax_of(fn)), p2[1], h1, M, f1w.shape[0], d, flags=L.EPI_BIAS | L.EPI_RELU, bias=f1b)
             del fn_img

@@ -4,6 +4,8 @@ A P2 image holds exactly what lvt_gemm_f32 stages in LDS in LVT_MATH_F16X2 mode,
 in the same order into the same accumulators, so the bar is BIT-IDENTITY with lvt_gemm_f32 on the fp32 matrices the images were
 made from (torch.equal) -- which in turn is held to 2e-5 of torch fp32 by tests/test_gpu_engine.py.  The images themselves are
 checked byte for byte against a torch restatement of the split (hi = RN16(x s), lo = RN16(2^11 (x s - hi)))."""
+import os
+
 import pytest
 import torch
 
@@ -207,8 +209,9 @@ def test_gemm_p2_image_a_many_workgroups_fresh_outputs(M):
 
 
 def test_dsfvt_loss_with_p2_images_is_bit_identical():
-    """The model path on request (vt_attention.P2_IMAGES = True: LayerNorm outputs + q/k/v and first-FFN weights as images, both
-    operands of those products by LDS-DMA): the DSFVT training loss and every gradient equal the default path's bit for bit, on
+    """The model paths with P2 images -- LVT_P2=qkv (q/k/v weight image, fp32 A) and the full one (vt_attention.P2_IMAGES =
+    True: LayerNorm outputs + q/k/v and first-FFN weights as images, both operands of those products by LDS-DMA): the DSFVT
+    training loss and every gradient equal the engine-only path's (P2_IMAGES = False) bit for bit, on
     fresh models from the same seed (the shape that caught the LDS-DMA visibility hole: 8 slices, 24 batches per q/k/v launch)."""
     import lvt_amd.modeling.autoregressive.vt_attention as VA
     from lvt_amd.data.dataset_mapper import prepare_slices_batch
@@ -217,7 +220,9 @@ def test_dsfvt_loss_with_p2_images_is_bit_identical():
     from util_models import dsfvt_cfg
 
     def run(p2):
-        VA.P2_IMAGES = p2
+        VA.P2_IMAGES = None if p2 == "qkv" else p2
+        if p2 == "qkv":
+            os.environ["LVT_P2"] = "qkv"
         try:
             cfg = dsfvt_cfg("cuda:0")
             cfg.OUTPUT_DIR = "/tmp/lvt_test_out"
@@ -236,12 +241,15 @@ def test_dsfvt_loss_with_p2_images_is_bit_identical():
             return float(loss.detach()), {n: p.grad.clone() for n, p in model.model.named_parameters() if p.grad is not None}, used
         finally:
             VA.P2_IMAGES = None
+            os.environ.pop("LVT_P2", None)
     l0, g0, u0 = run(False)
-    junk = torch.full((1 << 26,), float("nan"), device="cuda:0")      # dirty the allocator's free blocks between the runs
-    del junk
-    l1, g1, u1 = run(True)
-    assert u1 and not u0
-    assert l0 == l1
-    assert g0.keys() == g1.keys()
-    for n in g0:
-        assert torch.equal(g0[n], g1[n]), n
+    assert not u0
+    for mode in (True, "qkv"):     # "full" (both operands of the LayerNorm-fed products), and the q/k/v weight image only
+        junk = torch.full((1 << 26,), float("nan"), device="cuda:0")      # dirty the allocator's free blocks between the runs
+        del junk
+        l1, g1, u1 = run(mode)
+        assert u1, mode
+        assert l0 == l1
+        assert g0.keys() == g1.keys()
+        for n in g0:
+            assert torch.equal(g0[n], g1[n]), (mode, n)
