@@ -376,16 +376,26 @@ def prefetch_module_weights(module):
     contribute their packed (3, na, d, da) q/k/v buffer, which is what the launches address."""
     if _math_mode != "f16x2":
         return
+    # the walk over the module tree is planned once per model (0.5 ms of generators per pass otherwise); the plan holds modules and
+    # parameter NAMES, so a parameter that is replaced later is still the one that gets scanned
+    plan = module.__dict__.get("_lvt_prefetch_plan")
+    if plan is None:
+        plan = []
+        for m in module.modules():
+            packed = getattr(m, "packed_qkv", None)
+            skip = ("w_q", "w_k", "w_v") if packed is not None else ()
+            names = [name for name, p in m.named_parameters(recurse=False)
+                     if name not in skip and (p.dim() >= 2 or isinstance(m, torch.nn.LayerNorm))]
+            if packed is not None or names:      # (LayerNorm weight / bias: the a-priori bound of its output, lvt_layernorm_fwd)
+                plan.append((m, packed is not None, names))
+        module.__dict__["_lvt_prefetch_plan"] = plan
     todo = []
-    for m in module.modules():
-        packed = getattr(m, "packed_qkv", None)
-        skip = ()
-        if packed is not None:
-            todo.append(packed())
-            skip = ("w_q", "w_k", "w_v")
-        for name, p in m.named_parameters(recurse=False):
-            if name not in skip and (p.dim() >= 2 or isinstance(m, torch.nn.LayerNorm)):
-                todo.append(p)          # (LayerNorm weight / bias: the a-priori bound of its output, lvt_layernorm_fwd)
+    for m, has_packed, names in plan:
+        if has_packed:
+            todo.append(m.packed_qkv())
+        params = m._parameters
+        for name in names:
+            todo.append(params[name])
     amax_prefetch(todo)
 
 
@@ -441,7 +451,15 @@ def check(rc, what=""):
         raise LvtError("%s failed (rc=%d): %s" % (what, rc, lib().lvt_last_error().decode()))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream object through
+    several Python layers (9 us per call, 1.3 + 3.6 ms of host time per DSFVT train step at one call per launch:
+    tools/profile/host_profile.py); the raw accessor answers the same question in well under a microsecond."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -26,6 +26,6 @@ def run_nosync(n=20):
     for i in range(n): leg.step(i)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 for i in range(5): leg.step(i)
-for us in (0, 250, 500, 1000, 2000):
+for us in (0, 1000, 2000, 4000, 6000, 8000, 12000):
     delay[0] = us
     print("busy-wait %4d us in _begin_pass: step %.3f ms (synchronised per step), %.3f ms (free-running)" % (us, run(), run_nosync()))
