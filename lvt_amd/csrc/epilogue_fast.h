@@ -73,6 +73,39 @@ __device__ __forceinline__ float lvt_epi_fast_wave(const LvtEpi &e, lvt_f32x16 (
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (f_bias && colok) bias4 = *reinterpret_cast<const float4 *>(e.bias + col);
     float am = 0.f;
+    // residual / mask rows of BOTH 32-row rounds are requested up front: requested per round (round 6, first form) a cold operand --
+    // the saved hidden activation that masks the FFN data gradient comes from HBM -- exposed its latency once per round (the
+    // 16384 x 512 x 512 product with a mask 51 us against 37 without).  LVT_EPI_LATE_LOADS=1: the per-round form (A/B switch).
+#ifndef LVT_EPI_LATE_LOADS
+#define LVT_EPI_LATE_LOADS 0
+#endif
+    long long orow_all[TM][8];
+    float4 rv_all[TM][8], mv_all[TM][8];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row0 = m_w + i * 32 + r0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) orow_all[i][u] = rm(row0 + 4 * u);
+    }
+    auto request = [&](int i) {
+        const int row0 = m_w + i * 32 + r0;
+        if (f_res) {
+            const float *rp = e.res + e.coff + col;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                rv_all[i][u] = (colok && row0 + 4 * u < e.M) ? *reinterpret_cast<const float4 *>(rp + orow_all[i][u] * e.ldr) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (f_mask) {
+            const float *mp = e.mask + e.coff + col;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                mv_all[i][u] = (colok && row0 + 4 * u < e.M) ? *reinterpret_cast<const float4 *>(mp + orow_all[i][u] * e.ldm) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (!LVT_EPI_LATE_LOADS) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) request(i);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -80,22 +113,10 @@ __device__ __forceinline__ float lvt_epi_fast_wave(const LvtEpi &e, lvt_f32x16 (
 #pragma unroll
             for (int r = 0; r < 16; ++r) wave_tile[((r & 3) + 8 * (r >> 2) + 4 * half) * SW + 32 * j + l31] = acc[i][j][r];
         const int row0 = m_w + i * 32 + r0;                                  // rows row0 + 4 u, u = 0 .. 7
-        long long orow[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) orow[u] = rm(row0 + 4 * u);
-        float4 rv[8], mv[8];
-        if (f_res) {
-            const float *rp = e.res + e.coff + col;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                rv[u] = (colok && row0 + 4 * u < e.M) ? *reinterpret_cast<const float4 *>(rp + orow[u] * e.ldr) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (f_mask) {
-            const float *mp = e.mask + e.coff + col;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                mv[u] = (colok && row0 + 4 * u < e.M) ? *reinterpret_cast<const float4 *>(mp + orow[u] * e.ldm) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        if (LVT_EPI_LATE_LOADS) request(i);
+        const long long (&orow)[8] = orow_all[i];
+        const float4 (&rv)[8] = rv_all[i];
+        const float4 (&mv)[8] = mv_all[i];
         float *cp = e.C + e.coff + col;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
