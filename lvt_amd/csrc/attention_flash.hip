@@ -197,13 +197,15 @@ __device__ __forceinline__ void fa_park8(const G8 &g, unsigned short *slot, floa
 // The wave's stationary operand straight from global memory in B-fragment layout: lane (tile column c16 = row `row` of the
 // operand, k block kg) holds k = 32 s + 8 kg .. + 7 of each of the four k steps; the row's scale from the 32 values of the lane
 // and the three other lanes of the column.  inv = 2^(e - 14).
-__device__ __forceinline__ void fa_load_bfrags(const float *__restrict__ row, int kg, f16x8 (&fr)[4][2], float &inv) {
-    float4 v[8];
+// (two pieces, so that a prologue can request the row together with its other operands and split it when they are all on their way)
+__device__ __forceinline__ void fa_bfrags_request(const float *__restrict__ row, int kg, float4 (&v)[8]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         v[2 * s] = *reinterpret_cast<const float4 *>(row + 32 * s + 8 * kg);
         v[2 * s + 1] = *reinterpret_cast<const float4 *>(row + 32 * s + 8 * kg + 4);
     }
+}
+__device__ __forceinline__ void fa_bfrags_split(const float4 (&v)[8], f16x8 (&fr)[4][2], float &inv) {
     float m = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) m = fmaxf(m, fa_absmax4(v[e]));
@@ -222,6 +224,11 @@ __device__ __forceinline__ void fa_load_bfrags(const float *__restrict__ row, in
         fr[s][0] = __builtin_bit_cast(f16x8, uh);
         fr[s][1] = __builtin_bit_cast(f16x8, ul);
     }
+}
+__device__ __forceinline__ void fa_load_bfrags(const float *__restrict__ row, int kg, f16x8 (&fr)[4][2], float &inv) {
+    float4 v[8];
+    fa_bfrags_request(row, kg, v);
+    fa_bfrags_split(v, fr, inv);
 }
 // fragment of LDS row `row` (A operand: the row is the tile row; B operand: the row is the tile column), k = 32 s + 8 kg .. + 7
 __device__ __forceinline__ f16x8 fa_rowfrag(const unsigned short *slot, int pl, int row, int s, int kg) {
@@ -465,6 +472,12 @@ __global__ __launch_bounds__(512, 1) void lvt_attn_fwd_flash_kernel(const FaArgs
 // encoder layer's w_q (tests/test_gpu_vt.py, G12).  The pass therefore also accumulates C_i = sum_j p_ij K_j at fp16 precision
 // (one MFMA per 16 dims on the hi plane of the K^T fragments that dQ loads anyway) and the realised row sum eps_i = sum_j g_ij,
 // returns dQ_i - eps_i C_i / temper, and hands kernel B delta + eps (B then forms g as the two-pass form did).
+#ifndef FA_EARLY_LOADS
+#define FA_EARLY_LOADS 1                    // kernel A (0: its prologue requests q, dO, o one after the other, the round-5 order)
+#endif
+#ifndef FB_EARLY_LOADS
+#define FB_EARLY_LOADS 0                    // kernel B: measured 161.4 / 158.5 -> 164.5 / 160.7 us with it (A: 198.8 / 196.5 -> 196.9 / 192.9)
+#endif
 #ifndef LVT_FA_A_CORR
 #define LVT_FA_A_CORR 1                   // (timing builds: 0 = one pass without the C_i accumulation -- fails G12's w_q bound)
 #endif
@@ -495,8 +508,31 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
     load_item(0, g0);
     f16x8 qb[4][2], dob[4][2];
     float qinv, doinv;
+#if FA_EARLY_LOADS
+    // q, dO and (one pass) the forward's output row of this lane's query are requested TOGETHER, then split: one round of
+    // global-load latency instead of three dependent ones (q -> split, dO -> split, and after the first barrier o / dO again for
+    // delta = dO . O, which reads exactly the 32 columns of the dO fragments)
+    float4 qraw[8], doraw[8], oraw[ONEP ? 8 : 1];
+    fa_bfrags_request(A.q + (row0 + i) * A.ld + h * AT_D, kg, qraw);
+    fa_bfrags_request(A.d_o + (row0 + i) * A.ld + h * AT_D, kg, doraw);
+    if constexpr (ONEP) fa_bfrags_request(A.o + (row0 + i) * A.ld + h * AT_D, kg, oraw);
+    fa_bfrags_split(qraw, qb, qinv);
+    fa_bfrags_split(doraw, dob, doinv);
+    float delta_early = 0.f;
+    if constexpr (ONEP) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const float4 o0 = oraw[2 * s_], o1 = oraw[2 * s_ + 1], d0 = doraw[2 * s_], d1 = doraw[2 * s_ + 1];
+            a0 = fmaf(o0.x, d0.x, a0); a0 = fmaf(o0.y, d0.y, a0); a0 = fmaf(o0.z, d0.z, a0); a0 = fmaf(o0.w, d0.w, a0);
+            a1 = fmaf(o1.x, d1.x, a1); a1 = fmaf(o1.y, d1.y, a1); a1 = fmaf(o1.z, d1.z, a1); a1 = fmaf(o1.w, d1.w, a1);
+        }
+        delta_early = fa_kg_sum(a0 + a1);
+    }
+#else
     fa_load_bfrags(A.q + (row0 + i) * A.ld + h * AT_D, kg, qb, qinv);
     fa_load_bfrags(A.d_o + (row0 + i) * A.ld + h * AT_D, kg, dob, doinv);
+#endif
     const long long si = ((long long)b * A.H + h) * AT_S + i;
     const float m_i = A.m[si], linv = A.l[si];
     const int wi = i % BW, hi = (i / BW) % BH, ti = i / (BW * BH);
@@ -518,6 +554,9 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
     float sgf = 0.f, kmr = 0.f, dl = 0.f;                             // pass 2: scale of g from its bound, 1 / kmax (applied one
                                                                       // after the other: their product can leave the float range), delta / l
     int ebG = FA_EMIN;                                                // ONEP: the running exponent of max |g 2^(e_K - 14)| of this query row
+#if FA_EARLY_LOADS
+    if constexpr (ONEP) { delta = delta_early; dl = delta * linv; }
+#else
     if constexpr (ONEP) {
         // delta_i = dO_i . O_i: the lane's 32 columns (those of its B fragments), then the four lanes of the column
         const float *orow = A.o + (row0 + i) * A.ld + h * AT_D + 8 * kg, *drow = A.d_o + (row0 + i) * A.ld + h * AT_D + 8 * kg;
@@ -532,6 +571,7 @@ __device__ __forceinline__ float fa_bwd_a_body(const FaArgs &A, FaSmemA<BT + Geo
         delta = fa_kg_sum(a0 + a1);
         dl = delta * linv;
     }
+#endif
     f32x4v qacc[AT_D / 16];
 #pragma unroll
     for (int d = 0; d < AT_D / 16; ++d) qacc[d] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -836,20 +876,31 @@ __device__ __forceinline__ float fa_bwd_b_body(const FaArgs &A, FaSmemB &sm, int
     auto load_item = [&](int t, G4 &gg) {
         fa_load(gg, qbase + (long long)(32 * (C0 + t)) * A.ld, dobase + (long long)(32 * (C0 + t)) * A.ld, A.ld, tid);
     };
+    float4 kraw[8];
     {                                   // the workgroup's 128 V rows -> LDS, resident
         const float *rows = A.v + (row0 + khalf * 128) * A.ld + h * AT_D;
         G4 a, bq;
         fa_load(a, rows, rows + 32 * A.ld, A.ld, tid);
         fa_load(bq, rows + 64 * A.ld, rows + 96 * A.ld, A.ld, tid);
+#if FB_EARLY_LOADS
+        // the first Q | dO item and the wave's K rows are requested BEFORE the V rows are split and stored: one round of global-load
+        // latency per workgroup instead of two (four workgroups per CU and launch, nothing beside a prologue to hide it)
+        load_item(0, g0);
+        fa_bfrags_request(A.k + (row0 + j) * A.ld + h * AT_D, kg, kraw);
+#endif
 #ifdef FB_X_NOVSTAGE
         if (A.H < 0)
 #endif
         { fa_park(a, sm.vres[0], sm.vinv[0], tid); fa_park(bq, sm.vres[1], sm.vinv[1], tid); }
     }
-    load_item(0, g0);
     f16x8 kb[4][2];
     float kinv;
+#if FB_EARLY_LOADS
+    fa_bfrags_split(kraw, kb, kinv);
+#else
+    load_item(0, g0);
     fa_load_bfrags(A.k + (row0 + j) * A.ld + h * AT_D, kg, kb, kinv);
+#endif
     // bounds from kernel A (both query halves): exponent of the dO rows, bound of g 2^(e_q - 14)
     const float *sc = A.scal + (long long)bh_ * 4;
     const float domax = fmaxf(sc[0], sc[2]), umax = fmaxf(sc[1], sc[3]);
